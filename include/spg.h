@@ -1,0 +1,265 @@
+/* include/spg.h — C ABI of the MI355X pose-graph sparsification hot path.
+ *
+ * The reference (Lecanyu/SparsifyPoseGraph) has no FFI: its seams are C++ virtual interfaces.
+ * Each entry point below names the reference interface it stands in for (file:line under the
+ * reference tree). The product library libspg_hip.so exports every symbol declared here; the CPU
+ * oracle (oracle/libspg_ref.so, test infrastructure only) exports spg_marginalize_batch and
+ * spg_run_round with the same signatures so parity tests call both through one binding.
+ *
+ * Conventions: plain pointers and sizes; caller owns every buffer it passes; the library owns the
+ * context/graph objects it returns. All arithmetic is fp64, graph indices int32, arena offsets int64
+ * (counted in doubles). Functions return 0 on success or a negative SPG_E* code; they never abort.
+ */
+#ifndef SPG_H_
+#define SPG_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums mirroring reference types ------------------------------------------------------- */
+/* EvaluateInfo::algorithm (src/evaluate.h:20-22) / GraphWrapperG2O(useGLC) (src/graph_wrapper_g2o.cpp:102) */
+enum { SPG_ALG_NFR = 0, SPG_ALG_GLC = 1 };
+/* SparsityOptions::SparsityTopology (src/sparsity_options.h:12-14), same numeric order */
+enum { SPG_TOPO_TREE = 0, SPG_TOPO_SUBGRAPH = 1, SPG_TOPO_CLIQUEY_SUBGRAPH = 2, SPG_TOPO_DENSE = 3,
+       SPG_TOPO_CLIQUEY_DENSE = 4 };
+/* SparsityOptions::LinearizationPoint (src/sparsity_options.h:16-18) */
+enum { SPG_LIN_LOCAL = 0, SPG_LIN_GLOBAL = 1 };
+/* edge kinds: pose-pose edge (EdgeSE2ISAM / EdgeSE3ISAM, src/se2_compatibility.h:20, src/se3_compatibility.h:25)
+ * and n-ary GLC edge (GLCEdge, src/glc_edge.h:14) */
+enum { SPG_EDGE_BINARY = 0, SPG_EDGE_GLC = 1 };
+
+/* per-blanket status (replaces the reference's assert / exit(0) / NULL-edge failure modes,
+ * src/vertex_remover.cpp:291,461, src/optimizer.cpp:75-77, src/topology_provider_glc.cpp:46-49,85-89) */
+enum {
+    SPG_OK = 0,
+    SPG_ST_HMM_NOT_PD = 1,      /* LLT(H_mm) failed (src/vertex_remover.cpp:444) */
+    SPG_ST_EIG_FAIL = 2,        /* eigen-decomposition did not converge */
+    SPG_ST_NONFINITE = 3,       /* non-finite value in the target information */
+    SPG_ST_TIKHONOV_NOT_PD = 4, /* LLT(Lambda + I) failed (src/pseudo_chow_liu.cpp:189) */
+    SPG_ST_CLOSED_FORM_NOT_PD = 5, /* LLT(J Sigma J^T) failed (src/logdet_function.cpp:246,273) */
+    SPG_ST_KLD_NOT_PD = 6,      /* value() returned +inf (src/logdet_function.cpp:130-131); edges still valid */
+    SPG_ST_NEEDS_INTERIOR_POINT = 7, /* no closed form (src/optimizer.cpp:38-79): out of scope, no edges written */
+    SPG_ST_MARGINAL_NOT_PD = 8, /* LLT inside PseudoChowLiu::marginal failed (src/pseudo_chow_liu.cpp:134) */
+    SPG_ST_EMPTY_BLANKET = 9,   /* removed vertex without edges (assert at src/vertex_remover.cpp:291) */
+    SPG_ST_UNSUPPORTED = 10     /* option combination the reference asserts against or that is out of scope */
+};
+/* informational bits OR-ed into status << 8 are not used; see spg_result.info */
+enum {
+    SPG_INFO_RANK_DEFICIENT = 1, /* smalleigs > dim: chooseDimensions path taken (src/logdet_function.cpp:42-59) */
+    SPG_INFO_GLC_ROOT_EDGE = 2   /* a unary GLC root edge survived the 1e-8 cut (src/topology_provider_glc.cpp:134-140) */
+};
+
+enum {
+    SPG_EINVAL = -1, SPG_ENODEV = -2, SPG_ENOMEM = -3, SPG_ECAPACITY = -4, SPG_EHIP = -5, SPG_EIO = -6,
+    SPG_ESTATE = -7, SPG_EBLANKET = -8 /* at least one blanket has status != OK that prevents graph update */
+};
+
+/* SparsityOptions (src/sparsity_options.h:11-30) + algorithm selector + pose dimension */
+typedef struct {
+    int32_t pose_dim;             /* 3 (SE2) or 6 (SE3) */
+    int32_t algorithm;            /* SPG_ALG_* */
+    int32_t topology;             /* SPG_TOPO_* */
+    int32_t lin_point;            /* SPG_LIN_* */
+    int32_t include_intra_clique; /* reference default true; never changed by any caller */
+    int32_t flags;                /* SPG_FLAG_* */
+    double chord_ratio;           /* reference default 1 */
+} spg_options;
+enum { SPG_FLAG_GLC_KLD = 1 /* also evaluate the per-blanket KLD (src/logdet_function.cpp:119-133) for GLC edges */ };
+
+/* One batch of mutually independent Markov blankets in CSR form: the data VertexRemover::remove
+ * gathers per iteration (src/vertex_remover.cpp:93-108): blanket vertices (removed first, then kept
+ * in ascending original id = g2o indexMapping order, src/vertex_remover.cpp:349-356), their
+ * estimates, and every edge with all endpoints in the blanket (src/vertex_remover.cpp:225-251). */
+typedef struct {
+    int32_t B;
+    const int32_t *vert_off;      /* B+1 */
+    const int32_t *n_remove;      /* B : m_b >= 1 */
+    const int32_t *vert_id;       /* V : original ids (only echoed into new_edge_vert) */
+    const double *pose;           /* V x (3 | 7): (x y theta) | (tx ty tz qx qy qz qw) */
+    const int32_t *edge_off;      /* B+1 */
+    const int32_t *edge_kind;     /* E : SPG_EDGE_* */
+    const int32_t *edge_vert_off; /* E+1 */
+    const int32_t *edge_vert;     /* local vertex index inside the blanket */
+    const int64_t *edge_data_off; /* E+1 */
+    const double *edge_data;      /* binary: meas (3|7) + information upper triangle row-wise (6|21)
+                                     GLC   : meas (d*q) + W row-major (r x d*q)  [r = (len-dq)/dq] */
+} spg_batch;
+
+/* Outputs of VertexRemover::remove for the batch: the new edges handed to updateInputGraph
+ * (src/vertex_remover.cpp:500-546), plus the target information (src/vertex_remover.cpp:447-449)
+ * and the per-blanket KLD (src/logdet_function.cpp:119-133). Capacities are supplied by the caller. */
+typedef struct {
+    double *target_info;          /* optional (NULL to skip): blanket b at target_info_off[b], n_b x n_b row-major */
+    const int64_t *target_info_off; /* B+1 when target_info != NULL */
+    int32_t *new_edge_off;        /* B+1, written */
+    int32_t *new_edge_kind;       /* new_edge_cap */
+    int32_t *new_edge_vert_off;   /* new_edge_cap+1 */
+    int32_t *new_edge_vert;       /* ORIGINAL ids, new_edge_vert_cap */
+    int64_t *new_edge_data_off;   /* new_edge_cap+1 */
+    double *new_edge_data;        /* same record layout as spg_batch.edge_data */
+    int32_t new_edge_cap, new_edge_vert_cap;
+    int64_t new_edge_data_cap;
+    double *kld;                  /* B */
+    double *min_gap;              /* B, optional: smallest relative gap between consecutive Chow-Liu weights popped */
+    int32_t *status;              /* B : SPG_ST_* */
+    int32_t *info;                /* B, optional: SPG_INFO_* bits */
+} spg_result;
+
+/* ---- context ------------------------------------------------------------------------------ */
+typedef struct spg_ctx spg_ctx;
+/* one context per (host thread, device); owns a HIP stream and scratch. device = HIP ordinal.
+ * Fails with SPG_ENODEV when no gfx950 device / code object is available: there is no CPU fallback. */
+int spg_ctx_create(spg_ctx **out, int device);
+void spg_ctx_destroy(spg_ctx *ctx);
+const char *spg_last_error(spg_ctx *ctx);
+/* HIP stream the context launches on (hipStream_t as void*), for event timing by the caller */
+void *spg_ctx_stream(spg_ctx *ctx);
+int spg_ctx_synchronize(spg_ctx *ctx);
+
+/* VertexRemover::remove restricted to its arithmetic, for B independent blankets at once
+ * (replaces src/vertex_remover.cpp:108-132 + src/topology_provider_binary.hpp:23-70 +
+ *  src/topology_provider_glc.cpp:100-185 + src/optimizer.cpp:16-22). Host pointers. */
+int spg_marginalize_batch(spg_ctx *ctx, const spg_options *opts, const spg_batch *batch, spg_result *result);
+
+/* ---- decimation (src/decimation.h:18-22, src/decimation.cpp:11-49) -------------------------- */
+/* Each writes at most cap ids into out and returns the count (or the required count if > cap). */
+int spg_decimate_global(int last, int endvert, int sparsity, int cluster_size, int32_t *out, int cap);
+int spg_decimate_online(int last, int endvert, int sparsity, int cluster_size, int32_t *out, int cap);
+int spg_decimate_cluster(int last, int endvert, int sparsity, int cluster_size, int32_t *out, int cap);
+
+/* ---- device-resident graph: GraphWrapper (src/graph_wrapper.h:17-78) ------------------------- */
+typedef struct spg_graph spg_graph;
+
+/* GraphWrapperG2O(verbose,useGLC) (src/graph_wrapper_g2o.cpp:102): empty graph of SE2 (3) or SE3 (6) poses */
+int spg_graph_create(spg_ctx *ctx, int pose_dim, spg_graph **out);
+void spg_graph_destroy(spg_graph *g);
+/* GraphWrapperG2O(fname, optimize=false, ...) (src/graph_wrapper_g2o.cpp:107-154), .g2o text:
+ * VERTEX_SE2 / EDGE_SE2 / VERTEX_SE3:QUAT / EDGE_SE3:QUAT. No optimisation (LM is out of scope). */
+int spg_graph_load_g2o(spg_ctx *ctx, const char *path, spg_graph **out);
+/* GraphWrapper::write (src/graph_wrapper_g2o.cpp:467-470) incl. GLC_EDGE records (src/glc_edge.cpp:95-119) */
+int spg_graph_write_g2o(spg_graph *g, const char *path);
+/* addVertex / addEdge (src/graph_wrapper_g2o.cpp:214-247). pose/meas as in spg_batch; info = upper triangle */
+int spg_graph_add_vertex(spg_graph *g, int id, const double *pose);
+int spg_graph_add_edge(spg_graph *g, int from, int to, const double *meas, const double *info_upper);
+/* n-ary GLC edge (GLCEdge::read, src/glc_edge.cpp:64-93) */
+int spg_graph_add_glc_edge(spg_graph *g, int q, const int32_t *ids, int r, const double *meas, const double *W);
+int spg_graph_pose_dim(const spg_graph *g);
+int spg_graph_num_vertices(const spg_graph *g);
+int spg_graph_num_edges(const spg_graph *g);
+int64_t spg_graph_edge_data_size(const spg_graph *g); /* total doubles of all live edge records */
+int64_t spg_graph_edge_vert_size(const spg_graph *g); /* total endpoints of all live edges */
+/* vertices() / vertex(id)->estimate() (src/graph_wrapper.h:70-72): ids ascending, poses V x (3|7) */
+int spg_graph_get_vertices(spg_graph *g, int32_t *ids, double *poses);
+/* all live edges in insertion order; arrays sized from the three counters above (+1 for offsets) */
+int spg_graph_get_edges(spg_graph *g, int32_t *kind, int32_t *vert_off, int32_t *vert_ids,
+                        int64_t *data_off, double *data);
+/* setEstimate (src/graph_wrapper_g2o.cpp:614-621) */
+int spg_graph_set_estimate(spg_graph *g, int id, const double *pose);
+
+typedef struct {
+    int32_t n_removed;     /* vertices actually marginalised */
+    int32_t n_rounds;      /* conflict-free rounds executed */
+    int32_t n_new_edges;
+    int32_t n_bad_status;  /* blankets with a status that is not SPG_OK / SPG_ST_KLD_NOT_PD */
+    int32_t max_blanket;   /* largest k+m */
+    int32_t n_launches;    /* kernel launches */
+    double kld_sum;        /* sum of finite per-blanket KLD */
+    double host_seconds;   /* host scheduling + graph update */
+    double device_seconds; /* time blocked on the device (launch -> results visible) */
+} spg_marg_stats;
+
+/* GraphWrapperG2O::marginalizeNoOptimize (src/graph_wrapper_g2o.cpp:398-453): removes `which` with
+ * the sequential semantics of VertexRemover::remove (src/vertex_remover.cpp:83-140), executed as
+ * conflict-free rounds of independent blankets on the device. Does NOT run optimize()
+ * (src/graph_wrapper_g2o.cpp:462) — LM is outside the accelerated path. */
+int spg_graph_marginalize(spg_graph *g, const int32_t *which, int n, const spg_options *opts,
+                          spg_marg_stats *stats);
+/* per-removed-vertex diagnostics of the last marginalize call, in processing order */
+int spg_graph_last_blanket_count(const spg_graph *g);
+int spg_graph_last_blankets(const spg_graph *g, int32_t *root_id, int32_t *round, int32_t *status,
+                            int32_t *info, double *kld, double *min_gap);
+
+/* ---- round-stepping form of the same call, for multi-GPU sharding ---------------------------
+ * All ranks hold a replica and run the same deterministic scheduler; rank r computes its slice of
+ * each round's blankets; the caller exchanges the round's output region of the arena between
+ * ranks (one all-gather over RCCL/xGMI) between compute and commit. */
+typedef struct {
+    int32_t n_blankets;       /* blankets scheduled in this round (all ranks) */
+    int32_t my_first, my_count; /* this rank's slice */
+    int64_t region_off;       /* arena offset (doubles) of the round's output region */
+    int64_t chunk_len;        /* doubles per rank chunk; region = nranks * chunk_len, rank r owns chunk r */
+} spg_round_info;
+int spg_graph_marginalize_begin(spg_graph *g, const int32_t *which, int n, const spg_options *opts,
+                                int rank, int nranks);
+/* returns 1 if a round was prepared (info filled), 0 when the removal list is exhausted */
+int spg_graph_round_prepare(spg_graph *g, spg_round_info *info);
+int spg_graph_round_compute(spg_graph *g);   /* asynchronous on the context stream */
+int spg_graph_round_commit(spg_graph *g);    /* waits, reads back the region, applies the graph update */
+int spg_graph_marginalize_end(spg_graph *g, spg_marg_stats *stats);
+/* device (or, for an injected backend, host) address of the arena and its capacity in doubles;
+ * the arena may be re-allocated by add_* calls but never between begin and end */
+void *spg_graph_arena(spg_graph *g, int64_t *capacity);
+/* reserve arena capacity up front (doubles) so the address stays fixed */
+int spg_graph_reserve(spg_graph *g, int64_t arena_doubles);
+
+/* ---- compute backend ------------------------------------------------------------------------
+ * The device side of a round, as the product's HIP backend implements it and as a test may inject
+ * it (spg_ctx_create_injected): tests/ use this to run the host scheduler and the multi-rank
+ * exchange on CPU-only machines with oracle/libspg_ref.so as the arithmetic. The product never
+ * injects anything: spg_ctx_create always binds the HIP backend and fails without a device. */
+typedef struct {
+    int32_t vert_begin, n_vert, n_remove; /* into vert_pose_off[] */
+    int32_t edge_begin, n_edge;           /* into edge refs */
+    int32_t n_new_max;                    /* most new edges this blanket can emit */
+    int32_t n_new_vert_max;               /* most endpoints over all its new edges */
+    int32_t pad_;
+    int64_t new_off;                      /* arena offset where new-edge records are packed */
+    int64_t new_len;                      /* doubles reserved at new_off */
+    int64_t out_off;                      /* arena offset of the per-blanket output record */
+    int64_t tinfo_off;                    /* arena offset for the target information, or -1 */
+} spg_blanket_desc;
+typedef struct {
+    int64_t off;    /* arena offset of the edge record */
+    int32_t len;    /* record length in doubles */
+    int32_t kind;   /* SPG_EDGE_* */
+    int32_t vbegin; /* into edge_vert[] (local blanket indices) */
+    int32_t nv;
+} spg_edge_ref;
+/* per-blanket output record layout (doubles) at out_off:
+ *   [0] status  [1] info bits  [2] kld  [3] min_gap  [4] n_new
+ *   then per new edge e < n_new: [5+4e] kind  [6+4e] record offset relative to new_off
+ *                                [7+4e] record length  [8+4e] nv
+ *   then, starting at 5 + 4*n_new_max: the local vertex indices of the new edges, concatenated
+ * record length = SPG_OUT_LEN(n_new_max, n_new_vert_max) */
+#define SPG_OUT_HDR 5
+#define SPG_OUT_LEN(n_new_max, n_new_vert_max) (SPG_OUT_HDR + 4 * (n_new_max) + (n_new_vert_max))
+typedef struct {
+    const spg_options *opts;
+    int32_t n_blankets, first, count;    /* compute blankets [first, first+count) */
+    const spg_blanket_desc *blankets;    /* n_blankets */
+    const int64_t *vert_pose_off;        /* arena offsets of the blanket vertices' poses */
+    const spg_edge_ref *edges;
+    const int32_t *edge_vert;
+    int64_t n_vert_total, n_edge_total, n_edge_vert_total;
+} spg_round_desc;
+typedef struct {
+    void *user;
+    void *(*alloc)(void *user, int64_t doubles);
+    void (*release)(void *user, void *p);
+    int (*upload)(void *user, void *dst, const double *src, int64_t doubles);   /* host -> arena */
+    int (*download)(void *user, double *dst, const void *src, int64_t doubles); /* arena -> host */
+    int (*run_round)(void *user, void *arena, const spg_round_desc *round);     /* may be asynchronous */
+    int (*synchronize)(void *user);
+} spg_backend;
+int spg_ctx_create_injected(spg_ctx **out, const spg_backend *backend);
+
+/* oracle-side twin of run_round on host memory (exported by oracle/libspg_ref.so only) */
+int spg_run_round(double *arena, const spg_round_desc *round);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPG_H_ */

@@ -1,0 +1,438 @@
+// oracle/spg_ref.cpp — C entry points of the CPU oracle (libspg_ref.so).
+//
+// TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+// leg as the checker / reported baseline; never linked or loaded by the product path.
+// PARITY UNPINNED: no reference-owned golden vector exists for this path and the reference cannot be
+// built in this container (Eigen, g2o, iSAM, CHOLMOD absent) — see DESIGN.md "Oracle".
+//
+// Exports
+//   spg_marginalize_batch / spg_run_round   same signatures as include/spg.h (ctx ignored)
+//   spgref_graph_*                          literal, strictly sequential restatement of
+//                                           GraphWrapperG2O::marginalizeNoOptimize -> VertexRemover::remove
+//                                           (src/graph_wrapper_g2o.cpp:398-453, src/vertex_remover.cpp:83-251,500-546)
+//   spgref_* unit functions                 so tests can pin the building blocks against numpy
+#include <chrono>
+#include <cstdio>
+#include <map>
+#include <set>
+#include <thread>
+#include "ref_blanket.hpp"
+
+using namespace spgref;
+
+// ------------------------------------------------------------------------------ batch entry
+extern "C" int spg_marginalize_batch(spg_ctx *, const spg_options *o, const spg_batch *b, spg_result *r) {
+    if (!o || !b || !r) return SPG_EINVAL;
+    int d = o->pose_dim, ps = pose_stride(d);
+    int32_t ne = 0, nev = 0;
+    int64_t ned = 0;
+    r->new_edge_off[0] = 0;
+    r->new_edge_vert_off[0] = 0;
+    r->new_edge_data_off[0] = 0;
+    for (int bi = 0; bi < b->B; bi++) {
+        BlanketIn in;
+        in.d = d;
+        in.nv = b->vert_off[bi + 1] - b->vert_off[bi];
+        in.m = b->n_remove[bi];
+        in.pose = b->pose + (size_t)b->vert_off[bi] * ps;
+        for (int e = b->edge_off[bi]; e < b->edge_off[bi + 1]; e++) {
+            EdgeIn ei;
+            ei.kind = b->edge_kind[e];
+            for (int v = b->edge_vert_off[e]; v < b->edge_vert_off[e + 1]; v++) ei.v.push_back(b->edge_vert[v]);
+            ei.data = b->edge_data + b->edge_data_off[e];
+            ei.len = b->edge_data_off[e + 1] - b->edge_data_off[e];
+            in.edges.push_back(ei);
+        }
+        BlanketOut out = run_blanket(*o, in);
+        r->status[bi] = out.status;
+        if (r->info) r->info[bi] = out.info;
+        r->kld[bi] = out.kld;
+        if (r->min_gap) r->min_gap[bi] = out.min_gap;
+        if (r->target_info && out.target.r > 0) {
+            double *dst = r->target_info + r->target_info_off[bi];
+            std::memcpy(dst, out.target.a.data(), out.target.a.size() * sizeof(double));
+        }
+        for (const NewEdge &e : out.edges) {
+            if (ne + 1 > r->new_edge_cap || nev + (int)e.v.size() > r->new_edge_vert_cap ||
+                ned + (int64_t)e.data.size() > r->new_edge_data_cap)
+                return SPG_ECAPACITY;
+            r->new_edge_kind[ne] = e.kind;
+            for (int v : e.v) r->new_edge_vert[nev++] = b->vert_id[b->vert_off[bi] + v];
+            std::memcpy(r->new_edge_data + ned, e.data.data(), e.data.size() * sizeof(double));
+            ned += (int64_t)e.data.size();
+            ne++;
+            r->new_edge_vert_off[ne] = nev;
+            r->new_edge_data_off[ne] = ned;
+        }
+        r->new_edge_off[bi + 1] = ne;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ round entry
+extern "C" int spg_run_round(double *arena, const spg_round_desc *rd) {
+    const spg_options &o = *rd->opts;
+    int d = o.pose_dim, ps = pose_stride(d);
+    for (int bi = rd->first; bi < rd->first + rd->count; bi++) {
+        const spg_blanket_desc &bd = rd->blankets[bi];
+        std::vector<double> poses((size_t)bd.n_vert * ps);
+        for (int v = 0; v < bd.n_vert; v++)
+            std::memcpy(&poses[(size_t)v * ps], arena + rd->vert_pose_off[bd.vert_begin + v], ps * sizeof(double));
+        BlanketIn in;
+        in.d = d; in.nv = bd.n_vert; in.m = bd.n_remove; in.pose = poses.data();
+        for (int e = bd.edge_begin; e < bd.edge_begin + bd.n_edge; e++) {
+            const spg_edge_ref &er = rd->edges[e];
+            EdgeIn ei;
+            ei.kind = er.kind;
+            for (int v = 0; v < er.nv; v++) ei.v.push_back(rd->edge_vert[er.vbegin + v]);
+            ei.data = arena + er.off;
+            ei.len = er.len;
+            in.edges.push_back(ei);
+        }
+        BlanketOut out = run_blanket(o, in);
+        double *rec = arena + bd.out_off;
+        int64_t reclen = SPG_OUT_LEN(bd.n_new_max, bd.n_new_vert_max);
+        for (int64_t i = 0; i < reclen; i++) rec[i] = 0;
+        rec[0] = out.status; rec[1] = out.info; rec[2] = out.kld; rec[3] = out.min_gap;
+        int nn = 0, nvv = 0;
+        int64_t off = 0;
+        for (const NewEdge &e : out.edges) {
+            if (nn >= bd.n_new_max || nvv + (int)e.v.size() > bd.n_new_vert_max || off + (int64_t)e.data.size() > bd.new_len)
+                return SPG_ECAPACITY;
+            rec[SPG_OUT_HDR + 4 * nn + 0] = e.kind;
+            rec[SPG_OUT_HDR + 4 * nn + 1] = (double)off;
+            rec[SPG_OUT_HDR + 4 * nn + 2] = (double)e.data.size();
+            rec[SPG_OUT_HDR + 4 * nn + 3] = (double)e.v.size();
+            for (int v : e.v) rec[SPG_OUT_HDR + 4 * bd.n_new_max + nvv++] = v;
+            std::memcpy(arena + bd.new_off + off, e.data.data(), e.data.size() * sizeof(double));
+            off += (int64_t)e.data.size();
+            nn++;
+        }
+        rec[4] = nn;
+        if (bd.tinfo_off >= 0 && out.target.r > 0)
+            std::memcpy(arena + bd.tinfo_off, out.target.a.data(), out.target.a.size() * sizeof(double));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ sequential graph
+namespace {
+struct REdge {
+    int kind;
+    std::vector<int> ids;
+    std::vector<double> data;
+    bool alive;
+};
+struct RBlanketLog { int root, status, info; double kld, min_gap; int k; };
+struct RGraph {
+    int d;
+    std::map<int, std::vector<double>> pose;  // id -> estimate
+    std::map<int, std::set<int>> adj;         // id -> live edge indices
+    std::vector<REdge> edges;
+    std::vector<RBlanketLog> log;
+    double seconds = 0;
+};
+
+// markovBlanketVertices (src/vertex_remover.cpp:197-215)
+std::set<int> blanket_vertices(const RGraph &g, int root) {
+    std::set<int> vs;
+    vs.insert(root);
+    for (int e : g.adj.at(root)) for (int id : g.edges[e].ids) vs.insert(id);
+    return vs;
+}
+
+// extendedMarkovBlanketVertices, active (#else) branch (src/vertex_remover.cpp:142-195): one ascending
+// pass over the growing id-ordered set.
+std::set<int> extended_blanket_vertices(const RGraph &g, int root, const std::set<int> &pickBin, std::set<int> &picked) {
+    picked.clear();
+    std::set<int> ret = blanket_vertices(g, root);
+    picked.insert(root);
+    for (auto it = ret.begin(); it != ret.end(); ++it) {
+        int v = *it;
+        if (pickBin.count(v) > 0 && picked.count(v) == 0) {
+            picked.insert(v);
+            std::set<int> other = blanket_vertices(g, v);
+            ret.insert(other.begin(), other.end());
+        }
+    }
+    return ret;
+}
+
+// markovBlanketEdges (src/vertex_remover.cpp:225-251)
+std::set<int> blanket_edges(const RGraph &g, const std::set<int> &vs, const std::set<int> &hubs, bool intra) {
+    std::set<int> es;
+    for (int v : vs)
+        for (int e : g.adj.at(v)) {
+            bool is_markov = true, found_hub = false;
+            for (int id : g.edges[e].ids) {
+                if (vs.count(id) == 0) { is_markov = false; break; }
+                if (hubs.count(id) > 0) found_hub = true;
+            }
+            if (is_markov && (intra || found_hub)) es.insert(e);
+        }
+    return es;
+}
+}  // namespace
+
+extern "C" {
+
+void *spgref_graph_create(int pose_dim) {
+    RGraph *g = new RGraph;
+    g->d = pose_dim;
+    return g;
+}
+void spgref_graph_destroy(void *h) { delete (RGraph *)h; }
+
+int spgref_graph_add_vertex(void *h, int id, const double *pose) {
+    RGraph *g = (RGraph *)h;
+    int ps = pose_stride(g->d);
+    g->pose[id] = std::vector<double>(pose, pose + ps);
+    g->adj[id];
+    return 0;
+}
+
+int spgref_graph_add_edge(void *h, int kind, int nv, const int32_t *ids, const double *data, int64_t len) {
+    RGraph *g = (RGraph *)h;
+    REdge e;
+    e.kind = kind;
+    e.ids.assign(ids, ids + nv);
+    e.data.assign(data, data + len);
+    e.alive = true;
+    for (int i = 0; i < nv; i++) if (!g->pose.count(ids[i])) return SPG_EINVAL;
+    int idx = (int)g->edges.size();
+    g->edges.push_back(e);
+    for (int i = 0; i < nv; i++) g->adj[ids[i]].insert(idx);
+    return 0;
+}
+
+// VertexRemover::remove (src/vertex_remover.cpp:83-140), strictly sequential.
+int spgref_graph_marginalize(void *h, const int32_t *which, int n, const spg_options *o) {
+    RGraph *g = (RGraph *)h;
+    auto t0 = std::chrono::steady_clock::now();
+    int d = g->d, ps = pose_stride(d);
+    std::set<int> toRemoveSet(which, which + n), deleted;
+    g->log.clear();
+    int rc = 0;
+    for (int i = 0; i < n; i++) {
+        int root = which[i];
+        if (deleted.count(root)) continue;
+        if (!g->pose.count(root)) return SPG_EINVAL;
+        std::set<int> vmarkov, toRemoveNow;
+        if (o->topology == SPG_TOPO_DENSE || o->topology == SPG_TOPO_CLIQUEY_DENSE) {
+            vmarkov = extended_blanket_vertices(*g, root, toRemoveSet, toRemoveNow);
+        } else {
+            vmarkov = blanket_vertices(*g, root);
+            toRemoveNow.insert(root);
+        }
+        std::set<int> emarkov = blanket_edges(*g, vmarkov, toRemoveNow, o->include_intra_clique != 0);
+        // buildSubgraph (src/vertex_remover.cpp:349-361): removed first, then kept, both ascending id
+        std::vector<int> order(toRemoveNow.begin(), toRemoveNow.end());
+        for (int v : vmarkov) if (!toRemoveNow.count(v)) order.push_back(v);
+        std::map<int, int> local;
+        for (size_t k = 0; k < order.size(); k++) local[order[k]] = (int)k;
+        std::vector<double> poses(order.size() * ps);
+        for (size_t k = 0; k < order.size(); k++) std::memcpy(&poses[k * ps], g->pose[order[k]].data(), ps * sizeof(double));
+        BlanketIn in;
+        in.d = d; in.nv = (int)order.size(); in.m = (int)toRemoveNow.size(); in.pose = poses.data();
+        for (int e : emarkov) {
+            EdgeIn ei;
+            ei.kind = g->edges[e].kind;
+            for (int id : g->edges[e].ids) ei.v.push_back(local[id]);
+            ei.data = g->edges[e].data.data();
+            ei.len = (int64_t)g->edges[e].data.size();
+            in.edges.push_back(ei);
+        }
+        BlanketOut out = run_blanket(*o, in);
+        g->log.push_back({root, out.status, out.info, out.kld, out.min_gap, in.nv - in.m});
+        bool fatal = !(out.status == SPG_OK || out.status == SPG_ST_KLD_NOT_PD);
+        if (fatal) { rc = SPG_EBLANKET; break; }
+        // updateInputGraph (src/vertex_remover.cpp:500-546)
+        for (int e : emarkov) {
+            g->edges[e].alive = false;
+            for (int id : g->edges[e].ids) g->adj[id].erase(e);
+        }
+        for (int v : toRemoveNow) { g->pose.erase(v); g->adj.erase(v); }
+        for (const NewEdge &ne : out.edges) {
+            REdge e;
+            e.kind = ne.kind;
+            for (int v : ne.v) e.ids.push_back(order[v]);
+            e.data = ne.data;
+            e.alive = true;
+            int idx = (int)g->edges.size();
+            g->edges.push_back(e);
+            for (int id : e.ids) g->adj[id].insert(idx);
+        }
+        deleted.insert(toRemoveNow.begin(), toRemoveNow.end());
+    }
+    g->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+double spgref_graph_last_seconds(void *h) { return ((RGraph *)h)->seconds; }
+int spgref_graph_num_vertices(void *h) { return (int)((RGraph *)h)->pose.size(); }
+int spgref_graph_num_edges(void *h) {
+    int c = 0;
+    for (auto &e : ((RGraph *)h)->edges) c += e.alive;
+    return c;
+}
+int64_t spgref_graph_edge_data_size(void *h) {
+    int64_t c = 0;
+    for (auto &e : ((RGraph *)h)->edges) if (e.alive) c += (int64_t)e.data.size();
+    return c;
+}
+int64_t spgref_graph_edge_vert_size(void *h) {
+    int64_t c = 0;
+    for (auto &e : ((RGraph *)h)->edges) if (e.alive) c += (int64_t)e.ids.size();
+    return c;
+}
+int spgref_graph_get_vertices(void *h, int32_t *ids, double *poses) {
+    RGraph *g = (RGraph *)h;
+    int ps = pose_stride(g->d), k = 0;
+    for (auto &kv : g->pose) {
+        ids[k] = kv.first;
+        std::memcpy(poses + (size_t)k * ps, kv.second.data(), ps * sizeof(double));
+        k++;
+    }
+    return k;
+}
+int spgref_graph_get_edges(void *h, int32_t *kind, int32_t *vert_off, int32_t *vert_ids, int64_t *data_off, double *data) {
+    RGraph *g = (RGraph *)h;
+    int ne = 0, nv = 0;
+    int64_t nd = 0;
+    vert_off[0] = 0; data_off[0] = 0;
+    for (auto &e : g->edges) {
+        if (!e.alive) continue;
+        kind[ne] = e.kind;
+        for (int id : e.ids) vert_ids[nv++] = id;
+        std::memcpy(data + nd, e.data.data(), e.data.size() * sizeof(double));
+        nd += (int64_t)e.data.size();
+        ne++;
+        vert_off[ne] = nv; data_off[ne] = nd;
+    }
+    return ne;
+}
+int spgref_graph_last_blanket_count(void *h) { return (int)((RGraph *)h)->log.size(); }
+int spgref_graph_last_blankets(void *h, int32_t *root, int32_t *status, int32_t *info, double *kld, double *min_gap, int32_t *k) {
+    RGraph *g = (RGraph *)h;
+    for (size_t i = 0; i < g->log.size(); i++) {
+        root[i] = g->log[i].root; status[i] = g->log[i].status; info[i] = g->log[i].info;
+        kld[i] = g->log[i].kld; min_gap[i] = g->log[i].min_gap; k[i] = g->log[i].k;
+    }
+    return (int)g->log.size();
+}
+
+// Batch entry spread over host threads (cpu_baseline "B": same rounds, all cores). Blankets are
+// independent; outputs are produced per thread and stitched in order.
+int spgref_marginalize_batch_mt(const spg_options *o, const spg_batch *b, spg_result *r, int nthreads) {
+    if (nthreads <= 1) return spg_marginalize_batch(nullptr, o, b, r);
+    int d = o->pose_dim, ps = pose_stride(d);
+    std::vector<BlanketOut> outs(b->B);
+    auto work = [&](int t) {
+        for (int bi = t; bi < b->B; bi += nthreads) {
+            BlanketIn in;
+            in.d = d;
+            in.nv = b->vert_off[bi + 1] - b->vert_off[bi];
+            in.m = b->n_remove[bi];
+            in.pose = b->pose + (size_t)b->vert_off[bi] * ps;
+            for (int e = b->edge_off[bi]; e < b->edge_off[bi + 1]; e++) {
+                EdgeIn ei;
+                ei.kind = b->edge_kind[e];
+                for (int v = b->edge_vert_off[e]; v < b->edge_vert_off[e + 1]; v++) ei.v.push_back(b->edge_vert[v]);
+                ei.data = b->edge_data + b->edge_data_off[e];
+                ei.len = b->edge_data_off[e + 1] - b->edge_data_off[e];
+                in.edges.push_back(ei);
+            }
+            outs[bi] = run_blanket(*o, in);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back(work, t);
+    for (auto &t : th) t.join();
+    int32_t ne = 0, nev = 0;
+    int64_t ned = 0;
+    r->new_edge_off[0] = 0; r->new_edge_vert_off[0] = 0; r->new_edge_data_off[0] = 0;
+    for (int bi = 0; bi < b->B; bi++) {
+        BlanketOut &out = outs[bi];
+        r->status[bi] = out.status;
+        if (r->info) r->info[bi] = out.info;
+        r->kld[bi] = out.kld;
+        if (r->min_gap) r->min_gap[bi] = out.min_gap;
+        if (r->target_info && out.target.r > 0)
+            std::memcpy(r->target_info + r->target_info_off[bi], out.target.a.data(), out.target.a.size() * sizeof(double));
+        for (const NewEdge &e : out.edges) {
+            if (ne + 1 > r->new_edge_cap || nev + (int)e.v.size() > r->new_edge_vert_cap ||
+                ned + (int64_t)e.data.size() > r->new_edge_data_cap)
+                return SPG_ECAPACITY;
+            r->new_edge_kind[ne] = e.kind;
+            for (int v : e.v) r->new_edge_vert[nev++] = b->vert_id[b->vert_off[bi] + v];
+            std::memcpy(r->new_edge_data + ned, e.data.data(), e.data.size() * sizeof(double));
+            ned += (int64_t)e.data.size();
+            ne++;
+            r->new_edge_vert_off[ne] = nev;
+            r->new_edge_data_off[ne] = ned;
+        }
+        r->new_edge_off[bi + 1] = ne;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ unit functions
+void spgref_se2_edge(const double *xi, const double *xj, const double *z, double *err, double *Ji, double *Jj) {
+    se2_edge(xi, xj, z, err, Ji, Jj);
+}
+void spgref_se3_edge(const double *xi, const double *xj, const double *z, double *err, double *Ji, double *Jj) {
+    se3_edge(iso_from_tq(xi), iso_from_tq(xj), iso_from_tq(z), err, Ji, Jj);
+}
+// error after X <- X * fromVectorMQT(delta) on either endpoint (finite-difference checks)
+void spgref_se3_error_perturbed(const double *xi, const double *xj, const double *z, const double *di, const double *dj, double *err) {
+    Iso3 Xi = se3_oplus(iso_from_tq(xi), di), Xj = se3_oplus(iso_from_tq(xj), dj);
+    se3_edge(Xi, Xj, iso_from_tq(z), err, nullptr, nullptr);
+}
+void spgref_se3_between(const double *xi, const double *xj, double *z) {
+    iso_to_tq(iso_mul(iso_inv(iso_from_tq(xi)), iso_from_tq(xj)), z);
+}
+void spgref_se2_between(const double *xi, const double *xj, double *z) { se2_between(xi, xj, z); }
+int spgref_chol(int n, const double *A, double *L) {
+    Mat M(n, n);
+    std::memcpy(M.a.data(), A, sizeof(double) * n * n);
+    bool ok = chol_lower(M);
+    std::memcpy(L, M.a.data(), sizeof(double) * n * n);
+    return ok ? 0 : 1;
+}
+int spgref_eigh(int n, const double *A, double *w, double *V) {
+    Mat M(n, n), Vm;
+    std::memcpy(M.a.data(), A, sizeof(double) * n * n);
+    std::vector<double> ww;
+    bool ok = jacobi_eigh(M, ww, Vm);
+    std::memcpy(w, ww.data(), sizeof(double) * n);
+    std::memcpy(V, Vm.a.data(), sizeof(double) * n * n);
+    return ok ? 0 : 1;
+}
+int spgref_lu_inverse(int n, const double *A, double *X) {
+    Mat M(n, n);
+    std::memcpy(M.a.data(), A, sizeof(double) * n * n);
+    bool ok;
+    Mat I = lu_inverse(M, ok);
+    std::memcpy(X, I.a.data(), sizeof(double) * n * n);
+    return ok ? 0 : 1;
+}
+double spgref_spd_logdet(int n, const double *A) {
+    Mat M(n, n);
+    std::memcpy(M.a.data(), A, sizeof(double) * n * n);
+    bool ok;
+    double v = spd_logdet(M, ok);
+    return ok ? v : NAN;
+}
+// GLCReparamBinary: err (d*q) and J (dq x dq) for q poses (q x ps) with measurement meas (d*q, may be NULL)
+void spgref_glc_reparam(int d, int q, const double *poses, const double *meas, double *err, double *J) {
+    int ps = pose_stride(d);
+    std::vector<const double *> pp(q);
+    for (int i = 0; i < q; i++) pp[i] = poses + (size_t)i * ps;
+    std::vector<double> e;
+    Mat Jm;
+    glc_reparam(d, q, pp.data(), meas, &e, &Jm);
+    std::memcpy(err, e.data(), sizeof(double) * d * q);
+    std::memcpy(J, Jm.a.data(), sizeof(double) * d * q * d * q);
+}
+
+}  // extern "C"
