@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py — nodes marginalised per second on the synthetic 100k-pose SE3 graph (BASELINE.json).
+
+One "step" = one full GraphWrapper::marginalizeNoOptimize of the globalDecimate(sparsity 2) removal
+list (49 998 vertices) on a fresh, HBM-resident replica of the graph: host scheduling of the
+conflict-free rounds + the per-blanket HIP kernel + graph update. Inputs (poses + edge records) are
+resident in HBM before the timed region starts; per round only int descriptors go up and the
+per-blanket output records come back.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds a replica, each
+round's blankets are sharded over the ranks and one all-gather (RCCL over xGMI) per round exchanges
+the recovered edge records — total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel,
+HIP-event timed on its own stream) and, at N = 1, `cpu_baseline` (the CPU oracle, 1 core).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 vector
+FLOP_PER_NODE_K4 = 240e3   # SURVEY.md 8d estimate for the k=4 SE3 blanket
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--poses", type=int, default=100000)
+    ap.add_argument("--ring", type=int, default=400)
+    ap.add_argument("--sparsity", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-poses", type=int, default=0, help="0 = full workload")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = f"cuda:{local_rank}"
+
+    from sparsifyposegraph_amd import abi, g2o_io
+    from sparsifyposegraph_amd.graph import DecimateOptions, GraphWrapperHIP, globalDecimate
+    from sparsifyposegraph_amd.lib import Context
+    from sparsifyposegraph_amd.parallel import marginalize_sharded
+
+    ctx = Context(local_rank)  # raises without a gfx950 device: no CPU fallback
+    g = g2o_io.synth_sphere(n_poses=args.poses, ring=args.ring)
+    last = int(g["ids"][-1])
+    which = np.array(globalDecimate(last, last, DecimateOptions(args.sparsity)), np.int32)
+    opts = abi.make_options(6, abi.ALG_NFR, abi.TOPO_TREE, abi.LIN_GLOBAL)
+
+    n_rep = args.warmup + args.steps
+    arena_need = int(len(g["ids"]) * 7 + len(g["edge_ij"]) * 28) * 3
+    replicas = []
+    for _ in range(n_rep):
+        hg = GraphWrapperHIP.from_dict(g, ctx=ctx)
+        hg.reserve(arena_need)  # uploads poses + edge records: resident in HBM before timing
+        replicas.append(hg)
+
+    def run(hg):
+        if world > 1:
+            return marginalize_sharded(hg, which, opts, device=device)
+        return hg.marginalizeNoOptimize(which, opts)
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        run(replicas[i])
+    fence()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    stats = None
+    for i in range(args.steps):
+        stats = run(replicas[args.warmup + i])
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    removed = stats["n_removed"]
+    value = removed * args.steps / dt
+    out = {
+        "metric": "nodes_marginalized_per_s", "value": value, "unit": "nodes/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"synthetic SE3 sphere-spiral pose graph, {args.poses} poses ({args.poses // args.ring} rings x {args.ring}), "
+                        f"{len(g['edge_ij'])} edges, NFR Tree, Global linearisation point = stored estimates, "
+                        f"globalDecimate sparsity {args.sparsity} ({len(which)} removals), marginalizeNoOptimize only",
+            "parallelism": "single GPU" if world == 1 else f"replicated graph, blankets of each round sharded over {world} GPUs, 1 all-gather/round",
+            "rounds": stats["n_rounds"], "removed": removed, "max_blanket": stats["max_blanket"],
+            "kld_sum": stats["kld_sum"], "host_seconds_per_step": stats["host_seconds"], "device_wait_seconds_per_step": stats["device_seconds"],
+        },
+    }
+    if prof["launches"] > 0 and prof["kernel_ms"] > 0:
+        per_launch_bytes = prof["alg_bytes"] / prof["launches"]
+        per_launch_s = 1e-3 * prof["kernel_ms"] / prof["launches"]
+        achieved = per_launch_bytes / per_launch_s / 1e9
+        flops = FLOP_PER_NODE_K4 * prof["blankets"] / (1e-3 * prof["kernel_ms"]) / 1e12
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None, "kernel": "blanket_kernel<6,64,false>", "launches": prof["launches"],
+            "avg_launch_us": 1e6 * per_launch_s, "alg_bytes_per_launch": per_launch_bytes,
+            "blankets_per_launch": prof["blankets"] / prof["launches"],
+            "note": "path is fp64-ALU/latency-bound on paper (SURVEY.md 8d: ~110 flop/B); fp64 vector fraction alongside",
+            "fp64_vector_tflops_est": flops, "fp64_vector_frac_est": flops / FP64_VECTOR_PEAK_TFLOPS,
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from tests import oracle_lib, util
+        gs = g
+        ws = which
+        sample = "full workload, strictly sequential (the reference's execution model), 1 core"
+        if args.cpu_sample_poses and args.cpu_sample_poses < args.poses:
+            n = args.cpu_sample_poses
+            keep = (g["edge_ij"][:, 0] < n) & (g["edge_ij"][:, 1] < n)
+            gs = {"pose_dim": 6, "ids": g["ids"][:n], "poses": g["poses"][:n], "edge_ij": g["edge_ij"][keep], "edge_data": g["edge_data"][keep]}
+            ws = which[which < n]
+            sample = f"vertex prefix of {n} poses of the same graph ({len(ws)} removals), strictly sequential, 1 core"
+        og = oracle_lib.OracleGraph.from_dict(gs)
+        rc = og.marginalize(ws, opts)
+        secs = og.seconds()
+        bl = og.blankets()
+        out["cpu_baseline"] = {"value": len(bl["root"]) / secs, "unit": "nodes/s", "cores": 1, "kind": "port",
+                               "sample": sample, "seconds": secs, "rc": rc,
+                               "what": "CPU restatement of the reference's Eigen/CHOLMOD path (oracle/libspg_ref.so), not the reference"}
+        if gs is g:
+            kref = float(np.nansum(bl["kld"]))
+            out["parity"] = {"kld_sum_ref": kref, "kld_sum_rel_err": abs(kref - stats["kld_sum"]) / max(abs(kref), 1e-300)}
+            try:
+                out["parity"]["max_edge_rel_err"] = util.compare_edge_sets(6, og.edges(), replicas[-1].edges(), rtol=1.0)
+                out["parity"]["topology_identical"] = True
+            except AssertionError as e:
+                out["parity"]["topology_identical"] = False
+                out["parity"]["error"] = str(e)[:200]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

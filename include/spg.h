@@ -118,6 +118,11 @@ const char *spg_last_error(spg_ctx *ctx);
 /* HIP stream the context launches on (hipStream_t as void*), for event timing by the caller */
 void *spg_ctx_stream(spg_ctx *ctx);
 int spg_ctx_synchronize(spg_ctx *ctx);
+/* per-launch timing of the blanket kernel with HIP events on the context stream (bench roofline leg):
+ * enable/reset, then read the sums over every launch completed since: kernel milliseconds, algorithmic
+ * HBM bytes (SURVEY.md 8d formula evaluated on the launched blankets), launches, blankets */
+int spg_ctx_profile(spg_ctx *ctx, int enable);
+int spg_ctx_profile_read(spg_ctx *ctx, double *kernel_ms, double *alg_bytes, int64_t *launches, int64_t *blankets);
 
 /* VertexRemover::remove restricted to its arithmetic, for B independent blankets at once
  * (replaces src/vertex_remover.cpp:108-132 + src/topology_provider_binary.hpp:23-70 +
@@ -144,6 +149,9 @@ int spg_graph_write_g2o(spg_graph *g, const char *path);
 /* addVertex / addEdge (src/graph_wrapper_g2o.cpp:214-247). pose/meas as in spg_batch; info = upper triangle */
 int spg_graph_add_vertex(spg_graph *g, int id, const double *pose);
 int spg_graph_add_edge(spg_graph *g, int from, int to, const double *meas, const double *info_upper);
+/* bulk forms: poses n x (3|7); ij n x 2; records n x (meas + info upper triangle) */
+int spg_graph_add_vertices(spg_graph *g, int n, const int32_t *ids, const double *poses);
+int spg_graph_add_edges(spg_graph *g, int n, const int32_t *ij, const double *records);
 /* n-ary GLC edge (GLCEdge::read, src/glc_edge.cpp:64-93) */
 int spg_graph_add_glc_edge(spg_graph *g, int q, const int32_t *ids, int r, const double *meas, const double *W);
 int spg_graph_pose_dim(const spg_graph *g);

@@ -1,0 +1,308 @@
+// csrc/spg_dev_la.hpp — workgroup-cooperative dense fp64 linear algebra on LDS / L2-resident tiles.
+//
+// One workgroup (NT = 64: a single wavefront, or 256 for large blankets) owns one Markov blanket.
+// All routines are written as strided loops over the NT lanes with workgroup barriers between
+// dependent phases, so the same code serves a 12x12 SE2 block in LDS and a 132x132 SE3 tile in the
+// global workspace. Matrices are row-major with an odd leading dimension (bank-conflict-free column
+// walks on the 64-bank LDS). These replace the Eigen calls of the reference:
+//   LLT / LLT::solve(I)            src/vertex_remover.cpp:444-447, src/pseudo_chow_liu.cpp:189-190,
+//                                  src/logdet_function.cpp:246-247,273-274
+//   LDLT::vectorD().log().sum()    src/pseudo_chow_liu.cpp:178-182, src/logdet_function.cpp:123-127
+//   SelfAdjointEigenSolver         src/logdet_function.cpp:19, src/topology_provider_glc.cpp:45,66
+//   PartialPivLU                   src/topology_provider_glc.cpp:63-64
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace spgdev {
+
+template <int NT>
+struct Team {
+    int tid;
+    double *red;  // NT doubles of LDS for reductions
+    int *flag;    // one int of LDS (sticky failure / broadcast)
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+
+    // deterministic sum of one value per lane (fixed order), result broadcast to all lanes
+    __device__ __forceinline__ double sum(double v) const {
+        red[tid] = v;
+        sync();
+        if (tid == 0) {
+            double s = 0;
+            for (int i = 0; i < NT; i++) s += red[i];
+            red[0] = s;
+        }
+        sync();
+        double r = red[0];
+        sync();
+        return r;
+    }
+};
+
+__device__ __forceinline__ int ceil_log2(int n) {
+    int s = 0;
+    while ((1 << s) < n) s++;
+    return s;
+}
+
+// In-place lower Cholesky (right-looking). Reads/writes the lower triangle only. On failure sets
+// *T.flag = 1 (checked by the caller after the call) and stops at the failing column.
+template <int NT>
+__device__ void chol_lower(const Team<NT> &T, double *A, int n, int ld) {
+    for (int j = 0; j < n; j++) {
+        if (T.tid == 0) {
+            double d = A[j * ld + j];
+            if (!(d > 0.0) || !isfinite(d)) { *T.flag = 1; A[j * ld + j] = 1.0; }
+            else A[j * ld + j] = sqrt(d);
+        }
+        T.sync();
+        double inv = 1.0 / A[j * ld + j];
+        T.sync();
+        for (int i = j + 1 + T.tid; i < n; i += NT) A[i * ld + j] *= inv;
+        T.sync();
+        // trailing update: rows i > j, cols j < c <= i
+        int m = n - j - 1;
+        int sh = ceil_log2(m > 0 ? m : 1);
+        int tot = m << sh;
+        for (int it = T.tid; it < tot; it += NT) {
+            int r = it >> sh, c = it & ((1 << sh) - 1);
+            if (c <= r && c < m) {
+                int i = j + 1 + r, cc = j + 1 + c;
+                A[i * ld + cc] -= A[i * ld + j] * A[cc * ld + j];
+            }
+        }
+        T.sync();
+    }
+}
+
+// 2 * sum(log L_ii) of a Cholesky factor
+template <int NT>
+__device__ double chol_logdet(const Team<NT> &T, const double *L, int n, int ld) {
+    double s = 0;
+    for (int i = T.tid; i < n; i += NT) s += log(L[i * ld + i]);
+    return 2.0 * T.sum(s);
+}
+
+// Linv = L^-1 (lower), one lane per column; Linv may not alias L. Strict upper of Linv is zeroed.
+template <int NT>
+__device__ void tri_inverse_lower(const Team<NT> &T, const double *L, double *Li, int n, int ld) {
+    for (int c = T.tid; c < n; c += NT) {
+        for (int i = 0; i < c; i++) Li[i * ld + c] = 0.0;
+        Li[c * ld + c] = 1.0 / L[c * ld + c];
+        for (int i = c + 1; i < n; i++) {
+            double s = 0;
+            for (int k = c; k < i; k++) s += L[i * ld + k] * Li[k * ld + c];
+            Li[i * ld + c] = -s / L[i * ld + i];
+        }
+    }
+    T.sync();
+}
+
+// Out = Li^T Li (full symmetric), i.e. (L L^T)^-1 from Li = L^-1. Out may not alias Li.
+template <int NT>
+__device__ void gram_lower_inverse(const Team<NT> &T, const double *Li, double *Out, int n, int ld) {
+    int sh = ceil_log2(n);
+    int tot = n << sh;
+    for (int it = T.tid; it < tot; it += NT) {
+        int i = it >> sh, j = it & ((1 << sh) - 1);
+        if (j <= i) {
+            double s = 0;
+            for (int k = i; k < n; k++) s += Li[k * ld + i] * Li[k * ld + j];
+            Out[i * ld + j] = s;
+            Out[j * ld + i] = s;
+        }
+    }
+    T.sync();
+}
+
+// Y <- L^-1 Y for a (n x m) right-hand side stored row-major with leading dimension ldy; lane per column.
+template <int NT>
+__device__ void tri_solve_lower(const Team<NT> &T, const double *L, int n, int ld, double *Y, int m, int ldy) {
+    for (int c = T.tid; c < m; c += NT) {
+        for (int i = 0; i < n; i++) {
+            double s = Y[i * ldy + c];
+            for (int k = 0; k < i; k++) s -= L[i * ld + k] * Y[k * ldy + c];
+            Y[i * ldy + c] = s / L[i * ld + i];
+        }
+    }
+    T.sync();
+}
+
+// strict upper -> strict lower
+template <int NT>
+__device__ void mirror_upper(const Team<NT> &T, double *A, int n, int ld) {
+    int sh = ceil_log2(n);
+    int tot = n << sh;
+    for (int it = T.tid; it < tot; it += NT) {
+        int i = it >> sh, j = it & ((1 << sh) - 1);
+        if (j > i && j < n) A[j * ld + i] = A[i * ld + j];
+    }
+    T.sync();
+}
+
+// Round-robin pairing for parallel Jacobi: n2 even players, step s in [0, n2-1), pair index pi in [0, n2/2)
+__device__ __forceinline__ void rr_pair(int s, int pi, int n2, int &p, int &q) {
+    int m = n2 - 1;
+    if (pi == 0) { p = m; q = s; }
+    else {
+        p = s + pi; if (p >= m) p -= m;
+        q = s - pi; if (q < 0) q += m;
+    }
+    if (p > q) { int t = p; p = q; q = t; }
+}
+
+// Symmetric eigendecomposition by parallel-order two-sided Jacobi. A (n x n, full, destroyed: on
+// exit its diagonal holds the eigenvalues), V receives the eigenvectors in columns. cs: 2*(n/2+1)
+// doubles of scratch. Returns false (uniformly) if not converged in max_sweeps.
+template <int NT>
+__device__ bool jacobi_eigh(const Team<NT> &T, double *A, double *V, int n, int ld, double *cs, int max_sweeps = 60) {
+    int sh = ceil_log2(n);
+    int tot = n << sh;
+    double f = 0;
+    for (int it = T.tid; it < tot; it += NT) {
+        int i = it >> sh, j = it & ((1 << sh) - 1);
+        if (j < n) {
+            V[i * ld + j] = (i == j) ? 1.0 : 0.0;
+            double a = A[i * ld + j];
+            f += a * a;
+        }
+    }
+    double fro2 = T.sum(f);
+    if (n <= 1 || fro2 == 0.0) return true;
+    int np = (n + 1) >> 1, n2 = np * 2;
+    int shp = ceil_log2(n);
+    bool converged = false;
+    for (int sweep = 0; sweep < max_sweeps; sweep++) {
+        double o = 0;
+        for (int it = T.tid; it < tot; it += NT) {
+            int i = it >> sh, j = it & ((1 << sh) - 1);
+            if (j < n && i != j) { double a = A[i * ld + j]; o += a * a; }
+        }
+        double off2 = T.sum(o);
+        if (off2 <= 1e-31 * fro2) { converged = true; break; }
+        for (int s = 0; s < n2 - 1; s++) {
+            for (int pi = T.tid; pi < np; pi += NT) {
+                int p, q;
+                rr_pair(s, pi, n2, p, q);
+                double c = 1.0, sn = 0.0;
+                if (q < n) {
+                    double apq = A[p * ld + q];
+                    if (fabs(apq) > 1e-300) {
+                        double tau = (A[q * ld + q] - A[p * ld + p]) / (2.0 * apq);
+                        double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        sn = t * c;
+                    }
+                }
+                cs[2 * pi] = c; cs[2 * pi + 1] = sn;
+            }
+            T.sync();
+            // column pass on A and V
+            int totc = np << shp;
+            for (int it = T.tid; it < totc; it += NT) {
+                int pi = it >> shp, i = it & ((1 << shp) - 1);
+                if (i >= n) continue;
+                int p, q;
+                rr_pair(s, pi, n2, p, q);
+                if (q >= n) continue;
+                double c = cs[2 * pi], sn = cs[2 * pi + 1];
+                if (sn == 0.0) continue;
+                double aip = A[i * ld + p], aiq = A[i * ld + q];
+                A[i * ld + p] = c * aip - sn * aiq;
+                A[i * ld + q] = sn * aip + c * aiq;
+                double vip = V[i * ld + p], viq = V[i * ld + q];
+                V[i * ld + p] = c * vip - sn * viq;
+                V[i * ld + q] = sn * vip + c * viq;
+            }
+            T.sync();
+            // row pass on A
+            for (int it = T.tid; it < totc; it += NT) {
+                int pi = it >> shp, j = it & ((1 << shp) - 1);
+                if (j >= n) continue;
+                int p, q;
+                rr_pair(s, pi, n2, p, q);
+                if (q >= n) continue;
+                double c = cs[2 * pi], sn = cs[2 * pi + 1];
+                if (sn == 0.0) continue;
+                double apj = A[p * ld + j], aqj = A[q * ld + j];
+                double np_ = c * apj - sn * aqj, nq_ = sn * apj + c * aqj;
+                if (j == q) np_ = 0.0;
+                if (j == p) nq_ = 0.0;
+                A[p * ld + j] = np_;
+                A[q * ld + j] = nq_;
+            }
+            T.sync();
+        }
+    }
+    return converged;
+}
+
+// rank-by-counting sort of n keys (ascending, ties by index): perm[rank] = index
+template <int NT>
+__device__ void sort_ascending(const Team<NT> &T, const double *key, int stride, int n, int *perm) {
+    for (int i = T.tid; i < n; i += NT) {
+        double ki = key[i * stride];
+        int r = 0;
+        for (int j = 0; j < n; j++) {
+            double kj = key[j * stride];
+            r += (kj < ki) || (kj == ki && j < i);
+        }
+        perm[r] = i;
+    }
+    T.sync();
+}
+
+// Small fixed-size helpers evaluated by ONE lane in registers (D = 3 or 6) --------------------
+template <int D>
+__device__ __forceinline__ bool chol_reg(double *a /*D*D row-major, lower used, in place*/) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double d = a[j * D + j];
+#pragma unroll
+        for (int k = 0; k < D; k++) if (k < j) d -= a[j * D + k] * a[j * D + k];
+        if (!(d > 0.0) || !isfinite(d)) { ok = false; d = 1.0; }
+        double l = sqrt(d);
+        a[j * D + j] = l;
+        double inv = 1.0 / l;
+#pragma unroll
+        for (int i = 0; i < D; i++) if (i > j) {
+            double s = a[i * D + j];
+#pragma unroll
+            for (int k = 0; k < D; k++) if (k < j) s -= a[i * D + k] * a[j * D + k];
+            a[i * D + j] = s * inv;
+        }
+    }
+    return ok;
+}
+
+// X = (L L^T)^-1 from the lower factor in a[] (registers); writes full symmetric X
+template <int D>
+__device__ __forceinline__ void chol_inverse_reg(const double *L, double *X) {
+    double Li[D * D];
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            if (i < c) Li[i * D + c] = 0.0;
+            else if (i == c) Li[i * D + c] = 1.0 / L[c * D + c];
+            else {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < D; k++) if (k >= c && k < i) s += L[i * D + k] * Li[k * D + c];
+                Li[i * D + c] = -s / L[i * D + i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int j = 0; j < D; j++) if (j <= i) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < D; k++) if (k >= i) s += Li[k * D + i] * Li[k * D + j];
+            X[i * D + j] = s;
+            X[j * D + i] = s;
+        }
+}
+
+}  // namespace spgdev

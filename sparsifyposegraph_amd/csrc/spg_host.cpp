@@ -1,0 +1,1059 @@
+// csrc/spg_host.cpp — host side of libspg_hip.so: contexts, the device-resident pose graph, the
+// conflict-free round scheduler and the C ABI of include/spg.h.
+//
+// What stays on the host is the integer graph work of the reference's loop:
+//   markovBlanketVertices / extendedMarkovBlanketVertices / markovBlanketEdges
+//                                             src/vertex_remover.cpp:142-251
+//   buildSubgraph's vertex ordering           src/vertex_remover.cpp:349-356
+//   updateInputGraph                          src/vertex_remover.cpp:500-546
+//   GraphWrapperG2O bookkeeping               src/graph_wrapper_g2o.cpp:207-247,398-453
+// Everything numeric runs in the HIP backend (spg_kernels.hip) on records that live in one HBM
+// arena: [poses | edge records | per-round output regions]. The host keeps topology only.
+//
+// Sequential semantics. VertexRemover::remove mutates the graph after every vertex
+// (src/vertex_remover.cpp:134). Two removals commute exactly when neither centre lies in the other's
+// blanket and the blankets share at most one vertex (then no existing or future edge can belong to
+// both). Each round scans the pending list in the reference's order and selects a vertex only if it
+// commutes with every earlier vertex that is selected in this round or still deferred — a deferred
+// vertex is represented by a superset D(u) of every vertex its blanket can reach before its turn.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/spg.h"
+#include "spg_internal.h"
+
+namespace {
+inline int pose_stride(int d) { return d == 3 ? 3 : 7; }
+inline int info_len(int d) { return d * (d + 1) / 2; }
+inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+}  // namespace
+
+struct spg_ctx {
+    spg_backend be{};
+    bool is_hip = false;
+    char err[768] = {0};
+};
+
+struct GEdge {
+    int32_t kind, nv, vbeg, len;
+    int64_t off;
+    uint8_t alive;
+};
+
+struct RoundBlanket {
+    int32_t root;                 // vertex index
+    int32_t n_remove;
+    std::vector<int32_t> verts;   // vertex indices, removed first (asc id) then kept (asc id)
+    std::vector<int32_t> edges;   // edge ids, ascending
+    int32_t rank = 0;
+    spg_blanket_desc desc{};
+};
+
+struct BlanketLog { int32_t root_id, round, status, info; double kld, min_gap; };
+
+struct spg_graph {
+    spg_ctx *ctx = nullptr;
+    int d = 0, ps = 0, rec = 0;
+    std::vector<int32_t> vid;
+    std::unordered_map<int32_t, int32_t> vidx;
+    std::vector<uint8_t> valive;
+    std::vector<int64_t> vpose;
+    std::vector<std::vector<int32_t>> adj;
+    std::vector<GEdge> edges;
+    std::vector<int32_t> everts;
+    int n_live_v = 0, n_live_e = 0;
+    // arena
+    void *dev = nullptr;
+    int64_t cap = 0, used = 0;
+    std::vector<double> host;      // mirror of [0, used)
+    int64_t dev_synced = 0;        // device holds [0, dev_synced)
+    int64_t stale_lo = 0, stale_hi = 0;  // host mirror range that only the device holds
+    // marginalisation state
+    bool active = false;
+    spg_options opts{};
+    int rank = 0, nranks = 1;
+    std::vector<int32_t> pending;
+    std::vector<uint8_t> in_set;   // vertex index is in the removal list
+    std::vector<RoundBlanket> rb;
+    std::vector<spg_blanket_desc> h_blk;
+    std::vector<int64_t> h_vpo;
+    std::vector<spg_edge_ref> h_er;
+    std::vector<int32_t> h_ev;
+    std::vector<int64_t> chunk_hdr;   // per rank: doubles of out records at the start of its chunk
+    spg_round_info rinfo{};
+    bool round_open = false;
+    int round_no = 0;
+    spg_marg_stats stats{};
+    std::vector<BlanketLog> log;
+    std::vector<double> hdr_buf;
+    // scheduler scratch
+    std::vector<int32_t> vstamp, estamp;
+    int32_t stamp = 0;
+    std::vector<std::vector<int32_t>> vowners;
+    std::vector<int32_t> touched;
+    std::vector<std::vector<int32_t>> Dsets;
+    std::vector<int32_t> ocnt;
+    std::vector<int32_t> lidx;
+};
+
+static int set_err(spg_ctx *c, int code, const char *fmt, const char *a = "") {
+    if (c) snprintf(c->err, sizeof c->err, fmt, a);
+    return code;
+}
+
+// ================================================================================= context
+extern "C" int spg_ctx_create(spg_ctx **out, int device) {
+    if (!out) return SPG_EINVAL;
+    spg_ctx *c = new spg_ctx;
+    int rc = spg::hip_backend_create(device, &c->be, c->err, sizeof c->err);
+    if (rc != 0) {
+        fprintf(stderr, "libspg_hip: %s\n", c->err);
+        delete c;
+        *out = nullptr;
+        return rc;
+    }
+    c->is_hip = true;
+    *out = c;
+    return 0;
+}
+
+extern "C" int spg_ctx_create_injected(spg_ctx **out, const spg_backend *backend) {
+    if (!out || !backend || !backend->alloc || !backend->run_round) return SPG_EINVAL;
+    spg_ctx *c = new spg_ctx;
+    c->be = *backend;
+    c->is_hip = false;
+    *out = c;
+    return 0;
+}
+
+extern "C" void spg_ctx_destroy(spg_ctx *c) {
+    if (!c) return;
+    if (c->is_hip) spg::hip_backend_destroy(&c->be);
+    delete c;
+}
+
+extern "C" const char *spg_last_error(spg_ctx *c) {
+    if (!c) return "";
+    if (c->err[0]) return c->err;
+    return c->is_hip ? spg::hip_backend_error(&c->be) : "";
+}
+extern "C" void *spg_ctx_stream(spg_ctx *c) { return (c && c->is_hip) ? spg::hip_backend_stream(&c->be) : nullptr; }
+extern "C" int spg_ctx_synchronize(spg_ctx *c) { return c ? c->be.synchronize(c->be.user) : SPG_EINVAL; }
+
+extern "C" int spg_ctx_profile(spg_ctx *c, int enable) {
+    if (!c || !c->is_hip) return SPG_EINVAL;
+    spg::hip_backend_profile(&c->be, enable);
+    return 0;
+}
+extern "C" int spg_ctx_profile_read(spg_ctx *c, double *kernel_ms, double *alg_bytes, int64_t *launches, int64_t *blankets) {
+    if (!c || !c->is_hip || !kernel_ms || !alg_bytes || !launches || !blankets) return SPG_EINVAL;
+    long long l = 0, b = 0;
+    spg::hip_backend_profile_read(&c->be, kernel_ms, alg_bytes, &l, &b);
+    *launches = l; *blankets = b;
+    return 0;
+}
+
+// ================================================================================= decimation
+// src/decimation.cpp:11-49
+static int emit(const std::vector<int> &v, int32_t *out, int cap) {
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = v[i];
+    return (int)v.size();
+}
+extern "C" int spg_decimate_cluster(int last, int endvert, int sparsity, int clusterSize, int32_t *out, int cap) {
+    std::vector<int> ret;
+    if (clusterSize > 0 && (((last - 4) % clusterSize == 0 && last > 4) || last == endvert)) {
+        for (int i = int(std::ceil((last - 5) / (double)clusterSize) - 1) * clusterSize + 5; i <= last; i++)
+            if (i % sparsity > 0) ret.push_back(i);
+    }
+    return emit(ret, out, cap);
+}
+extern "C" int spg_decimate_online(int last, int, int sparsity, int, int32_t *out, int cap) {
+    std::vector<int> ret;
+    if (last % sparsity != 0) ret.push_back(last);
+    return emit(ret, out, cap);
+}
+extern "C" int spg_decimate_global(int last, int endvert, int sparsity, int, int32_t *out, int cap) {
+    std::vector<int> ret;
+    if (last == endvert)
+        for (int i = 4; i <= endvert; i++)
+            if (i % sparsity != 0) ret.push_back(i);
+    return emit(ret, out, cap);
+}
+
+// ================================================================================= arena
+static int arena_ensure(spg_graph *g, int64_t need);
+
+static int sync_host(spg_graph *g) {  // pull device-only ranges into the host mirror
+    if (g->stale_hi > g->stale_lo) {
+        if ((int64_t)g->host.size() < g->used) g->host.resize((size_t)g->used);
+        int rc = g->ctx->be.download(g->ctx->be.user, g->host.data() + g->stale_lo,
+                                     (char *)g->dev + g->stale_lo * 8, g->stale_hi - g->stale_lo);
+        if (rc) return rc;
+        g->stale_lo = g->stale_hi = 0;
+    }
+    return 0;
+}
+
+static int sync_device(spg_graph *g) {  // push host-only tail to the device
+    if (g->dev_synced < g->used) {
+        if (int rc = arena_ensure(g, g->used)) return rc;
+        int64_t lo = g->dev_synced;
+        // the tail may overlap a stale (device-only) range only if it was produced on the device,
+        // in which case dev_synced already covers it
+        int rc = g->ctx->be.upload(g->ctx->be.user, (char *)g->dev + lo * 8, g->host.data() + lo, g->used - lo);
+        if (rc) return rc;
+        g->dev_synced = g->used;
+    }
+    return 0;
+}
+
+static int arena_ensure(spg_graph *g, int64_t need) {
+    if (need <= g->cap && g->dev) return 0;
+    if (int rc = sync_host(g)) return rc;
+    int64_t nc = std::max<int64_t>(need, std::max<int64_t>(g->cap * 2, 1 << 16));
+    void *nd = g->ctx->be.alloc(g->ctx->be.user, nc);
+    if (!nd) return set_err(g->ctx, SPG_ENOMEM, "arena allocation failed");
+    if (g->dev) g->ctx->be.release(g->ctx->be.user, g->dev);
+    g->dev = nd;
+    g->cap = nc;
+    g->dev_synced = 0;
+    if ((int64_t)g->host.size() < g->used) g->host.resize((size_t)g->used);
+    return 0;
+}
+
+static int64_t arena_push(spg_graph *g, const double *src, int64_t len) {
+    int64_t off = g->used;
+    if ((int64_t)g->host.size() < off + len) g->host.resize((size_t)std::max<int64_t>(off + len, (int64_t)g->host.size() * 2));
+    if (src) memcpy(g->host.data() + off, src, (size_t)len * 8);
+    g->used += len;
+    return off;
+}
+
+// ================================================================================= graph basics
+extern "C" int spg_graph_create(spg_ctx *ctx, int pose_dim, spg_graph **out) {
+    if (!ctx || !out || (pose_dim != 3 && pose_dim != 6)) return SPG_EINVAL;
+    spg_graph *g = new spg_graph;
+    g->ctx = ctx;
+    g->d = pose_dim;
+    g->ps = pose_stride(pose_dim);
+    g->rec = g->ps + info_len(pose_dim);
+    *out = g;
+    return 0;
+}
+
+extern "C" void spg_graph_destroy(spg_graph *g) {
+    if (!g) return;
+    if (g->dev) g->ctx->be.release(g->ctx->be.user, g->dev);
+    delete g;
+}
+
+extern "C" int spg_graph_add_vertex(spg_graph *g, int id, const double *pose) {
+    if (!g || !pose || g->active) return SPG_EINVAL;
+    if (g->vidx.count(id)) return set_err(g->ctx, SPG_EINVAL, "duplicate vertex id");
+    int32_t idx = (int32_t)g->vid.size();
+    g->vid.push_back(id);
+    g->vidx[id] = idx;
+    g->valive.push_back(1);
+    g->adj.emplace_back();
+    g->vpose.push_back(arena_push(g, pose, g->ps));
+    g->n_live_v++;
+    return 0;
+}
+
+static int add_edge_idx(spg_graph *g, int kind, int nv, const int32_t *vix, int64_t off, int32_t len) {
+    GEdge e;
+    e.kind = kind; e.nv = nv; e.vbeg = (int32_t)g->everts.size(); e.len = len; e.off = off; e.alive = 1;
+    int32_t eid = (int32_t)g->edges.size();
+    for (int i = 0; i < nv; i++) g->everts.push_back(vix[i]);
+    g->edges.push_back(e);
+    for (int i = 0; i < nv; i++) {
+        bool dup = false;
+        for (int j = 0; j < i; j++) dup |= (vix[j] == vix[i]);
+        if (!dup) g->adj[vix[i]].push_back(eid);
+    }
+    g->n_live_e++;
+    return eid;
+}
+
+extern "C" int spg_graph_add_edge(spg_graph *g, int from, int to, const double *meas, const double *info_upper) {
+    if (!g || !meas || !info_upper || g->active) return SPG_EINVAL;
+    auto a = g->vidx.find(from), b = g->vidx.find(to);
+    if (a == g->vidx.end() || b == g->vidx.end() || !g->valive[a->second] || !g->valive[b->second])
+        return set_err(g->ctx, SPG_EINVAL, "edge endpoint does not exist");
+    int64_t off = arena_push(g, meas, g->ps);
+    arena_push(g, info_upper, info_len(g->d));
+    int32_t vix[2] = {a->second, b->second};
+    add_edge_idx(g, SPG_EDGE_BINARY, 2, vix, off, g->rec);
+    return 0;
+}
+
+extern "C" int spg_graph_add_glc_edge(spg_graph *g, int q, const int32_t *ids, int r, const double *meas, const double *W) {
+    if (!g || q < 1 || r < 1 || !ids || !meas || !W || g->active) return SPG_EINVAL;
+    std::vector<int32_t> vix(q);
+    for (int i = 0; i < q; i++) {
+        auto it = g->vidx.find(ids[i]);
+        if (it == g->vidx.end() || !g->valive[it->second]) return set_err(g->ctx, SPG_EINVAL, "edge endpoint does not exist");
+        vix[i] = it->second;
+    }
+    int n = g->d * q;
+    int64_t off = arena_push(g, meas, n);
+    arena_push(g, W, (int64_t)r * n);
+    add_edge_idx(g, SPG_EDGE_GLC, q, vix.data(), off, n + r * n);
+    return 0;
+}
+
+// bulk forms of addVertex / addEdge (same semantics, one call per array)
+extern "C" int spg_graph_add_vertices(spg_graph *g, int n, const int32_t *ids, const double *poses) {
+    if (!g || n < 0 || !ids || !poses) return SPG_EINVAL;
+    g->vid.reserve(g->vid.size() + n);
+    for (int i = 0; i < n; i++)
+        if (int rc = spg_graph_add_vertex(g, ids[i], poses + (size_t)i * g->ps)) return rc;
+    return 0;
+}
+extern "C" int spg_graph_add_edges(spg_graph *g, int n, const int32_t *ij, const double *records) {
+    if (!g || n < 0 || !ij || !records) return SPG_EINVAL;
+    g->edges.reserve(g->edges.size() + n);
+    for (int i = 0; i < n; i++) {
+        const double *r = records + (size_t)i * g->rec;
+        if (int rc = spg_graph_add_edge(g, ij[2 * i], ij[2 * i + 1], r, r + g->ps)) return rc;
+    }
+    return 0;
+}
+
+extern "C" int spg_graph_pose_dim(const spg_graph *g) { return g ? g->d : 0; }
+extern "C" int spg_graph_num_vertices(const spg_graph *g) { return g ? g->n_live_v : 0; }
+extern "C" int spg_graph_num_edges(const spg_graph *g) { return g ? g->n_live_e : 0; }
+extern "C" int64_t spg_graph_edge_data_size(const spg_graph *g) {
+    int64_t s = 0;
+    for (auto &e : g->edges) if (e.alive) s += e.len;
+    return s;
+}
+extern "C" int64_t spg_graph_edge_vert_size(const spg_graph *g) {
+    int64_t s = 0;
+    for (auto &e : g->edges) if (e.alive) s += e.nv;
+    return s;
+}
+
+extern "C" int spg_graph_get_vertices(spg_graph *g, int32_t *ids, double *poses) {
+    if (!g) return SPG_EINVAL;
+    if (int rc = sync_host(g)) return rc;
+    std::vector<std::pair<int32_t, int32_t>> order;
+    for (size_t i = 0; i < g->vid.size(); i++) if (g->valive[i]) order.push_back({g->vid[i], (int32_t)i});
+    std::sort(order.begin(), order.end());
+    for (size_t k = 0; k < order.size(); k++) {
+        ids[k] = order[k].first;
+        memcpy(poses + k * g->ps, g->host.data() + g->vpose[order[k].second], (size_t)g->ps * 8);
+    }
+    return (int)order.size();
+}
+
+extern "C" int spg_graph_get_edges(spg_graph *g, int32_t *kind, int32_t *vert_off, int32_t *vert_ids, int64_t *data_off, double *data) {
+    if (!g) return SPG_EINVAL;
+    if (int rc = sync_host(g)) return rc;
+    int ne = 0, nv = 0;
+    int64_t nd = 0;
+    vert_off[0] = 0; data_off[0] = 0;
+    for (auto &e : g->edges) {
+        if (!e.alive) continue;
+        kind[ne] = e.kind;
+        for (int i = 0; i < e.nv; i++) vert_ids[nv++] = g->vid[g->everts[e.vbeg + i]];
+        memcpy(data + nd, g->host.data() + e.off, (size_t)e.len * 8);
+        nd += e.len;
+        ne++;
+        vert_off[ne] = nv; data_off[ne] = nd;
+    }
+    return ne;
+}
+
+extern "C" int spg_graph_set_estimate(spg_graph *g, int id, const double *pose) {
+    if (!g || !pose || g->active) return SPG_EINVAL;
+    auto it = g->vidx.find(id);
+    if (it == g->vidx.end() || !g->valive[it->second]) return SPG_EINVAL;
+    int64_t off = g->vpose[it->second];
+    memcpy(g->host.data() + off, pose, (size_t)g->ps * 8);
+    if (off < g->dev_synced && g->dev)
+        return g->ctx->be.upload(g->ctx->be.user, (char *)g->dev + off * 8, pose, g->ps);
+    return 0;
+}
+
+extern "C" void *spg_graph_arena(spg_graph *g, int64_t *capacity) {
+    if (!g) return nullptr;
+    if (capacity) *capacity = g->cap;
+    return g->dev;
+}
+
+extern "C" int spg_graph_reserve(spg_graph *g, int64_t arena_doubles) {
+    if (!g) return SPG_EINVAL;
+    if (int rc = arena_ensure(g, std::max(arena_doubles, g->used))) return rc;
+    return sync_device(g);
+}
+
+// ================================================================================= .g2o I/O
+static void normalize_quat(double *q) {
+    double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (n > 0) for (int i = 0; i < 4; i++) q[i] /= n;
+}
+
+extern "C" int spg_graph_load_g2o(spg_ctx *ctx, const char *path, spg_graph **out) {
+    if (!ctx || !path || !out) return SPG_EINVAL;
+    FILE *f = fopen(path, "r");
+    if (!f) return set_err(ctx, SPG_EIO, "cannot open %s", path);
+    struct V { int id; double p[7]; };
+    struct E { int a, b; double r[28]; };
+    std::vector<V> vs;
+    std::vector<E> es;
+    int d = 0;
+    std::vector<char> line(1 << 16);
+    while (fgets(line.data(), (int)line.size(), f)) {
+        char *s = line.data();
+        while (*s == ' ' || *s == '\t') s++;
+        char tag[64];
+        int adv = 0;
+        if (sscanf(s, "%63s%n", tag, &adv) != 1) continue;
+        s += adv;
+        auto readn = [&](double *dst, int cnt) {
+            for (int i = 0; i < cnt; i++) {
+                char *end;
+                dst[i] = strtod(s, &end);
+                if (end == s) return false;
+                s = end;
+            }
+            return true;
+        };
+        auto readi = [&](int &v) {
+            char *end;
+            long x = strtol(s, &end, 10);
+            if (end == s) return false;
+            v = (int)x; s = end;
+            return true;
+        };
+        if (!strcmp(tag, "VERTEX_SE2")) {
+            V v{};
+            if (!readi(v.id) || !readn(v.p, 3)) continue;
+            if (!d) d = 3;
+            vs.push_back(v);
+        } else if (!strcmp(tag, "VERTEX_SE3:QUAT")) {
+            V v{};
+            if (!readi(v.id) || !readn(v.p, 7)) continue;
+            normalize_quat(v.p + 3);
+            if (!d) d = 6;
+            vs.push_back(v);
+        } else if (!strcmp(tag, "EDGE_SE2")) {
+            E e{};
+            if (!readi(e.a) || !readi(e.b) || !readn(e.r, 9)) continue;
+            es.push_back(e);
+        } else if (!strcmp(tag, "EDGE_SE3:QUAT")) {
+            E e{};
+            if (!readi(e.a) || !readi(e.b) || !readn(e.r, 28)) continue;
+            normalize_quat(e.r + 3);
+            es.push_back(e);
+        }
+    }
+    fclose(f);
+    if (!d) return set_err(ctx, SPG_EIO, "no SE2/SE3 vertices in %s", path);
+    std::stable_sort(vs.begin(), vs.end(), [](const V &a, const V &b) { return a.id < b.id; });
+    spg_graph *g;
+    if (int rc = spg_graph_create(ctx, d, &g)) return rc;
+    for (auto &v : vs) if (int rc = spg_graph_add_vertex(g, v.id, v.p)) { spg_graph_destroy(g); return rc; }
+    for (auto &e : es) if (int rc = spg_graph_add_edge(g, e.a, e.b, e.r, e.r + g->ps)) { spg_graph_destroy(g); return rc; }
+    *out = g;
+    return 0;
+}
+
+extern "C" int spg_graph_write_g2o(spg_graph *g, const char *path) {
+    if (!g || !path) return SPG_EINVAL;
+    if (int rc = sync_host(g)) return rc;
+    FILE *f = fopen(path, "w");
+    if (!f) return set_err(g->ctx, SPG_EIO, "cannot open %s for writing", path);
+    std::vector<std::pair<int32_t, int32_t>> order;
+    for (size_t i = 0; i < g->vid.size(); i++) if (g->valive[i]) order.push_back({g->vid[i], (int32_t)i});
+    std::sort(order.begin(), order.end());
+    const char *vt = g->d == 3 ? "VERTEX_SE2" : "VERTEX_SE3:QUAT", *et = g->d == 3 ? "EDGE_SE2" : "EDGE_SE3:QUAT";
+    for (auto &o : order) {
+        fprintf(f, "%s %d", vt, o.first);
+        for (int i = 0; i < g->ps; i++) fprintf(f, " %.17g", g->host[g->vpose[o.second] + i]);
+        fputc('\n', f);
+    }
+    for (auto &e : g->edges) {
+        if (!e.alive) continue;
+        if (e.kind == SPG_EDGE_BINARY) {
+            fprintf(f, "%s %d %d", et, g->vid[g->everts[e.vbeg]], g->vid[g->everts[e.vbeg + 1]]);
+            for (int i = 0; i < e.len; i++) fprintf(f, " %.17g", g->host[e.off + i]);
+        } else {
+            // GLCEdge::write (src/glc_edge.cpp:95-119): "|| <reparam tag> r dq meas W info(upper of I_r)"
+            int n = g->d * e.nv, r = (e.len - n) / n;
+            fprintf(f, "GLC_EDGE");
+            for (int i = 0; i < e.nv; i++) fprintf(f, " %d", g->vid[g->everts[e.vbeg + i]]);
+            fprintf(f, " || %s %d %d", g->d == 3 ? "GLC_REPARAM_SE2_ISAM" : "GLC_REPARAM_SE3", r, n);
+            for (int i = 0; i < e.len; i++) fprintf(f, " %.17g", g->host[e.off + i]);
+            for (int i = 0; i < r; i++) for (int j = i; j < r; j++) fprintf(f, " %d", i == j ? 1 : 0);
+        }
+        fputc('\n', f);
+    }
+    fclose(f);
+    return 0;
+}
+
+// ================================================================================= scheduler
+static void next_stamp(spg_graph *g) {
+    if (g->vstamp.size() < g->vid.size()) g->vstamp.resize(g->vid.size(), 0);
+    if (g->estamp.size() < g->edges.size()) g->estamp.resize(g->edges.size(), 0);
+    g->stamp++;
+}
+
+// N[v] including v (markovBlanketVertices, src/vertex_remover.cpp:197-215); unsorted, deduplicated
+static void closed_neighbourhood(spg_graph *g, int32_t v, std::vector<int32_t> &out) {
+    next_stamp(g);
+    out.clear();
+    out.push_back(v);
+    g->vstamp[v] = g->stamp;
+    for (int32_t eid : g->adj[v]) {
+        const GEdge &e = g->edges[eid];
+        for (int i = 0; i < e.nv; i++) {
+            int32_t u = g->everts[e.vbeg + i];
+            if (g->vstamp[u] != g->stamp) { g->vstamp[u] = g->stamp; out.push_back(u); }
+        }
+    }
+}
+
+// extendedMarkovBlanketVertices (src/vertex_remover.cpp:142-195), literal: one ascending pass over
+// the growing id-ordered set; pick bin = every vertex of the removal list that is still alive.
+static void extended_blanket(spg_graph *g, int32_t root, std::vector<int32_t> &verts, std::vector<int32_t> &picked) {
+    auto byid = [g](int32_t a, int32_t b) { return g->vid[a] < g->vid[b]; };
+    std::set<int32_t, decltype(byid)> ret(byid), pk(byid);
+    std::vector<int32_t> tmp;
+    closed_neighbourhood(g, root, tmp);
+    ret.insert(tmp.begin(), tmp.end());
+    pk.insert(root);
+    for (auto it = ret.begin(); it != ret.end(); ++it) {
+        int32_t v = *it;
+        if (g->in_set[v] && !pk.count(v)) {
+            pk.insert(v);
+            closed_neighbourhood(g, v, tmp);
+            ret.insert(tmp.begin(), tmp.end());
+        }
+    }
+    verts.assign(ret.begin(), ret.end());
+    picked.assign(pk.begin(), pk.end());
+}
+
+static bool dense_mode(const spg_options &o) { return o.topology == SPG_TOPO_DENSE || o.topology == SPG_TOPO_CLIQUEY_DENSE; }
+
+// markovBlanketEdges (src/vertex_remover.cpp:225-251) for a selected blanket. `verts` must be stamped.
+static void collect_edges(spg_graph *g, const std::vector<int32_t> &verts, const std::vector<int32_t> &centres,
+                          bool intra, std::vector<int32_t> &out) {
+    next_stamp(g);
+    int32_t st = g->stamp;
+    for (int32_t v : verts) g->vstamp[v] = st;
+    std::vector<uint8_t> dummy;
+    out.clear();
+    for (int32_t v : verts)
+        for (int32_t eid : g->adj[v]) {
+            if (g->estamp[eid] == st) continue;
+            g->estamp[eid] = st;
+            const GEdge &e = g->edges[eid];
+            bool ok = true, hub = false;
+            for (int i = 0; i < e.nv; i++) {
+                int32_t u = g->everts[e.vbeg + i];
+                if (g->vstamp[u] != st) { ok = false; break; }
+                if (!intra) for (int32_t c : centres) hub |= (c == u);
+            }
+            if (ok && (intra || hub)) out.push_back(eid);
+        }
+    std::sort(out.begin(), out.end());
+}
+
+static void new_edge_budget(const spg_options &o, int d, int k, int32_t &n_new_max, int32_t &n_new_vert_max, int64_t &new_len) {
+    int ps = pose_stride(d);
+    if (o.algorithm == SPG_ALG_NFR) {
+        n_new_max = std::max(k - 1, 0);
+        n_new_vert_max = 2 * n_new_max;
+        new_len = (int64_t)n_new_max * (ps + info_len(d));
+    } else if (o.topology == SPG_TOPO_DENSE || k <= 1) {
+        int64_t n = (int64_t)d * k;
+        n_new_max = k > 0 ? 1 : 0;
+        n_new_vert_max = k;
+        new_len = n + n * n;
+    } else {
+        int64_t n2 = 2 * d;
+        n_new_max = k;
+        n_new_vert_max = 2 * k - 1;
+        new_len = (d + (int64_t)d * d) + (int64_t)(k - 1) * (n2 + n2 * n2);
+    }
+}
+
+// Select this round's mutually commuting blankets, in list order. Fills g->rb; rewrites g->pending.
+static void schedule_round(spg_graph *g) {
+    const spg_options &o = g->opts;
+    const bool dense = dense_mode(o);
+    const size_t DCAP = 512;
+    g->rb.clear();
+    if (g->vowners.size() < g->vid.size()) g->vowners.resize(g->vid.size());
+    for (int32_t v : g->touched) g->vowners[v].clear();
+    g->touched.clear();
+    g->Dsets.clear();
+    g->ocnt.clear();
+    std::vector<int32_t> newpending, B, centres, Dv, tmp;
+    std::vector<int32_t> hit;
+    bool stop = false;
+    size_t n_deferred = 0;
+    auto reg = [&](const std::vector<int32_t> &D) {
+        int32_t oid = (int32_t)g->Dsets.size();
+        g->Dsets.push_back(D);
+        g->ocnt.push_back(0);
+        for (int32_t x : D) {
+            if (g->vowners[x].empty()) g->touched.push_back(x);
+            g->vowners[x].push_back(oid);
+        }
+    };
+    for (size_t pos = 0; pos < g->pending.size(); pos++) {
+        int32_t v = g->pending[pos];
+        if (!g->valive[v]) continue;  // absorbed by an earlier cluster (`deleted`, src/vertex_remover.cpp:91)
+        if (stop) { newpending.push_back(v); continue; }
+        if (dense) extended_blanket(g, v, B, centres);
+        else { closed_neighbourhood(g, v, B); centres.assign(1, v); }
+        bool inD = false, conflict = false;
+        hit.clear();
+        for (int32_t x : B) {
+            bool is_c = false;
+            for (int32_t c : centres) is_c |= (c == x);
+            for (int32_t oid : g->vowners[x]) {
+                if (is_c) inD = true;
+                if (g->ocnt[oid]++ == 0) hit.push_back(oid);
+                if (g->ocnt[oid] >= 2) conflict = true;
+            }
+        }
+        for (int32_t oid : hit) g->ocnt[oid] = 0;
+        if (!inD && !conflict) {
+            RoundBlanket rbk;
+            rbk.root = v;
+            rbk.n_remove = (int32_t)centres.size();
+            auto byid = [g](int32_t a, int32_t b) { return g->vid[a] < g->vid[b]; };
+            std::sort(centres.begin(), centres.end(), byid);
+            rbk.verts = centres;
+            tmp.clear();
+            for (int32_t x : B) {
+                bool is_c = false;
+                for (int32_t c : centres) is_c |= (c == x);
+                if (!is_c) tmp.push_back(x);
+            }
+            std::sort(tmp.begin(), tmp.end(), byid);
+            rbk.verts.insert(rbk.verts.end(), tmp.begin(), tmp.end());
+            collect_edges(g, rbk.verts, centres, o.include_intra_clique != 0, rbk.edges);
+            reg(B);
+            g->rb.push_back(std::move(rbk));
+        } else {
+            newpending.push_back(v);
+            n_deferred++;
+            // D(v): everything v's blanket can reach before its turn
+            next_stamp(g);
+            int32_t st = g->stamp;
+            Dv.clear();
+            auto addv = [&](int32_t x) { if (g->vstamp[x] != st) { g->vstamp[x] = st; Dv.push_back(x); } };
+            for (int32_t x : B) addv(x);
+            std::vector<int32_t> work(centres.begin(), centres.end());
+            std::vector<uint8_t> dummy;
+            size_t wi = 0;
+            std::vector<int32_t> seen_owner;
+            while (wi < work.size() && Dv.size() <= DCAP) {
+                int32_t c = work[wi++];
+                for (int32_t oid : g->vowners[c]) {
+                    bool seen = false;
+                    for (int32_t so : seen_owner) seen |= (so == oid);
+                    if (seen) continue;
+                    seen_owner.push_back(oid);
+                    for (int32_t y : g->Dsets[oid]) {
+                        bool fresh = g->vstamp[y] != st;
+                        addv(y);
+                        // Dense: a newly reachable removable vertex is itself absorbed and brings its neighbourhood
+                        if (dense && fresh && g->in_set[y] && g->valive[y]) work.push_back(y);
+                    }
+                }
+                if (dense && c != v) {
+                    // neighbourhood of an absorbed vertex (stamps are in use: gather without closed_neighbourhood)
+                    for (int32_t eid : g->adj[c]) {
+                        const GEdge &e = g->edges[eid];
+                        for (int i = 0; i < e.nv; i++) {
+                            int32_t y = g->everts[e.vbeg + i];
+                            bool fresh = g->vstamp[y] != st;
+                            addv(y);
+                            if (fresh && g->in_set[y] && g->valive[y]) work.push_back(y);
+                        }
+                    }
+                }
+            }
+            if (Dv.size() > DCAP) { stop = true; continue; }
+            reg(Dv);
+            if (n_deferred > 256 + 2 * g->rb.size()) stop = true;
+        }
+    }
+    g->pending.swap(newpending);
+}
+
+// ================================================================================= rounds
+extern "C" int spg_graph_marginalize_begin(spg_graph *g, const int32_t *which, int n, const spg_options *opts, int rank, int nranks) {
+    if (!g || !opts || (n > 0 && !which) || nranks < 1 || rank < 0 || rank >= nranks) return SPG_EINVAL;
+    if (g->active) return set_err(g->ctx, SPG_ESTATE, "marginalize already in progress");
+    if (opts->pose_dim != g->d) return set_err(g->ctx, SPG_EINVAL, "pose_dim mismatch");
+    g->opts = *opts;
+    g->rank = rank; g->nranks = nranks;
+    g->pending.clear();
+    g->in_set.assign(g->vid.size(), 0);
+    for (int i = 0; i < n; i++) {
+        auto it = g->vidx.find(which[i]);
+        if (it == g->vidx.end() || !g->valive[it->second])
+            return set_err(g->ctx, SPG_EINVAL, "vertex needs to exist in order to be marginalized");
+        if (g->in_set[it->second]) continue;
+        g->in_set[it->second] = 1;
+        g->pending.push_back(it->second);
+    }
+    if (int rc = sync_device(g)) return rc;
+    g->active = true;
+    g->round_open = false;
+    g->round_no = 0;
+    g->stats = spg_marg_stats{};
+    g->log.clear();
+    return 0;
+}
+
+extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
+    if (!g || !g->active || g->round_open) return SPG_ESTATE;
+    double t0 = now_s();
+    schedule_round(g);
+    int B = (int)g->rb.size();
+    if (B == 0) { g->stats.host_seconds += now_s() - t0; return 0; }
+    const spg_options &o = g->opts;
+    const int d = g->d, nr = g->nranks;
+    // ---- contiguous, cost-balanced slices (cost ~ n^3 + E d^3)
+    std::vector<double> cost(B);
+    double total = 0;
+    for (int b = 0; b < B; b++) {
+        RoundBlanket &r = g->rb[b];
+        double nn = (double)d * (r.verts.size() - r.n_remove);
+        cost[b] = nn * nn * nn + (double)r.edges.size() * d * d * d + 1.0;
+        total += cost[b];
+    }
+    std::vector<int> first(nr + 1, B);
+    {
+        double acc = 0;
+        int q = 0;
+        first[0] = 0;
+        for (int b = 0; b < B; b++) {
+            while (q + 1 < nr && acc >= total * (q + 1) / nr) first[++q] = b;
+            acc += cost[b];
+        }
+        for (int qq = q + 1; qq <= nr; qq++) first[qq] = B;
+        first[nr] = B;
+    }
+    // ---- descriptors
+    g->h_blk.resize(B);
+    g->h_vpo.clear(); g->h_er.clear(); g->h_ev.clear();
+    g->chunk_hdr.assign(nr, 0);
+    std::vector<int64_t> chunk_len(nr, 0);
+    if (g->lidx.size() < g->vid.size()) g->lidx.resize(g->vid.size(), -1);
+    std::vector<int32_t> &lidx = g->lidx;
+    for (int q = 0; q < nr; q++) {
+        int64_t hdr = 0, body = 0;
+        for (int b = first[q]; b < first[q + 1]; b++) {
+            RoundBlanket &r = g->rb[b];
+            r.rank = q;
+            int k = (int)r.verts.size() - r.n_remove;
+            spg_blanket_desc &bd = g->h_blk[b];
+            memset(&bd, 0, sizeof bd);
+            bd.vert_begin = (int32_t)g->h_vpo.size();
+            bd.n_vert = (int32_t)r.verts.size();
+            bd.n_remove = r.n_remove;
+            for (size_t i = 0; i < r.verts.size(); i++) { g->h_vpo.push_back(g->vpose[r.verts[i]]); lidx[r.verts[i]] = (int32_t)i; }
+            bd.edge_begin = (int32_t)g->h_er.size();
+            bd.n_edge = (int32_t)r.edges.size();
+            for (int32_t eid : r.edges) {
+                const GEdge &e = g->edges[eid];
+                spg_edge_ref er;
+                er.off = e.off; er.len = e.len; er.kind = e.kind; er.vbegin = (int32_t)g->h_ev.size(); er.nv = e.nv;
+                for (int i = 0; i < e.nv; i++) g->h_ev.push_back(lidx[g->everts[e.vbeg + i]]);
+                g->h_er.push_back(er);
+            }
+            new_edge_budget(o, d, k, bd.n_new_max, bd.n_new_vert_max, bd.new_len);
+            bd.out_off = hdr;  // relative for now
+            hdr += SPG_OUT_LEN(bd.n_new_max, bd.n_new_vert_max);
+            bd.new_off = body;
+            body += bd.new_len;
+            bd.tinfo_off = -1;
+        }
+        g->chunk_hdr[q] = hdr;
+        chunk_len[q] = hdr + body;
+    }
+    int64_t clen = 0;
+    for (int q = 0; q < nr; q++) clen = std::max(clen, chunk_len[q]);
+    clen = align_up(std::max<int64_t>(clen, 1), 32);
+    int64_t region = align_up(g->used, 32);
+    int64_t need = region + clen * nr;
+    if (need > g->cap) {
+        // grow: pull device-only ranges into the mirror, re-allocate, push the whole mirror back
+        if (int rc = arena_ensure(g, need + need / 2)) return rc;
+        if (int rc = sync_device(g)) return rc;
+    }
+    for (int q = 0; q < nr; q++) {
+        int64_t base = region + clen * q;
+        for (int b = first[q]; b < first[q + 1]; b++) {
+            spg_blanket_desc &bd = g->h_blk[b];
+            bd.out_off += base;
+            bd.new_off += base + g->chunk_hdr[q];
+            g->rb[b].desc = bd;
+        }
+    }
+    if ((int64_t)g->host.size() < need) g->host.resize((size_t)need);
+    g->used = need;
+    g->dev_synced = need;  // the region is produced on the device
+    g->rinfo.n_blankets = B;
+    g->rinfo.my_first = first[g->rank];
+    g->rinfo.my_count = first[g->rank + 1] - first[g->rank];
+    g->rinfo.region_off = region;
+    g->rinfo.chunk_len = clen;
+    if (info) *info = g->rinfo;
+    g->round_open = true;
+    g->round_no++;
+    g->stats.host_seconds += now_s() - t0;
+    return 1;
+}
+
+extern "C" int spg_graph_round_compute(spg_graph *g) {
+    if (!g || !g->active || !g->round_open) return SPG_ESTATE;
+    double t0 = now_s();
+    spg_round_desc rd;
+    rd.opts = &g->opts;
+    rd.n_blankets = g->rinfo.n_blankets;
+    rd.first = g->rinfo.my_first;
+    rd.count = g->rinfo.my_count;
+    rd.blankets = g->h_blk.data();
+    rd.vert_pose_off = g->h_vpo.data();
+    rd.edges = g->h_er.data();
+    rd.edge_vert = g->h_ev.data();
+    rd.n_vert_total = (int64_t)g->h_vpo.size();
+    rd.n_edge_total = (int64_t)g->h_er.size();
+    rd.n_edge_vert_total = (int64_t)g->h_ev.size();
+    int rc = g->ctx->be.run_round(g->ctx->be.user, g->dev, &rd);
+    g->stats.device_seconds += now_s() - t0;
+    if (rc && g->ctx->is_hip) snprintf(g->ctx->err, sizeof g->ctx->err, "%s", spg::hip_backend_error(&g->ctx->be));
+    return rc;
+}
+
+extern "C" int spg_graph_round_commit(spg_graph *g) {
+    if (!g || !g->active || !g->round_open) return SPG_ESTATE;
+    double t0 = now_s();
+    const int nr = g->nranks;
+    int rc = g->ctx->be.synchronize(g->ctx->be.user);
+    if (rc) return rc;
+    // read back the out-record part of every rank chunk
+    for (int q = 0; q < nr; q++) {
+        if (g->chunk_hdr[q] == 0) continue;
+        int64_t base = g->rinfo.region_off + g->rinfo.chunk_len * q;
+        rc = g->ctx->be.download(g->ctx->be.user, g->host.data() + base, (char *)g->dev + base * 8, g->chunk_hdr[q]);
+        if (rc) return rc;
+    }
+    double t1 = now_s();
+    g->stats.device_seconds += t1 - t0;
+    // the payload part of the region stays device-only until someone asks for it
+    {
+        int64_t lo = g->rinfo.region_off, hi = g->rinfo.region_off + g->rinfo.chunk_len * nr;
+        if (g->stale_hi <= g->stale_lo) { g->stale_lo = lo; g->stale_hi = hi; }
+        else { g->stale_lo = std::min(g->stale_lo, lo); g->stale_hi = std::max(g->stale_hi, hi); }
+    }
+    // updateInputGraph (src/vertex_remover.cpp:500-546), in list order
+    for (size_t b = 0; b < g->rb.size(); b++) {
+        RoundBlanket &r = g->rb[b];
+        const spg_blanket_desc &bd = r.desc;
+        const double *rec = g->host.data() + bd.out_off;
+        int status = (int)rec[0], inf = (int)rec[1], n_new = (int)rec[4];
+        g->log.push_back({g->vid[r.root], g->round_no, status, inf, rec[2], rec[3]});
+        g->stats.max_blanket = std::max(g->stats.max_blanket, (int32_t)r.verts.size());
+        bool fine = (status == SPG_OK || status == SPG_ST_KLD_NOT_PD);
+        if (!fine) { g->stats.n_bad_status++; continue; }
+        if (std::isfinite(rec[2])) g->stats.kld_sum += rec[2];
+        for (int32_t eid : r.edges) {
+            GEdge &e = g->edges[eid];
+            e.alive = 0;
+            g->n_live_e--;
+            for (int i = 0; i < e.nv; i++) {
+                auto &av = g->adj[g->everts[e.vbeg + i]];
+                for (size_t j = 0; j < av.size(); j++) if (av[j] == eid) { av[j] = av.back(); av.pop_back(); break; }
+            }
+        }
+        for (int i = 0; i < r.n_remove; i++) {
+            int32_t v = r.verts[i];
+            g->valive[v] = 0;
+            g->adj[v].clear();
+            g->n_live_v--;
+            g->stats.n_removed++;
+        }
+        int vpos = 0;
+        for (int e = 0; e < n_new; e++) {
+            int kind = (int)rec[SPG_OUT_HDR + 4 * e + 0];
+            int64_t rel = (int64_t)rec[SPG_OUT_HDR + 4 * e + 1];
+            int32_t len = (int32_t)rec[SPG_OUT_HDR + 4 * e + 2];
+            int nv = (int)rec[SPG_OUT_HDR + 4 * e + 3];
+            std::vector<int32_t> vix(nv);
+            for (int i = 0; i < nv; i++) vix[i] = r.verts[(int)rec[SPG_OUT_HDR + 4 * bd.n_new_max + vpos + i]];
+            vpos += nv;
+            add_edge_idx(g, kind, nv, vix.data(), bd.new_off + rel, len);
+            g->stats.n_new_edges++;
+        }
+    }
+    g->round_open = false;
+    g->stats.n_rounds = g->round_no;
+    g->stats.host_seconds += now_s() - t1;
+    return 0;
+}
+
+extern "C" int spg_graph_marginalize_end(spg_graph *g, spg_marg_stats *stats) {
+    if (!g || !g->active) return SPG_ESTATE;
+    g->active = false;
+    g->round_open = false;
+    if (g->ctx->is_hip) g->stats.n_launches = spg::hip_backend_launches(&g->ctx->be);
+    if (stats) *stats = g->stats;
+    return g->stats.n_bad_status ? SPG_EBLANKET : 0;
+}
+
+extern "C" int spg_graph_marginalize(spg_graph *g, const int32_t *which, int n, const spg_options *opts, spg_marg_stats *stats) {
+    int launches0 = (g && g->ctx->is_hip) ? spg::hip_backend_launches(&g->ctx->be) : 0;
+    int rc = spg_graph_marginalize_begin(g, which, n, opts, 0, 1);
+    if (rc) return rc;
+    for (;;) {
+        rc = spg_graph_round_prepare(g, nullptr);
+        if (rc < 0) break;
+        if (rc == 0) break;
+        if ((rc = spg_graph_round_compute(g)) != 0) break;
+        if ((rc = spg_graph_round_commit(g)) != 0) break;
+    }
+    int rc2 = spg_graph_marginalize_end(g, stats);
+    if (stats && g->ctx->is_hip) stats->n_launches -= launches0;
+    return rc < 0 ? rc : rc2;
+}
+
+extern "C" int spg_graph_last_blanket_count(const spg_graph *g) { return g ? (int)g->log.size() : 0; }
+extern "C" int spg_graph_last_blankets(const spg_graph *g, int32_t *root_id, int32_t *round, int32_t *status, int32_t *info, double *kld, double *min_gap) {
+    if (!g) return SPG_EINVAL;
+    for (size_t i = 0; i < g->log.size(); i++) {
+        if (root_id) root_id[i] = g->log[i].root_id;
+        if (round) round[i] = g->log[i].round;
+        if (status) status[i] = g->log[i].status;
+        if (info) info[i] = g->log[i].info;
+        if (kld) kld[i] = g->log[i].kld;
+        if (min_gap) min_gap[i] = g->log[i].min_gap;
+    }
+    return (int)g->log.size();
+}
+
+// ================================================================================= batch entry
+// Self-contained batch: builds a temporary arena [poses | edge records | out records | new slots |
+// target infos], runs ONE round through the same backend entry the graph uses, unpacks the result.
+extern "C" int spg_marginalize_batch(spg_ctx *ctx, const spg_options *o, const spg_batch *bt, spg_result *r) {
+    if (!ctx || !o || !bt || !r) return SPG_EINVAL;
+    const int d = o->pose_dim;
+    if (d != 3 && d != 6) return SPG_EINVAL;
+    const int ps = pose_stride(d);
+    const int B = bt->B;
+    r->new_edge_off[0] = 0;
+    r->new_edge_vert_off[0] = 0;
+    r->new_edge_data_off[0] = 0;
+    if (B == 0) return 0;
+    const int V = bt->vert_off[B], E = bt->edge_off[B];
+    const int64_t ED = bt->edge_data_off[E];
+    std::vector<double> host;
+    int64_t o_pose = 0, o_edge = (int64_t)V * ps;
+    int64_t cur = align_up(o_edge + ED, 32);
+    std::vector<spg_blanket_desc> blk(B);
+    std::vector<int64_t> vpo(V);
+    std::vector<spg_edge_ref> er(E);
+    for (int v = 0; v < V; v++) vpo[v] = o_pose + (int64_t)v * ps;
+    for (int e = 0; e < E; e++) {
+        er[e].off = o_edge + bt->edge_data_off[e];
+        er[e].len = (int32_t)(bt->edge_data_off[e + 1] - bt->edge_data_off[e]);
+        er[e].kind = bt->edge_kind[e];
+        er[e].vbegin = bt->edge_vert_off[e];
+        er[e].nv = bt->edge_vert_off[e + 1] - bt->edge_vert_off[e];
+    }
+    for (int b = 0; b < B; b++) {
+        spg_blanket_desc &bd = blk[b];
+        memset(&bd, 0, sizeof bd);
+        bd.vert_begin = bt->vert_off[b];
+        bd.n_vert = bt->vert_off[b + 1] - bt->vert_off[b];
+        bd.n_remove = bt->n_remove[b];
+        bd.edge_begin = bt->edge_off[b];
+        bd.n_edge = bt->edge_off[b + 1] - bt->edge_off[b];
+        int k = bd.n_vert - bd.n_remove;
+        new_edge_budget(*o, d, std::max(k, 0), bd.n_new_max, bd.n_new_vert_max, bd.new_len);
+        bd.out_off = cur; cur += SPG_OUT_LEN(bd.n_new_max, bd.n_new_vert_max);
+        bd.new_off = cur; cur += bd.new_len;
+        if (r->target_info) { int64_t n = (int64_t)d * std::max(k, 0); bd.tinfo_off = cur; cur += n * n; }
+        else bd.tinfo_off = -1;
+    }
+    int64_t in_len = align_up(o_edge + ED, 32);
+    host.assign((size_t)cur, 0.0);
+    memcpy(host.data(), bt->pose, (size_t)V * ps * 8);
+    if (ED) memcpy(host.data() + o_edge, bt->edge_data, (size_t)ED * 8);
+    void *dev = ctx->be.alloc(ctx->be.user, cur);
+    if (!dev) return set_err(ctx, SPG_ENOMEM, "arena allocation failed");
+    int rc = ctx->be.upload(ctx->be.user, dev, host.data(), in_len);
+    spg_round_desc rd;
+    rd.opts = o;
+    rd.n_blankets = B; rd.first = 0; rd.count = B;
+    rd.blankets = blk.data();
+    rd.vert_pose_off = vpo.data();
+    rd.edges = er.data();
+    rd.edge_vert = bt->edge_vert;
+    rd.n_vert_total = V; rd.n_edge_total = E; rd.n_edge_vert_total = bt->edge_vert_off[E];
+    if (!rc) rc = ctx->be.run_round(ctx->be.user, dev, &rd);
+    if (!rc) rc = ctx->be.synchronize(ctx->be.user);
+    if (!rc && cur > in_len) rc = ctx->be.download(ctx->be.user, host.data() + in_len, (char *)dev + in_len * 8, cur - in_len);
+    ctx->be.release(ctx->be.user, dev);
+    if (rc) {
+        if (ctx->is_hip) snprintf(ctx->err, sizeof ctx->err, "%s", spg::hip_backend_error(&ctx->be));
+        return rc;
+    }
+    int32_t ne = 0, nev = 0;
+    int64_t ned = 0;
+    for (int b = 0; b < B; b++) {
+        const spg_blanket_desc &bd = blk[b];
+        const double *rec = host.data() + bd.out_off;
+        r->status[b] = (int32_t)rec[0];
+        if (r->info) r->info[b] = (int32_t)rec[1];
+        r->kld[b] = rec[2];
+        if (r->min_gap) r->min_gap[b] = rec[3];
+        int n_new = (int)rec[4];
+        int k = bd.n_vert - bd.n_remove;
+        if (r->target_info && k > 0) {
+            int64_t n = (int64_t)d * k;
+            memcpy(r->target_info + r->target_info_off[b], host.data() + bd.tinfo_off, (size_t)(n * n) * 8);
+        }
+        int vpos = 0;
+        for (int e = 0; e < n_new; e++) {
+            int kind = (int)rec[SPG_OUT_HDR + 4 * e + 0];
+            int64_t rel = (int64_t)rec[SPG_OUT_HDR + 4 * e + 1];
+            int64_t len = (int64_t)rec[SPG_OUT_HDR + 4 * e + 2];
+            int nv = (int)rec[SPG_OUT_HDR + 4 * e + 3];
+            if (ne + 1 > r->new_edge_cap || nev + nv > r->new_edge_vert_cap || ned + len > r->new_edge_data_cap) return SPG_ECAPACITY;
+            r->new_edge_kind[ne] = kind;
+            for (int i = 0; i < nv; i++)
+                r->new_edge_vert[nev++] = bt->vert_id[bd.vert_begin + (int)rec[SPG_OUT_HDR + 4 * bd.n_new_max + vpos + i]];
+            vpos += nv;
+            memcpy(r->new_edge_data + ned, host.data() + bd.new_off + rel, (size_t)len * 8);
+            ned += len;
+            ne++;
+            r->new_edge_vert_off[ne] = nev;
+            r->new_edge_data_off[ne] = ned;
+        }
+        r->new_edge_off[b + 1] = ne;
+    }
+    return 0;
+}

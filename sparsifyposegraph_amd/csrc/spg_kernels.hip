@@ -1,0 +1,890 @@
+// csrc/spg_kernels.hip — the per-blanket marginalisation kernel for gfx950 and the HIP backend
+// that launches one conflict-free round of blankets.
+//
+// One workgroup per Markov blanket (64 lanes = one wavefront for blankets whose tiles fit in LDS,
+// 256 lanes with an L2-resident workspace for the rare large ones). The whole per-vertex iteration
+// of the reference's VertexRemover::remove (src/vertex_remover.cpp:108-132) runs inside the kernel:
+//
+//   gather     poses + edge records of the blanket straight from the HBM-resident arena
+//   assemble   H = sum_e J_e^T Omega_e J_e                   (g2o buildSystem, src/vertex_remover.cpp:397-402)
+//   Schur      Lambda_t = H_kk - H_mk^T LLT(H_mm)^-1 H_mk    (src/vertex_remover.cpp:444-449)
+//   topology   pseudo-Chow-Liu: (Lambda_t + I)^-1, pairwise log-det weights, Kruskal
+//                                                             (src/pseudo_chow_liu.cpp:33-87,169-196,253-289)
+//   skeleton   z_ab = x_a^-1 x_b, Jacobians at zero error     (src/topology_provider_binary.hpp:40-47,
+//                                                              src/vertex_remover.cpp:466-498)
+//   recover    eig(Lambda_t), gauge drop, Sigma = U S U^T, X_e = (J_e Sigma J_e^T)^-1
+//                                                             (src/logdet_function.cpp:14-64,236-279)
+//   KLD        1/2 (tr(S M) - logdet M - logdet S - r), M = U^T (J^T X J) U
+//                                                             (src/logdet_function.cpp:119-133,281-323)
+//   scatter    new edge records + per-blanket output record back into the arena
+//
+// 3x3 / 6x6 information blocks, Jacobians and the n x n tiles (n = d*k) live in LDS; HBM traffic is
+// the algorithmic minimum: every pose and edge record is read once, every new record written once.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "../../include/spg.h"
+#include "spg_dev_geom.hpp"
+#include "spg_dev_la.hpp"
+#include "spg_internal.h"
+
+using namespace spgdev;
+
+namespace {
+
+constexpr int EC = 4;  // edges whose Jacobians are staged per chunk
+
+// LDS / workspace carve-up for one blanket (all offsets in doubles). Monotone in k and m, so the
+// layout of the largest blanket of a launch bounds every blanket in it.
+struct Layout {
+    int n, nm, ld, ldm, P, NE;
+    int o_pose, o_red, o_cs, o_ev, o_S, o_w, o_ldb, o_Lb, o_nJ, o_X, o_eJ, o_eO, o_eT, o_int, small_doubles;
+    int o_M1, o_M2, o_M3, o_Hmm, o_Hmk, mat_doubles;
+    // int area offsets (in ints, relative to o_int)
+    int i_perm, i_keep, i_sorted, i_comp, i_pairs, i_ev, i_misc, int_count;
+};
+
+__host__ __device__ inline Layout make_layout(int D, int nt, int k, int m) {
+    Layout L;
+    int DD = D * D;
+    L.n = D * k; L.nm = D * m;
+    L.ld = L.n | 1; L.ldm = L.nm | 1;
+    L.P = k * (k - 1) / 2;
+    L.NE = k > 0 ? k : 1;  // most new edges any algorithm emits (GLC tree: root + k-1)
+    int psz = (D == 6) ? 12 : 3;
+    int o = 0;
+    L.o_pose = o; o += (k + m) * psz;
+    L.o_red = o; o += nt;
+    L.o_cs = o; o += L.n + 4;
+    L.o_ev = o; o += L.n;
+    L.o_S = o; o += L.n;
+    L.o_w = o; o += (L.P > 0 ? L.P : 1);
+    L.o_ldb = o; o += k + 1;
+    L.o_Lb = o; o += k * DD;
+    L.o_nJ = o; o += L.NE * 2 * DD;
+    L.o_X = o; o += L.NE * DD;
+    L.o_eJ = o; o += EC * 2 * DD;
+    L.o_eO = o; o += EC * DD;
+    L.o_eT = o; o += 2 * DD;
+    L.o_int = o;
+    int io = 0;
+    L.i_perm = io; io += L.n;
+    L.i_keep = io; io += L.n;
+    L.i_sorted = io; io += (L.P > 0 ? L.P : 1);
+    L.i_comp = io; io += k + 1;
+    L.i_pairs = io; io += 2 * L.NE;
+    L.i_ev = io; io += 2 * EC;
+    L.i_misc = io; io += 8;
+    L.int_count = io;
+    o += (io + 1) / 2;
+    L.small_doubles = o;
+    int mo = 0;
+    L.o_M1 = mo; mo += L.n * L.ld;
+    L.o_M2 = mo; mo += L.n * L.ld;
+    L.o_M3 = mo; mo += L.n * L.ld;
+    L.o_Hmm = mo; mo += L.nm * L.ldm;
+    L.o_Hmk = mo; mo += L.nm * L.ld;
+    L.mat_doubles = mo;
+    return L;
+}
+
+struct KArgs {
+    double *arena;
+    const spg_blanket_desc *blk;
+    const int64_t *vpo;
+    const spg_edge_ref *er;
+    const int32_t *ev;
+    const int32_t *list;
+    double *gws;
+    int64_t gws_stride;
+    int topology, algorithm, flags;
+    double chord_ratio;
+};
+
+// upper-triangular (row-wise) index of (r,c), r <= c
+__device__ __forceinline__ int utri(int r, int c, int D) { return r * D - (r * (r - 1)) / 2 + (c - r); }
+
+template <int D, int NT, bool GWS>
+__global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
+    extern __shared__ double smem[];
+    constexpr int DD = D * D;
+    constexpr int PS = (D == 6) ? 7 : 3;    // pose / measurement doubles in the arena
+    constexpr int PSZ = (D == 6) ? 12 : 3;  // pose doubles in LDS
+    constexpr int REC = PS + D * (D + 1) / 2;
+    const int tid = threadIdx.x;
+    const int b = a.list[blockIdx.x];
+    const spg_blanket_desc bd = a.blk[b];
+    const int nv = bd.n_vert, m = bd.n_remove, k = nv - m;
+    const Layout L = make_layout(D, NT, k, m);
+    const int n = L.n, nm = L.nm, ld = L.ld, ldm = L.ldm;
+    double *mat = GWS ? (a.gws + (size_t)blockIdx.x * (size_t)a.gws_stride) : (smem + L.small_doubles);
+    double *pose = smem + L.o_pose, *cs = smem + L.o_cs, *ev = smem + L.o_ev, *Sv = smem + L.o_S;
+    double *w = smem + L.o_w, *ldb = smem + L.o_ldb, *Lb = smem + L.o_Lb, *nJ = smem + L.o_nJ, *X = smem + L.o_X;
+    double *eJ = smem + L.o_eJ, *eO = smem + L.o_eO, *eT = smem + L.o_eT;
+    int *ints = reinterpret_cast<int *>(smem + L.o_int);
+    int *perm = ints + L.i_perm, *keep = ints + L.i_keep, *sorted = ints + L.i_sorted, *comp = ints + L.i_comp;
+    int *pairs = ints + L.i_pairs, *echv = ints + L.i_ev, *misc = ints + L.i_misc;
+    double *M1 = mat + L.o_M1, *M2 = mat + L.o_M2, *M3 = mat + L.o_M3, *Hmm = mat + L.o_Hmm, *Hmk = mat + L.o_Hmk;
+    Team<NT> T{tid, smem + L.o_red, misc + 0};
+    double *arena = a.arena;
+    double *orec = arena + bd.out_off;
+
+    int status = SPG_OK, info = 0, n_new = 0;
+    double kld = __builtin_nan(""), min_gap = __builtin_inf();
+
+    auto finish = [&]() {
+        if (tid == 0) {
+            orec[0] = (double)status; orec[1] = (double)info; orec[2] = kld; orec[3] = min_gap; orec[4] = (double)n_new;
+            for (int e = 0; e < n_new; e++) {
+                orec[SPG_OUT_HDR + 4 * e + 0] = (double)SPG_EDGE_BINARY;
+                orec[SPG_OUT_HDR + 4 * e + 1] = (double)(e * REC);
+                orec[SPG_OUT_HDR + 4 * e + 2] = (double)REC;
+                orec[SPG_OUT_HDR + 4 * e + 3] = 2.0;
+                orec[SPG_OUT_HDR + 4 * bd.n_new_max + 2 * e + 0] = (double)(m + pairs[2 * e]);
+                orec[SPG_OUT_HDR + 4 * bd.n_new_max + 2 * e + 1] = (double)(m + pairs[2 * e + 1]);
+            }
+        }
+    };
+
+    // ---------------------------------------------------------------- gather poses, clear H
+    if (tid == 0) { misc[0] = 0; misc[1] = 0; }
+    for (int v = tid; v < nv; v += NT) {
+        const double *p = arena + a.vpo[bd.vert_begin + v];
+        if (D == 6) iso_from_tq(p, pose + v * PSZ);
+        else { pose[v * PSZ] = p[0]; pose[v * PSZ + 1] = p[1]; pose[v * PSZ + 2] = p[2]; }
+    }
+    for (int i = tid; i < n * ld; i += NT) M1[i] = 0.0;
+    for (int i = tid; i < nm * ldm; i += NT) Hmm[i] = 0.0;
+    for (int i = tid; i < nm * ld; i += NT) Hmk[i] = 0.0;
+    T.sync();
+    if (bd.n_edge == 0 || m < 1) { status = SPG_ST_EMPTY_BLANKET; finish(); return; }
+    if (a.algorithm != SPG_ALG_NFR) { status = SPG_ST_UNSUPPORTED; finish(); return; }
+
+    // ---------------------------------------------------------------- assemble H (a6)
+    auto hadd = [&](int R, int Cc, double val) {
+        if (R < nm) {
+            if (Cc < nm) Hmm[R * ldm + Cc] += val;
+            else Hmk[R * ld + (Cc - nm)] += val;
+        } else if (Cc >= nm) {
+            M1[(R - nm) * ld + (Cc - nm)] += val;
+        }
+    };
+    for (int base = 0; base < bd.n_edge; base += EC) {
+        int cnt = min(EC, bd.n_edge - base);
+        if (tid < cnt) {
+            const spg_edge_ref er = a.er[bd.edge_begin + base + tid];
+            int vi = 0, vj = 0;
+            if (er.kind == SPG_EDGE_BINARY) {
+                vi = a.ev[er.vbegin]; vj = a.ev[er.vbegin + 1];
+                const double *rec = arena + er.off;
+                if (D == 6) {
+                    double Z[kIso];
+                    iso_from_tq(rec, Z);
+                    se3_edge_jac(pose + vi * PSZ, pose + vj * PSZ, Z, eJ + tid * 2 * DD, eJ + tid * 2 * DD + DD, nullptr);
+                } else {
+                    se2_edge_jac(pose + vi * PSZ, pose + vj * PSZ, rec, eJ + tid * 2 * DD, eJ + tid * 2 * DD + DD, nullptr);
+                }
+            } else {
+                misc[1] = 1;  // GLC edge inside an NFR blanket: no provider applies
+            }
+            echv[2 * tid] = vi; echv[2 * tid + 1] = vj;
+        }
+        for (int it = tid; it < cnt * DD; it += NT) {
+            int e = it / DD, rc = it - e * DD, r = rc / D, c = rc - r * D;
+            const spg_edge_ref er = a.er[bd.edge_begin + base + e];
+            int lo = r < c ? r : c, hi = r < c ? c : r;
+            eO[it] = arena[er.off + PS + utri(lo, hi, D)];
+        }
+        T.sync();
+        for (int e = 0; e < cnt; e++) {
+            const double *Ji = eJ + e * 2 * DD, *Jj = Ji + DD, *Om = eO + e * DD;
+            for (int it = tid; it < 2 * DD; it += NT) {
+                int wch = it / DD, rc = it - wch * DD, r = rc / D, c = rc - r * D;
+                const double *J = wch ? Jj : Ji;
+                double s = 0;
+#pragma unroll
+                for (int p = 0; p < D; p++) s += Om[r * D + p] * J[p * D + c];
+                eT[it] = s;
+            }
+            T.sync();
+            int vi = echv[2 * e], vj = echv[2 * e + 1];
+            for (int it = tid; it < 3 * DD; it += NT) {
+                int blk = it / DD, rc = it - blk * DD, r = rc / D, c = rc - r * D;
+                const double *Ja = (blk == 2) ? Jj : Ji;
+                const double *Tb = (blk == 0) ? eT : eT + DD;
+                double s = 0;
+#pragma unroll
+                for (int p = 0; p < D; p++) s += Ja[p * D + r] * Tb[p * D + c];
+                if (blk == 0) hadd(vi * D + r, vi * D + c, s);
+                else if (blk == 2) hadd(vj * D + r, vj * D + c, s);
+                else if (vi != vj) { hadd(vi * D + r, vj * D + c, s); hadd(vj * D + c, vi * D + r, s); }
+            }
+            T.sync();
+        }
+    }
+    if (misc[1]) { status = SPG_ST_UNSUPPORTED; finish(); return; }
+
+    // ---------------------------------------------------------------- Schur complement (a7)
+    chol_lower<NT>(T, Hmm, nm, ldm);
+    if (misc[0]) { status = SPG_ST_HMM_NOT_PD; finish(); return; }
+    tri_solve_lower<NT>(T, Hmm, nm, ldm, Hmk, n, ld);
+    {
+        int sh = ceil_log2(n), tot = n << sh;
+        double bad = 0;
+        for (int it = tid; it < tot; it += NT) {
+            int i = it >> sh, j = it & ((1 << sh) - 1);
+            if (j < n) {
+                double s = 0;
+                for (int p = 0; p < nm; p++) s += Hmk[p * ld + i] * Hmk[p * ld + j];
+                double v = M1[i * ld + j] - s;
+                M1[i * ld + j] = v;
+                if (!isfinite(v)) bad = 1;
+            }
+        }
+        double anybad = T.sum(bad);
+        mirror_upper<NT>(T, M1, n, ld);
+        if (anybad > 0) { status = SPG_ST_NONFINITE; finish(); return; }
+    }
+    if (bd.tinfo_off >= 0) {
+        double *dst = arena + bd.tinfo_off;
+        for (int it = tid; it < n * n; it += NT) { int i = it / n, j = it - i * n; dst[it] = M1[i * ld + j]; }
+    }
+    if (k < 2) { finish(); return; }
+
+    // ---------------------------------------------------------------- sparsity pattern (a8)
+    int ne;
+    {
+        int msub = (int)((1 + a.chord_ratio) * (k - 1));
+        bool full = msub >= k * (k - 1) / 2;
+        if (k == 2) ne = 1;
+        else if (a.topology == SPG_TOPO_TREE) ne = k - 1;
+        else if (a.topology == SPG_TOPO_DENSE || (a.topology == SPG_TOPO_SUBGRAPH && full)) ne = k * (k - 1) / 2;
+        else if (a.topology == SPG_TOPO_SUBGRAPH) ne = msub;
+        else { status = SPG_ST_UNSUPPORTED; finish(); return; }
+        if (ne * D != n - D) {
+            // Chow-Liu still runs in the reference before optimizeInformation discovers that no closed
+            // form exists (src/optimizer.cpp:21); the interior-point branch is out of scope.
+            status = SPG_ST_NEEDS_INTERIOR_POINT; finish(); return;
+        }
+    }
+    if (k == 2) {
+        if (tid == 0) { pairs[0] = 0; pairs[1] = 1; }
+        T.sync();
+    } else {
+        // Sigma~ = (Lambda_t + 1 I)^-1 in M2
+        for (int it = tid; it < n * ld; it += NT) M2[it] = M1[it];
+        T.sync();
+        for (int i = tid; i < n; i += NT) M2[i * ld + i] += 1.0;
+        T.sync();
+        chol_lower<NT>(T, M2, n, ld);
+        if (misc[0]) { status = SPG_ST_TIKHONOV_NOT_PD; finish(); return; }
+        tri_inverse_lower<NT>(T, M2, M3, n, ld);
+        gram_lower_inverse<NT>(T, M3, M2, n, ld);
+        // per-vertex diagonal blocks: Cholesky + log det
+        for (int v = tid; v < k; v += NT) {
+            double Ab[DD];
+#pragma unroll
+            for (int r = 0; r < D; r++)
+#pragma unroll
+                for (int c = 0; c < D; c++) Ab[r * D + c] = M2[(v * D + r) * ld + v * D + c];
+            if (!chol_reg<D>(Ab)) misc[0] = 1;
+            double s = 0;
+#pragma unroll
+            for (int r = 0; r < D; r++) {
+                s += log(Ab[r * D + r]);
+#pragma unroll
+                for (int c = 0; c < D; c++) Lb[v * DD + r * D + c] = Ab[r * D + c];
+            }
+            ldb[v] = 2.0 * s;
+        }
+        T.sync();
+        // pair weights w = ld_i + ld_j - ld_{ij}, ld_{ij} = ld_i + logdet(S_jj - S_ji S_ii^-1 S_ij)
+        for (int p = tid; p < L.P; p += NT) {
+            int i = 0, rem = p;
+            while (rem >= k - 1 - i) { rem -= k - 1 - i; i++; }
+            int j = i + 1 + rem;
+            const double *Li = Lb + i * DD;
+            double Y[DD];
+#pragma unroll
+            for (int c = 0; c < D; c++) {
+#pragma unroll
+                for (int r = 0; r < D; r++) {
+                    double s = M2[(i * D + r) * ld + j * D + c];
+#pragma unroll
+                    for (int q = 0; q < D; q++) if (q < r) s -= Li[r * D + q] * Y[q * D + c];
+                    Y[r * D + c] = s / Li[r * D + r];
+                }
+            }
+            double Sb[DD];
+#pragma unroll
+            for (int r = 0; r < D; r++)
+#pragma unroll
+                for (int c = 0; c < D; c++) if (c <= r) {
+                    double s = M2[(j * D + r) * ld + j * D + c];
+#pragma unroll
+                    for (int q = 0; q < D; q++) s -= Y[q * D + r] * Y[q * D + c];
+                    Sb[r * D + c] = s;
+                }
+            if (!chol_reg<D>(Sb)) misc[0] = 1;
+            double s = 0;
+#pragma unroll
+            for (int r = 0; r < D; r++) s += log(Sb[r * D + r]);
+            double lxy = ldb[i] + 2.0 * s;
+            w[p] = -((ldb[i] + ldb[j]) - lxy);  // stored negated: ascending sort == max-heap pop order
+        }
+        T.sync();
+        if (misc[0]) { status = SPG_ST_TIKHONOV_NOT_PD; finish(); return; }
+        sort_ascending<NT>(T, w, 1, L.P, sorted);
+        if (tid == 0) {
+            // Kruskal in pop order (src/pseudo_chow_liu.cpp:253-289); first `ne` of the bin are used
+            for (int v = 0; v < k; v++) comp[v] = v;
+            int nacc = 0, last = 0;
+            // accepted edges first; rejected ones are only needed when ne > k-1, which has no closed form
+            for (int s = 0; s < L.P && nacc < k - 1; s++) {
+                int p = sorted[s];
+                int i = 0, rem = p;
+                while (rem >= k - 1 - i) { rem -= k - 1 - i; i++; }
+                int j = i + 1 + rem;
+                int ci = comp[i], cj = comp[j];
+                if (ci != cj) {
+                    pairs[2 * nacc] = i; pairs[2 * nacc + 1] = j;
+                    nacc++;
+                    for (int v = 0; v < k; v++) if (comp[v] == cj) comp[v] = ci;
+                }
+                last = s;
+            }
+            int upto = min(last + 1, L.P - 1);
+            double g = __builtin_inf();
+            for (int s = 0; s < upto; s++) {
+                double x = -w[sorted[s]], y = -w[sorted[s + 1]];
+                double den = fmax(fmax(fabs(x), fabs(y)), 1e-300);
+                g = fmin(g, (x - y) / den);
+            }
+            cs[0] = g;
+        }
+        T.sync();
+        min_gap = cs[0];
+        T.sync();
+    }
+
+    // ---------------------------------------------------------------- new edge skeleton (a9, a10)
+    for (int e = tid; e < ne; e += NT) {
+        int va = m + pairs[2 * e], vb = m + pairs[2 * e + 1];
+        double *rec = arena + bd.new_off + (int64_t)e * REC;
+        if (D == 6) {
+            double Z[kIso], q[4];
+            iso_inv_mul(pose + va * PSZ, pose + vb * PSZ, Z);
+            R_to_quat(Z, q);
+            rec[0] = Z[9]; rec[1] = Z[10]; rec[2] = Z[11]; rec[3] = q[0]; rec[4] = q[1]; rec[5] = q[2]; rec[6] = q[3];
+            se3_edge_jac(pose + va * PSZ, pose + vb * PSZ, Z, nJ + e * 2 * DD, nJ + e * 2 * DD + DD, nullptr);
+        } else {
+            double z[3];
+            se2_between(pose + va * PSZ, pose + vb * PSZ, z);
+            rec[0] = z[0]; rec[1] = z[1]; rec[2] = z[2];
+            se2_edge_jac(pose + va * PSZ, pose + vb * PSZ, z, nJ + e * 2 * DD, nJ + e * 2 * DD + DD, nullptr);
+        }
+    }
+    T.sync();
+    if (ne == 1) {
+        // single-measurement case goes through sparseJacobian(): entries below epsilon are dropped
+        // (src/logdet_function.cpp:243-247,335)
+        for (int it = tid; it < 2 * DD; it += NT) if (fabs(nJ[it]) < 2.220446049250313e-16) nJ[it] = 0.0;
+        T.sync();
+    }
+
+    // ---------------------------------------------------------------- spectrum of Lambda_t (a11)
+    for (int it = tid; it < n * ld; it += NT) M3[it] = M1[it];
+    T.sync();
+    if (!jacobi_eigh<NT>(T, M3, M2, n, ld, cs)) { status = SPG_ST_EIG_FAIL; finish(); return; }
+    for (int i = tid; i < n; i += NT) ev[i] = M3[i * ld + i];
+    T.sync();
+    sort_ascending<NT>(T, ev, 1, n, perm);
+    const int r = n - D;
+    {
+        double cnt = 0;
+        for (int i = tid; i < n; i += NT) cnt += (ev[i] < 1e-5) ? 1.0 : 0.0;
+        int smalleigs = (int)T.sum(cnt);
+        if (smalleigs <= D) {
+            for (int j = tid; j < r; j += NT) { int idx = perm[D + j]; keep[j] = idx; Sv[j] = 1.0 / ev[idx]; }
+        } else {
+            info |= SPG_INFO_RANK_DEFICIENT;
+            if (tid == 0) {
+                // chooseDimensions (src/logdet_function.cpp:66-81): drop the D candidates with the
+                // smallest ||J u||; S clamped as at src/logdet_function.cpp:55
+                double *nrm = cs;  // smalleigs <= n doubles
+                for (int c = 0; c < smalleigs; c++) {
+                    int col = perm[c];
+                    double s2 = 0;
+                    for (int e = 0; e < ne; e++) {
+                        int oa = pairs[2 * e] * D, ob = pairs[2 * e + 1] * D;
+                        const double *Ja = nJ + e * 2 * DD, *Jb = Ja + DD;
+                        for (int rr = 0; rr < D; rr++) {
+                            double s = 0;
+                            for (int p = 0; p < D; p++) {
+                                double ja = Ja[rr * D + p], jb = Jb[rr * D + p];
+                                if (fabs(ja) >= 2.220446049250313e-16) s += ja * M2[(oa + p) * ld + col];
+                                if (fabs(jb) >= 2.220446049250313e-16) s += jb * M2[(ob + p) * ld + col];
+                            }
+                            s2 += s * s;
+                        }
+                    }
+                    nrm[c] = sqrt(s2);
+                }
+                // mark the D smallest (norm, then sorted position); keep[] doubles as the mark array
+                for (int i = 0; i < n; i++) keep[i] = 0;
+                for (int t = 0; t < D; t++) {
+                    int best = -1;
+                    for (int c = 0; c < smalleigs; c++) {
+                        if (keep[c]) continue;
+                        if (best < 0 || nrm[c] < nrm[best]) best = c;
+                    }
+                    keep[best] = 1;
+                }
+                double lmax = ev[perm[n - 1]];
+                int j = 0;
+                // compact in place: positions are visited in ascending order and j <= i always
+                for (int i = 0; i < n; i++) {
+                    bool dropped = keep[i] != 0;
+                    if (!dropped) {
+                        int idx = perm[i];
+                        keep[j] = idx;
+                        Sv[j] = fmin(fabs(1.0 / ev[idx]), 1e6 / lmax);
+                        j++;
+                    }
+                }
+            }
+        }
+        T.sync();
+    }
+    double logdetS;
+    {
+        double s = 0;
+        for (int j = tid; j < r; j += NT) s += log(Sv[j]);
+        logdetS = T.sum(s);
+    }
+
+    // ---------------------------------------------------------------- Sigma = U S U^T into M1
+    {
+        int sh = ceil_log2(n), tot = n << sh;
+        for (int it = tid; it < tot; it += NT) {
+            int i = it >> sh, j = it & ((1 << sh) - 1);
+            if (j <= i) {
+                double s = 0;
+                for (int q = 0; q < r; q++) { int c = keep[q]; s += M2[i * ld + c] * Sv[q] * M2[j * ld + c]; }
+                M1[i * ld + j] = s;
+                M1[j * ld + i] = s;
+            }
+        }
+        T.sync();
+    }
+
+    // ---------------------------------------------------------------- closed form X_e (a11)
+    {
+        double *Pw = M3;               // ne x 3 x DD
+        double *Bk = M3 + ne * 3 * DD; // ne x DD
+        for (int it = tid; it < ne * 3 * DD; it += NT) {
+            int e = it / (3 * DD), rem = it - e * 3 * DD, wch = rem / DD, rc = rem - wch * DD, rr = rc / D, c = rc - rr * D;
+            int oa = pairs[2 * e] * D, ob = pairs[2 * e + 1] * D;
+            const double *J = nJ + e * 2 * DD + (wch == 2 ? DD : 0);
+            int ro = (wch == 2) ? ob : oa, co = (wch == 0) ? oa : ob;
+            double s = 0;
+#pragma unroll
+            for (int p = 0; p < D; p++) s += J[rr * D + p] * M1[(ro + p) * ld + co + c];
+            Pw[it] = s;
+        }
+        T.sync();
+        for (int it = tid; it < ne * DD; it += NT) {
+            int e = it / DD, rc = it - e * DD, rr = rc / D, c = rc - rr * D;
+            const double *Ja = nJ + e * 2 * DD, *Jb = Ja + DD;
+            const double *P0 = Pw + e * 3 * DD, *P1 = P0 + DD, *P2 = P1 + DD;
+            double t1rc = 0, t1cr = 0, t2rc = 0, t2cr = 0, t3rc = 0, t3cr = 0;
+#pragma unroll
+            for (int p = 0; p < D; p++) {
+                t1rc += P0[rr * D + p] * Ja[c * D + p]; t1cr += P0[c * D + p] * Ja[rr * D + p];
+                t2rc += P1[rr * D + p] * Jb[c * D + p]; t2cr += P1[c * D + p] * Jb[rr * D + p];
+                t3rc += P2[rr * D + p] * Jb[c * D + p]; t3cr += P2[c * D + p] * Jb[rr * D + p];
+            }
+            double v = (ne == 1) ? (t1rc + t2rc + t2cr + t3rc)
+                                 : (0.5 * (t1rc + t1cr) + (t2rc + t2cr) + 0.5 * (t3rc + t3cr));
+            Bk[it] = v;
+        }
+        T.sync();
+        for (int e = tid; e < ne; e += NT) {
+            double Ab[DD], Xr[DD];
+#pragma unroll
+            for (int i = 0; i < DD; i++) Ab[i] = Bk[e * DD + i];
+            if (!chol_reg<D>(Ab)) misc[0] = 1;
+            chol_inverse_reg<D>(Ab, Xr);
+            double *rec = arena + bd.new_off + (int64_t)e * REC + PS;
+            int pidx = 0;
+#pragma unroll
+            for (int i = 0; i < D; i++)
+#pragma unroll
+                for (int j = 0; j < D; j++) {
+                    X[e * DD + i * D + j] = Xr[i * D + j];
+                    if (j >= i) rec[pidx++] = Xr[i * D + j];
+                }
+        }
+        T.sync();
+        if (misc[0]) { status = SPG_ST_CLOSED_FORM_NOT_PD; finish(); return; }
+    }
+    n_new = ne;
+
+    // ---------------------------------------------------------------- per-blanket KLD (a12)
+    {
+        double *XJ = M3;  // ne x 2 x DD
+        for (int it = tid; it < ne * 2 * DD; it += NT) {
+            int e = it / (2 * DD), rem = it - e * 2 * DD, wch = rem / DD, rc = rem - wch * DD, rr = rc / D, c = rc - rr * D;
+            const double *J = nJ + e * 2 * DD + wch * DD;
+            double s = 0;
+#pragma unroll
+            for (int p = 0; p < D; p++) s += X[e * DD + rr * D + p] * J[p * D + c];
+            XJ[it] = s;
+        }
+        for (int it = tid; it < n * ld; it += NT) M1[it] = 0.0;
+        T.sync();
+        for (int e = 0; e < ne; e++) {
+            int oa = pairs[2 * e] * D, ob = pairs[2 * e + 1] * D;
+            const double *Ja = nJ + e * 2 * DD, *Jb = Ja + DD;
+            const double *XJa = XJ + e * 2 * DD, *XJb = XJa + DD;
+            for (int it = tid; it < 3 * DD; it += NT) {
+                int blk = it / DD, rc = it - blk * DD, rr = rc / D, c = rc - rr * D;
+                const double *Jl = (blk == 2) ? Jb : Ja;
+                const double *Xr_ = (blk == 0) ? XJa : XJb;
+                double s = 0;
+#pragma unroll
+                for (int p = 0; p < D; p++) s += Jl[p * D + rr] * Xr_[p * D + c];
+                int R = ((blk == 2) ? ob : oa) + rr, Cc = ((blk == 0) ? oa : ob) + c;
+                M1[R * ld + Cc] += s;
+            }
+            T.sync();
+        }
+        mirror_upper<NT>(T, M1, n, ld);
+        // Tm = A * U_kept  (n x r) into M3 ; XJ no longer needed
+        int shr = ceil_log2(r > 0 ? r : 1);
+        for (int it = tid; it < (n << shr); it += NT) {
+            int i = it >> shr, j = it & ((1 << shr) - 1);
+            if (j < r) {
+                int c = keep[j];
+                double s = 0;
+                for (int p = 0; p < n; p++) s += M1[i * ld + p] * M2[p * ld + c];
+                M3[i * ld + j] = s;
+            }
+        }
+        T.sync();
+        // M = U_kept^T Tm  (r x r) into M1 (upper needed, lower mirrored)
+        for (int it = tid; it < (r << shr); it += NT) {
+            int i = it >> shr, j = it & ((1 << shr) - 1);
+            if (j < r && j >= i) {
+                int c = keep[i];
+                double s = 0;
+                for (int p = 0; p < n; p++) s += M2[p * ld + c] * M3[p * ld + j];
+                M1[i * ld + j] = s;
+                M1[j * ld + i] = s;
+            }
+        }
+        T.sync();
+        double tr;
+        {
+            double s = 0;
+            for (int i = tid; i < r; i += NT) s += M1[i * ld + i] * Sv[i];
+            tr = T.sum(s);
+        }
+        chol_lower<NT>(T, M1, r, ld);
+        if (misc[0]) {
+            kld = __builtin_inf();
+            status = SPG_ST_KLD_NOT_PD;
+        } else {
+            double ldM = chol_logdet<NT>(T, M1, r, ld);
+            kld = 0.5 * (tr - ldM - logdetS - (double)r);
+        }
+    }
+    finish();
+}
+
+}  // namespace
+
+// =================================================================================== HIP backend
+namespace spg {
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(err, sizeof err, "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return SPG_EHIP; } } while (0)
+
+struct HipBackend {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    // device-side descriptor buffers (grown on demand)
+    void *d_blk = nullptr, *d_vpo = nullptr, *d_er = nullptr, *d_ev = nullptr, *d_list = nullptr, *d_gws = nullptr;
+    size_t c_blk = 0, c_vpo = 0, c_er = 0, c_ev = 0, c_list = 0, c_gws = 0;
+    // pinned host staging
+    void *h_stage = nullptr;
+    size_t c_stage = 0;
+    int lds_limit = 160 * 1024;
+    int n_launches = 0;
+    // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
+    bool profiling = false;
+    struct Timed { hipEvent_t a, b; double bytes; int blankets; };
+    std::vector<Timed> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double prof_ms = 0, prof_bytes = 0;
+    long long prof_launches = 0, prof_blankets = 0;
+
+    int ensure(void **p, size_t *cap, size_t need) {
+        if (need <= *cap) return 0;
+        size_t nc = std::max(need, *cap * 2);
+        if (*p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(*p)); *p = nullptr; }
+        HIPCHK(hipMalloc(p, nc));
+        *cap = nc;
+        return 0;
+    }
+    int ensure_stage(size_t need) {
+        if (need <= c_stage) return 0;
+        size_t nc = std::max(need, c_stage * 2);
+        if (h_stage) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipHostFree(h_stage)); h_stage = nullptr; }
+        HIPCHK(hipHostMalloc(&h_stage, nc, hipHostMallocDefault));
+        c_stage = nc;
+        return 0;
+    }
+};
+
+template <int D, int NT, bool GWS>
+static int launch_bin(HipBackend *hb, const KArgs &ka, int nblocks, size_t lds_bytes, double alg_bytes) {
+    char *err = hb->err;
+    auto kern = blanket_kernel<D, NT, GWS>;
+    if (lds_bytes > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HipBackend::Timed t{};
+    if (hb->profiling) {
+        if (hb->pool.empty()) {
+            HIPCHK(hipEventCreate(&t.a));
+            HIPCHK(hipEventCreate(&t.b));
+        } else { t.a = hb->pool.back().first; t.b = hb->pool.back().second; hb->pool.pop_back(); }
+        t.bytes = alg_bytes; t.blankets = nblocks;
+        HIPCHK(hipEventRecord(t.a, hb->stream));
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), lds_bytes, hb->stream, ka);
+    HIPCHK(hipGetLastError());
+    if (hb->profiling) {
+        HIPCHK(hipEventRecord(t.b, hb->stream));
+        hb->pending.push_back(t);
+    }
+    hb->n_launches++;
+    return 0;
+}
+
+static void drain_profile(HipBackend *hb) {
+    for (auto &t : hb->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            hb->prof_ms += ms; hb->prof_bytes += t.bytes; hb->prof_launches++; hb->prof_blankets += t.blankets;
+        }
+        hb->pool.push_back({t.a, t.b});
+    }
+    hb->pending.clear();
+}
+
+static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
+    HipBackend *hb = (HipBackend *)user;
+    char *err = hb->err;
+    if (rd->count <= 0) return 0;
+    const spg_options &o = *rd->opts;
+    const int D = o.pose_dim;
+    if (D != 3 && D != 6) return SPG_EINVAL;
+    // ---- bin this rank's blankets by the LDS their tiles need
+    struct Bin { std::vector<int32_t> list; int kmax = 0, mmax = 0; double bytes = 0; };
+    const int NB = 5;
+    const size_t lim[NB - 1] = {24 * 1024, 40 * 1024, 80 * 1024, (size_t)hb->lds_limit};
+    Bin bins[NB];
+    for (int b = rd->first; b < rd->first + rd->count; b++) {
+        const spg_blanket_desc &bd = rd->blankets[b];
+        int k = bd.n_vert - bd.n_remove, m = bd.n_remove;
+        Layout L = make_layout(D, 64, k, m);
+        size_t need = (size_t)(L.small_doubles + L.mat_doubles) * 8;
+        int bi = NB - 1;
+        for (int i = 0; i < NB - 1; i++) if (need <= lim[i]) { bi = i; break; }
+        bins[bi].list.push_back(b);
+        {
+            // algorithmic HBM bytes of this blanket: poses + (2 x i32 + record) per edge
+            // + new records + (kld f64 + status i32)
+            const int ps = (D == 6) ? 7 : 3;
+            double by = 8.0 * ps * bd.n_vert + 12.0;
+            for (int e = bd.edge_begin; e < bd.edge_begin + bd.n_edge; e++) by += 4.0 * rd->edges[e].nv + 8.0 * rd->edges[e].len;
+            by += 8.0 * bd.new_len;
+            bins[bi].bytes += by;
+        }
+        bins[bi].kmax = std::max(bins[bi].kmax, k);
+        bins[bi].mmax = std::max(bins[bi].mmax, m);
+    }
+    // ---- upload the round's descriptors (one pinned staging buffer, async copies)
+    size_t s_blk = sizeof(spg_blanket_desc) * (size_t)rd->n_blankets;
+    size_t s_vpo = sizeof(int64_t) * (size_t)rd->n_vert_total;
+    size_t s_er = sizeof(spg_edge_ref) * (size_t)rd->n_edge_total;
+    size_t s_ev = sizeof(int32_t) * (size_t)rd->n_edge_vert_total;
+    size_t s_list = sizeof(int32_t) * (size_t)rd->count;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t tot = al(s_blk) + al(s_vpo) + al(s_er) + al(s_ev) + al(s_list);
+    HIPCHK(hipSetDevice(hb->device));
+    // the previous round's copies must have drained before the staging buffer is rewritten
+    HIPCHK(hipStreamSynchronize(hb->stream));
+    drain_profile(hb);
+    if (int rc = hb->ensure_stage(tot)) return rc;
+    if (int rc = hb->ensure(&hb->d_blk, &hb->c_blk, s_blk)) return rc;
+    if (int rc = hb->ensure(&hb->d_vpo, &hb->c_vpo, s_vpo)) return rc;
+    if (int rc = hb->ensure(&hb->d_er, &hb->c_er, s_er)) return rc;
+    if (int rc = hb->ensure(&hb->d_ev, &hb->c_ev, std::max(s_ev, (size_t)4))) return rc;
+    if (int rc = hb->ensure(&hb->d_list, &hb->c_list, s_list)) return rc;
+    char *st = (char *)hb->h_stage;
+    size_t off = 0;
+    auto put = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        if (bytes == 0) return hipSuccess;
+        memcpy(st + off, src, bytes);
+        hipError_t e = hipMemcpyAsync(dst, st + off, bytes, hipMemcpyHostToDevice, hb->stream);
+        off += al(bytes);
+        return e;
+    };
+    HIPCHK(put(hb->d_blk, rd->blankets, s_blk));
+    HIPCHK(put(hb->d_vpo, rd->vert_pose_off, s_vpo));
+    HIPCHK(put(hb->d_er, rd->edges, s_er));
+    HIPCHK(put(hb->d_ev, rd->edge_vert, s_ev));
+    {
+        std::vector<int32_t> all;
+        all.reserve(rd->count);
+        for (int i = 0; i < NB; i++) all.insert(all.end(), bins[i].list.begin(), bins[i].list.end());
+        HIPCHK(put(hb->d_list, all.data(), s_list));
+    }
+    // ---- launch each non-empty bin
+    KArgs ka;
+    ka.arena = (double *)arena;
+    ka.blk = (const spg_blanket_desc *)hb->d_blk;
+    ka.vpo = (const int64_t *)hb->d_vpo;
+    ka.er = (const spg_edge_ref *)hb->d_er;
+    ka.ev = (const int32_t *)hb->d_ev;
+    ka.gws = nullptr; ka.gws_stride = 0;
+    ka.topology = o.topology; ka.algorithm = o.algorithm; ka.flags = o.flags; ka.chord_ratio = o.chord_ratio;
+    size_t list_off = 0;
+    for (int i = 0; i < NB; i++) {
+        int nb = (int)bins[i].list.size();
+        if (nb == 0) continue;
+        ka.list = (const int32_t *)hb->d_list + list_off;
+        list_off += nb;
+        int rc;
+        if (i < NB - 1) {
+            Layout L = make_layout(D, 64, bins[i].kmax, bins[i].mmax);
+            size_t lds = (size_t)(L.small_doubles + L.mat_doubles) * 8;
+            rc = (D == 6) ? launch_bin<6, 64, false>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false>(hb, ka, nb, lds, bins[i].bytes);
+        } else {
+            Layout L = make_layout(D, 256, bins[i].kmax, bins[i].mmax);
+            size_t lds = (size_t)L.small_doubles * 8;
+            if (lds > (size_t)hb->lds_limit) { snprintf(err, sizeof hb->err, "blanket too large for LDS side buffers: k=%d m=%d", bins[i].kmax, bins[i].mmax); return SPG_ECAPACITY; }
+            size_t stride = ((size_t)L.mat_doubles + 31) & ~(size_t)31;
+            if (int rc2 = hb->ensure(&hb->d_gws, &hb->c_gws, stride * 8 * (size_t)nb)) return rc2;
+            ka.gws = (double *)hb->d_gws;
+            ka.gws_stride = (int64_t)stride;
+            rc = (D == 6) ? launch_bin<6, 256, true>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true>(hb, ka, nb, lds, bins[i].bytes);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+static void *hip_alloc(void *user, int64_t doubles) {
+    HipBackend *hb = (HipBackend *)user;
+    void *p = nullptr;
+    if (hipSetDevice(hb->device) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, (size_t)doubles * 8) != hipSuccess) return nullptr;
+    return p;
+}
+static void hip_release(void *user, void *p) {
+    HipBackend *hb = (HipBackend *)user;
+    (void)hipStreamSynchronize(hb->stream);
+    (void)hipFree(p);
+}
+static int hip_upload(void *user, void *dst, const double *src, int64_t doubles) {
+    HipBackend *hb = (HipBackend *)user;
+    char *err = hb->err;
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)doubles * 8, hipMemcpyHostToDevice, hb->stream));
+    HIPCHK(hipStreamSynchronize(hb->stream));
+    return 0;
+}
+static int hip_download(void *user, double *dst, const void *src, int64_t doubles) {
+    HipBackend *hb = (HipBackend *)user;
+    char *err = hb->err;
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)doubles * 8, hipMemcpyDeviceToHost, hb->stream));
+    HIPCHK(hipStreamSynchronize(hb->stream));
+    return 0;
+}
+static int hip_sync(void *user) {
+    HipBackend *hb = (HipBackend *)user;
+    char *err = hb->err;
+    HIPCHK(hipStreamSynchronize(hb->stream));
+    drain_profile(hb);
+    return 0;
+}
+
+int hip_backend_create(int device, spg_backend *out, char *errbuf, size_t errlen) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        snprintf(errbuf, errlen, "no HIP device available (count=%d, requested=%d): %s — libspg_hip has no CPU fallback",
+                 ndev, device, e == hipSuccess ? "ok" : hipGetErrorString(e));
+        return SPG_ENODEV;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { snprintf(errbuf, errlen, "hipGetDeviceProperties failed"); return SPG_ENODEV; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(errbuf, errlen, "device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+        return SPG_ENODEV;
+    }
+    HipBackend *hb = new HipBackend;
+    hb->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&hb->stream, hipStreamNonBlocking) != hipSuccess) {
+        snprintf(errbuf, errlen, "cannot create HIP stream on device %d", device);
+        delete hb;
+        return SPG_EHIP;
+    }
+    hb->lds_limit = (int)prop.sharedMemPerBlock > 0 ? (int)std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024) : 64 * 1024;
+    out->user = hb;
+    out->alloc = hip_alloc;
+    out->release = hip_release;
+    out->upload = hip_upload;
+    out->download = hip_download;
+    out->run_round = hip_run_round;
+    out->synchronize = hip_sync;
+    return 0;
+}
+
+void hip_backend_destroy(spg_backend *b) {
+    HipBackend *hb = (HipBackend *)b->user;
+    if (!hb) return;
+    (void)hipSetDevice(hb->device);
+    (void)hipStreamSynchronize(hb->stream);
+    if (hb->d_blk) (void)hipFree(hb->d_blk);
+    if (hb->d_vpo) (void)hipFree(hb->d_vpo);
+    if (hb->d_er) (void)hipFree(hb->d_er);
+    if (hb->d_ev) (void)hipFree(hb->d_ev);
+    if (hb->d_list) (void)hipFree(hb->d_list);
+    if (hb->d_gws) (void)hipFree(hb->d_gws);
+    if (hb->h_stage) (void)hipHostFree(hb->h_stage);
+    (void)hipStreamDestroy(hb->stream);
+    delete hb;
+    b->user = nullptr;
+}
+
+void *hip_backend_stream(spg_backend *b) { return b->user ? (void *)((HipBackend *)b->user)->stream : nullptr; }
+const char *hip_backend_error(spg_backend *b) { return b->user ? ((HipBackend *)b->user)->err : ""; }
+int hip_backend_launches(spg_backend *b) { return b->user ? ((HipBackend *)b->user)->n_launches : 0; }
+void hip_backend_profile(spg_backend *b, int enable) {
+    HipBackend *hb = (HipBackend *)b->user;
+    if (!hb) return;
+    hb->profiling = enable != 0;
+    hb->prof_ms = hb->prof_bytes = 0; hb->prof_launches = hb->prof_blankets = 0;
+}
+void hip_backend_profile_read(spg_backend *b, double *ms, double *bytes, long long *launches, long long *blankets) {
+    HipBackend *hb = (HipBackend *)b->user;
+    if (!hb) return;
+    *ms = hb->prof_ms; *bytes = hb->prof_bytes; *launches = hb->prof_launches; *blankets = hb->prof_blankets;
+}
+
+}  // namespace spg

@@ -1,0 +1,153 @@
+"""Loader for the product library sparsifyposegraph_amd/libspg_hip.so (C ABI of include/spg.h).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device is present when a
+context is created, this module raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspg_hip.so")
+_lib = None
+
+_f64p, _i32p, _i64p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+# every symbol include/spg.h declares for the product library: name -> (restype, argtypes)
+SYMBOLS = {
+    "spg_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "spg_ctx_create_injected": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(abi.Backend)]),
+    "spg_ctx_destroy": (None, [C.c_void_p]),
+    "spg_last_error": (C.c_char_p, [C.c_void_p]),
+    "spg_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "spg_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "spg_ctx_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "spg_ctx_profile_read": (C.c_int, [C.c_void_p, _f64p, _f64p, _i64p, _i64p]),
+    "spg_marginalize_batch": (C.c_int, [C.c_void_p, C.POINTER(abi.Options), C.POINTER(abi.Batch), C.POINTER(abi.Result)]),
+    "spg_decimate_global": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, C.c_int]),
+    "spg_decimate_online": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, C.c_int]),
+    "spg_decimate_cluster": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, C.c_int]),
+    "spg_graph_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "spg_graph_destroy": (None, [C.c_void_p]),
+    "spg_graph_load_g2o": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "spg_graph_write_g2o": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "spg_graph_add_vertex": (C.c_int, [C.c_void_p, C.c_int, _f64p]),
+    "spg_graph_add_edge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _f64p, _f64p]),
+    "spg_graph_add_vertices": (C.c_int, [C.c_void_p, C.c_int, _i32p, _f64p]),
+    "spg_graph_add_edges": (C.c_int, [C.c_void_p, C.c_int, _i32p, _f64p]),
+    "spg_graph_add_glc_edge": (C.c_int, [C.c_void_p, C.c_int, _i32p, C.c_int, _f64p, _f64p]),
+    "spg_graph_pose_dim": (C.c_int, [C.c_void_p]),
+    "spg_graph_num_vertices": (C.c_int, [C.c_void_p]),
+    "spg_graph_num_edges": (C.c_int, [C.c_void_p]),
+    "spg_graph_edge_data_size": (C.c_int64, [C.c_void_p]),
+    "spg_graph_edge_vert_size": (C.c_int64, [C.c_void_p]),
+    "spg_graph_get_vertices": (C.c_int, [C.c_void_p, _i32p, _f64p]),
+    "spg_graph_get_edges": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i64p, _f64p]),
+    "spg_graph_set_estimate": (C.c_int, [C.c_void_p, C.c_int, _f64p]),
+    "spg_graph_marginalize": (C.c_int, [C.c_void_p, _i32p, C.c_int, C.POINTER(abi.Options), C.POINTER(abi.MargStats)]),
+    "spg_graph_last_blanket_count": (C.c_int, [C.c_void_p]),
+    "spg_graph_last_blankets": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _f64p, _f64p]),
+    "spg_graph_marginalize_begin": (C.c_int, [C.c_void_p, _i32p, C.c_int, C.POINTER(abi.Options), C.c_int, C.c_int]),
+    "spg_graph_round_prepare": (C.c_int, [C.c_void_p, C.POINTER(abi.RoundInfo)]),
+    "spg_graph_round_compute": (C.c_int, [C.c_void_p]),
+    "spg_graph_round_commit": (C.c_int, [C.c_void_p]),
+    "spg_graph_marginalize_end": (C.c_int, [C.c_void_p, C.POINTER(abi.MargStats)]),
+    "spg_graph_arena": (C.c_void_p, [C.c_void_p, _i64p]),
+    "spg_graph_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
+}
+
+
+def build(force=False):
+    """Compile libspg_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-s", "-C", csrc, "clean"])
+    subprocess.check_call(["make", "-s", "-C", csrc])
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # raises AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class SpgError(RuntimeError):
+    pass
+
+
+def check(rc, ctx=None, what=""):
+    if rc < 0:
+        msg = ""
+        if ctx:
+            m = load().spg_last_error(ctx)
+            msg = m.decode() if m else ""
+        raise SpgError(f"{what} failed with code {rc}: {msg}")
+    return rc
+
+
+class Context:
+    """spg_ctx: one per (host thread, device). Raises if no gfx950 device is available."""
+
+    def __init__(self, device=0, _handle=None, _keep=None):
+        self.L = load()
+        self._keep = _keep
+        if _handle is not None:
+            self.h = _handle
+            return
+        h = C.c_void_p()
+        rc = self.L.spg_ctx_create(C.byref(h), int(device))
+        if rc != 0:
+            raise SpgError(f"spg_ctx_create(device={device}) failed with code {rc}: no usable gfx950 device "
+                           "(the product path has no CPU fallback)")
+        self.h = h
+
+    @classmethod
+    def injected(cls, backend, keep=None):
+        """Test seam: bind a caller-supplied compute backend (see include/spg.h `spg_backend`)."""
+        L = load()
+        h = C.c_void_p()
+        rc = L.spg_ctx_create_injected(C.byref(h), C.byref(backend))
+        if rc != 0:
+            raise SpgError(f"spg_ctx_create_injected failed: {rc}")
+        return cls(_handle=h, _keep=(backend, keep))
+
+    def stream(self):
+        return self.L.spg_ctx_stream(self.h)
+
+    def synchronize(self):
+        check(self.L.spg_ctx_synchronize(self.h), self.h, "spg_ctx_synchronize")
+
+    def profile(self, enable=True):
+        check(self.L.spg_ctx_profile(self.h, int(enable)), self.h, "spg_ctx_profile")
+
+    def profile_read(self):
+        ms, by = C.c_double(), C.c_double()
+        nl, nb = C.c_int64(), C.c_int64()
+        check(self.L.spg_ctx_profile_read(self.h, C.byref(ms), C.byref(by), C.byref(nl), C.byref(nb)), self.h, "spg_ctx_profile_read")
+        return {"kernel_ms": ms.value, "alg_bytes": by.value, "launches": nl.value, "blankets": nb.value}
+
+    def marginalize_batch(self, opts, batch, want_target=True):
+        return abi.marginalize_batch(self.L, self.h, opts, batch, want_target)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.spg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,67 @@
+"""Multi-GPU form of marginalizeNoOptimize: one process per GPU, graph replicated, each round's
+independent blankets sharded over the ranks, ONE all-gather of the round's output region per round.
+
+The reference has no counterpart (single process, no collective). All ranks run the
+same deterministic host scheduler on identical replicas, so the only data that has to move is what
+a rank computed for its slice: the recovered edge records and the per-blanket output records. They
+live in a rank-chunked region of the arena (`spg_round_info`: region = nranks * chunk_len, rank r
+owns chunk r), so the exchange is an in-place all-gather of equal-sized chunks — over RCCL/xGMI on
+the GPU box (`torch.distributed` backend "nccl"), over gloo in the CPU tests.
+"""
+import ctypes as C
+
+import numpy as np
+
+
+class _CudaArena:
+    """Zero-copy view of the device arena for torch (CUDA array interface v2)."""
+
+    def __init__(self, ptr, doubles):
+        self.__cuda_array_interface__ = {"shape": (int(doubles),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def arena_tensor(graph, device=None):
+    """torch tensor aliasing the graph's arena (device memory for the HIP backend, host memory for
+    an injected backend)."""
+    import torch
+    ptr, cap = graph.arena()
+    if device is not None and str(device).startswith("cuda"):
+        return torch.as_tensor(_CudaArena(ptr, cap), device=device)
+    buf = (C.c_double * cap).from_address(ptr)
+    return torch.from_numpy(np.ctypeslib.as_array(buf))
+
+
+def marginalize_sharded(graph, which, opts, device=None, group=None):
+    """Run graph.marginalizeNoOptimize(which) cooperatively on every rank of `group`.
+
+    Every rank must call this with identical arguments on an identical replica. Returns the
+    per-rank stats dict (identical on all ranks except timing fields).
+    """
+    import torch
+    import torch.distributed as dist
+    ws = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    on_gpu = device is not None and str(device).startswith("cuda")
+    graph.begin(which, opts, rank, ws)
+    view, view_ptr = None, None
+    try:
+        while True:
+            info = graph.round_prepare()
+            if info is None:
+                break
+            graph.round_compute()
+            if ws > 1:
+                ptr, _ = graph.arena()
+                if ptr != view_ptr:  # the arena may be re-allocated while a round is prepared
+                    view, view_ptr = arena_tensor(graph, device), ptr
+                graph.ctx.synchronize()  # this rank's chunk is complete in memory
+                region = view[info.region_off:info.region_off + ws * info.chunk_len]
+                mine = region[rank * info.chunk_len:(rank + 1) * info.chunk_len]
+                dist.all_gather_into_tensor(region, mine, group=group)
+                if on_gpu:
+                    torch.cuda.synchronize()
+            graph.round_commit()
+    finally:
+        stats = graph.end()
+    return stats

@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from tests import oracle_lib
+    return oracle_lib.lib()
+
+
+@pytest.fixture(scope="session")
+def hip_ctx():
+    """Product context on cuda:0 — fails (does not skip) when the HIP path is unavailable."""
+    from sparsifyposegraph_amd.lib import Context
+    return Context(0)

@@ -126,3 +126,48 @@ def canonical_edges(e, d):
         out.append((int(e["kind"][i]), ids, np.array(e["data"][e["data_off"][i]:e["data_off"][i + 1]])))
     out.sort(key=lambda t: (t[1], t[0], len(t[2]), tuple(np.round(t[2][:3], 6))))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Injected compute backend: host memory as "arena", the oracle's spg_run_round as the arithmetic.
+# Lets the CPU suite drive the product's host scheduler / round protocol without a GPU.
+class OracleBackend:
+    def __init__(self):
+        self.L = lib()
+        self.bufs = {}
+        libc = C.CDLL(None)
+        self._memmove = C.memmove
+
+        def _alloc(user, doubles):
+            buf = (C.c_double * max(int(doubles), 1))()
+            addr = C.addressof(buf)
+            self.bufs[addr] = buf
+            return addr
+
+        def _release(user, p):
+            self.bufs.pop(p, None)
+
+        def _upload(user, dst, src, doubles):
+            C.memmove(dst, src, int(doubles) * 8)
+            return 0
+
+        def _download(user, dst, src, doubles):
+            C.memmove(dst, src, int(doubles) * 8)
+            return 0
+
+        def _run_round(user, arena, rd):
+            return self.L.spg_run_round(arena, rd)
+
+        def _sync(user):
+            return 0
+
+        self.cb = (abi._ALLOC(_alloc), abi._RELEASE(_release), abi._UPLOAD(_upload), abi._DOWNLOAD(_download),
+                   abi._RUN_ROUND(_run_round), abi._SYNC(_sync))
+        self.struct = abi.Backend(None, *self.cb)
+
+
+def injected_context():
+    """Context of the PRODUCT library whose compute backend is the oracle (CPU tests only)."""
+    from sparsifyposegraph_amd.lib import Context
+    be = OracleBackend()
+    return Context.injected(be.struct, keep=be)

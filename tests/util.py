@@ -1,0 +1,123 @@
+"""Shared helpers for the parity tests."""
+import glob
+import os
+
+import numpy as np
+
+from sparsifyposegraph_amd import abi
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# relative fp64 tolerance the north star states for recovered information matrices and KLD
+RTOL = 1e-9
+# Chow-Liu topology must be identical whenever consecutive popped weights differ by more than this
+GAP_TOL = 1e-10
+
+
+def golden_cases():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {"pose_dim": int(z["pose_dim"]), "ids": z["ids"], "poses": z["poses"], "edge_ij": z["edge_ij"], "edge_data": z["edge_data"]}
+    opts = abi.make_options(g["pose_dim"], int(z["algorithm"]), int(z["topology"]))
+    out = {"kind": z["out_kind"], "vert_off": z["out_vert_off"], "vert_ids": z["out_vert_ids"], "data_off": z["out_data_off"], "data": z["out_data"]}
+    bl = {k[3:]: z[k] for k in z.files if k.startswith("bl_")}
+    return g, z["which"], opts, out, bl, z["out_vertex_ids"]
+
+
+def edge_list(e):
+    out = []
+    for i in range(len(e["kind"])):
+        ids = tuple(int(x) for x in e["vert_ids"][e["vert_off"][i]:e["vert_off"][i + 1]])
+        out.append((int(e["kind"][i]), ids, np.array(e["data"][e["data_off"][i]:e["data_off"][i + 1]])))
+    return out
+
+
+def canonical(e):
+    out = edge_list(e)
+    out.sort(key=lambda t: (t[1], t[0], len(t[2]), tuple(np.round(t[2][:3], 6))))
+    return out
+
+
+def glc_gram(d, ids, data):
+    """W^T W of a GLC record (W itself is only defined up to an orthogonal factor)."""
+    n = d * len(ids)
+    W = np.asarray(data[n:]).reshape(-1, n)
+    return W.T @ W
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    den = max(np.abs(a).max(initial=0.0), np.abs(b).max(initial=0.0), 1e-300)
+    return float(np.abs(a - b).max(initial=0.0) / den)
+
+
+def compare_edge_sets(d, ea, eb, rtol=RTOL):
+    """Asserts two edges() dicts describe the same graph: identical topology, measurements and
+    information (binary) / W^T W (GLC) within rtol. Returns the worst relative error."""
+    ca, cb = canonical(ea), canonical(eb)
+    assert [(k, i) for k, i, _ in ca] == [(k, i) for k, i, _ in cb], "edge topology differs"
+    ps = abi.pose_stride(d)
+    worst = 0.0
+    for (k, ids, xa), (_, _, xb) in zip(ca, cb):
+        if k == abi.EDGE_BINARY:
+            assert len(xa) == len(xb)
+            worst = max(worst, rel_err(xa[:ps], xb[:ps]), rel_err(xa[ps:], xb[ps:]))
+        else:
+            n = d * len(ids)
+            worst = max(worst, rel_err(xa[:n], xb[:n]))
+            ga, gb = glc_gram(d, ids, xa), glc_gram(d, ids, xb)
+            worst = max(worst, rel_err(ga, gb))
+    assert worst <= rtol, f"edge payload mismatch: {worst:.3e} > {rtol}"
+    return worst
+
+
+def first_round_batch(g, which, opts, limit=None):
+    """Gather, in pure Python, the blankets of the removal-list vertices that touch no other list
+    vertex's blanket (a trivially independent set), as an spg_batch dict. Tree-type blankets only."""
+    d = g["pose_dim"]
+    ids = g["ids"]
+    idx = {int(v): i for i, v in enumerate(ids)}
+    adj = {int(v): [] for v in ids}
+    for e, (a, b) in enumerate(g["edge_ij"]):
+        adj[int(a)].append(e)
+        if int(b) != int(a):
+            adj[int(b)].append(e)
+    used = set()
+    vert_off, n_remove, vert_id, pose = [0], [], [], []
+    edge_off, edge_kind, edge_vert_off, edge_vert, edge_data_off, edge_data = [0], [], [0], [], [0], []
+    roots = []
+    for v in which:
+        v = int(v)
+        nb = {v}
+        for e in adj[v]:
+            nb.update(int(x) for x in g["edge_ij"][e])
+        if nb & used:
+            continue
+        used |= nb
+        order = [v] + sorted(nb - {v})
+        loc = {x: i for i, x in enumerate(order)}
+        es = sorted({e for x in order for e in adj[x] if all(int(y) in loc for y in g["edge_ij"][e])})
+        for x in order:
+            vert_id.append(x)
+            pose.append(g["poses"][idx[x]])
+        vert_off.append(len(vert_id))
+        n_remove.append(1)
+        for e in es:
+            a, b = (int(x) for x in g["edge_ij"][e])
+            edge_kind.append(abi.EDGE_BINARY)
+            edge_vert += [loc[a], loc[b]]
+            edge_vert_off.append(len(edge_vert))
+            edge_data.append(g["edge_data"][e])
+            edge_data_off.append(edge_data_off[-1] + len(g["edge_data"][e]))
+        edge_off.append(len(edge_kind))
+        roots.append(v)
+        if limit and len(roots) >= limit:
+            break
+    return {"vert_off": np.array(vert_off, np.int32), "n_remove": np.array(n_remove, np.int32),
+            "vert_id": np.array(vert_id, np.int32), "pose": np.array(pose, np.float64).reshape(-1),
+            "edge_off": np.array(edge_off, np.int32), "edge_kind": np.array(edge_kind, np.int32),
+            "edge_vert_off": np.array(edge_vert_off, np.int32), "edge_vert": np.array(edge_vert, np.int32),
+            "edge_data_off": np.array(edge_data_off, np.int64),
+            "edge_data": np.concatenate(edge_data) if edge_data else np.zeros(0)}, roots
