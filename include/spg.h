@@ -67,7 +67,12 @@ typedef struct {
     int32_t flags;                /* SPG_FLAG_* */
     double chord_ratio;           /* reference default 1 */
 } spg_options;
-enum { SPG_FLAG_GLC_KLD = 1 /* also evaluate the per-blanket KLD (src/logdet_function.cpp:119-133) for GLC edges */ };
+enum {
+    SPG_FLAG_GLC_KLD = 1,   /* also evaluate the per-blanket KLD (src/logdet_function.cpp:119-133) for GLC edges */
+    SPG_FLAG_FORCE_EIG = 2  /* always take the eigen-decomposition route of src/logdet_function.cpp:14-64
+                               (default: the equivalent gauge/Cholesky route whenever its guard holds) */
+    /* bits 8..15: diagnostic pipeline truncation used by tools/phase_bench.py */
+};
 
 /* One batch of mutually independent Markov blankets in CSR form: the data VertexRemover::remove
  * gathers per iteration (src/vertex_remover.cpp:93-108): blanket vertices (removed first, then kept

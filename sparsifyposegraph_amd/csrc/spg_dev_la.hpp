@@ -22,19 +22,18 @@ struct Team {
     int *flag;    // one int of LDS (sticky failure / broadcast)
     __device__ __forceinline__ void sync() const { __syncthreads(); }
 
-    // deterministic sum of one value per lane (fixed order), result broadcast to all lanes
+    // deterministic sum of one value per lane (fixed butterfly order), result broadcast to all lanes
     __device__ __forceinline__ double sum(double v) const {
-        red[tid] = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (NT == 64) return v;
+        if ((tid & 63) == 0) red[tid >> 6] = v;
         sync();
-        if (tid == 0) {
-            double s = 0;
-            for (int i = 0; i < NT; i++) s += red[i];
-            red[0] = s;
-        }
+        double s = 0;
+#pragma unroll
+        for (int i = 0; i < NT / 64; i++) s += red[i];
         sync();
-        double r = red[0];
-        sync();
-        return r;
+        return s;
     }
 };
 

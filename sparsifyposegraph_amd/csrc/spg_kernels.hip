@@ -40,7 +40,7 @@ constexpr int EC = 4;  // edges whose Jacobians are staged per chunk
 // layout of the largest blanket of a launch bounds every blanket in it.
 struct Layout {
     int n, nm, ld, ldm, P, NE;
-    int o_pose, o_red, o_cs, o_ev, o_S, o_w, o_ldb, o_Lb, o_nJ, o_X, o_eJ, o_eO, o_eT, o_int, small_doubles;
+    int o_pose, o_red, o_cs, o_ev, o_S, o_w, o_ldb, o_Lb, o_nJ, o_X, o_eJ, o_eO, o_eT, o_Ng, o_tre, o_int, small_doubles;
     int o_M1, o_M2, o_M3, o_Hmm, o_Hmk, mat_doubles;
     // int area offsets (in ints, relative to o_int)
     int i_perm, i_keep, i_sorted, i_comp, i_pairs, i_ev, i_misc, int_count;
@@ -68,6 +68,8 @@ __host__ __device__ inline Layout make_layout(int D, int nt, int k, int m) {
     L.o_eJ = o; o += EC * 2 * DD;
     L.o_eO = o; o += EC * DD;
     L.o_eT = o; o += 2 * DD;
+    L.o_Ng = o; o += L.n * D;
+    L.o_tre = o; o += L.NE;
     L.o_int = o;
     int io = 0;
     L.i_perm = io; io += L.n;
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     };
 
     // ---------------------------------------------------------------- gather poses, clear H
-    if (tid == 0) { misc[0] = 0; misc[1] = 0; }
+    if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0; }
     for (int v = tid; v < nv; v += NT) {
         const double *p = arena + a.vpo[bd.vert_begin + v];
         if (D == 6) iso_from_tq(p, pose + v * PSZ);
@@ -225,6 +227,8 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         }
     }
     if (misc[1]) { status = SPG_ST_UNSUPPORTED; finish(); return; }
+    const int stop_after = (a.flags >> 8) & 0xff;  // diagnostic: truncate the pipeline (timing breakdowns only)
+    if (stop_after == 1) { finish(); return; }
 
     // ---------------------------------------------------------------- Schur complement (a7)
     chol_lower<NT>(T, Hmm, nm, ldm);
@@ -251,7 +255,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         double *dst = arena + bd.tinfo_off;
         for (int it = tid; it < n * n; it += NT) { int i = it / n, j = it - i * n; dst[it] = M1[i * ld + j]; }
     }
-    if (k < 2) { finish(); return; }
+    if (k < 2 || stop_after == 2) { finish(); return; }
 
     // ---------------------------------------------------------------- sparsity pattern (a8)
     int ne;
@@ -369,6 +373,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         T.sync();
     }
 
+    if (stop_after == 3) { finish(); return; }
     // ---------------------------------------------------------------- new edge skeleton (a9, a10)
     for (int e = tid; e < ne; e += NT) {
         int va = m + pairs[2 * e], vb = m + pairs[2 * e + 1];
@@ -394,96 +399,240 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         T.sync();
     }
 
-    // ---------------------------------------------------------------- spectrum of Lambda_t (a11)
-    for (int it = tid; it < n * ld; it += NT) M3[it] = M1[it];
-    T.sync();
-    if (!jacobi_eigh<NT>(T, M3, M2, n, ld, cs)) { status = SPG_ST_EIG_FAIL; finish(); return; }
-    for (int i = tid; i < n; i += NT) ev[i] = M3[i * ld + i];
-    T.sync();
-    sort_ascending<NT>(T, ev, 1, n, perm);
+    if (stop_after == 4) { finish(); return; }
+
+    // ================================================================ information recovery (a11, a12)
+    // Two routes to the same numbers.
+    //  * eigen route — the reference's own: eig(Lambda_t), drop the d gauge directions, Sigma = U S U^T
+    //    (src/logdet_function.cpp:14-64,236-279), KLD through M = U^T A U (src/logdet_function.cpp:119-133).
+    //  * gauge route — Lambda_t of a blanket of relative-pose edges has an exactly known d-dimensional
+    //    null space: the rigid motions of the whole blanket, N = [G_1; ...; G_k] in the vertices' update
+    //    coordinates. With N^ an orthonormal basis of it and C = Lambda_t + N^ N^^T (SPD):
+    //        U S U^T = C^-1 - N^ N^^T,   J_e N^ = 0  =>  J_e Sigma J_e^T = J_e C^-1 J_e^T,
+    //        log det S = -log det C,  tr(S M) = tr(C^-1 A),  log det(U^T A U) = log det(A + N^ N^^T),
+    //    so three Cholesky factorisations replace the Jacobi eigen-decomposition (~10x fewer dependent
+    //    steps). It is taken only when ||C^-1||_F < 5e4, which proves lambda_{d+1}(Lambda_t) > 1e-5, i.e.
+    //    the reference's `smalleigs <= dim` branch; anything else (rank-deficient blankets, failed
+    //    factorisations) goes through the eigen route. tests/test_gpu_parity.py checks both routes
+    //    against the oracle to 1e-9.
     const int r = n - D;
-    {
-        double cnt = 0;
-        for (int i = tid; i < n; i += NT) cnt += (ev[i] < 1e-5) ? 1.0 : 0.0;
-        int smalleigs = (int)T.sum(cnt);
-        if (smalleigs <= D) {
-            for (int j = tid; j < r; j += NT) { int idx = perm[D + j]; keep[j] = idx; Sv[j] = 1.0 / ev[idx]; }
-        } else {
-            info |= SPG_INFO_RANK_DEFICIENT;
-            if (tid == 0) {
-                // chooseDimensions (src/logdet_function.cpp:66-81): drop the D candidates with the
-                // smallest ||J u||; S clamped as at src/logdet_function.cpp:55
-                double *nrm = cs;  // smalleigs <= n doubles
-                for (int c = 0; c < smalleigs; c++) {
-                    int col = perm[c];
-                    double s2 = 0;
-                    for (int e = 0; e < ne; e++) {
-                        int oa = pairs[2 * e] * D, ob = pairs[2 * e + 1] * D;
-                        const double *Ja = nJ + e * 2 * DD, *Jb = Ja + DD;
-                        for (int rr = 0; rr < D; rr++) {
-                            double s = 0;
-                            for (int p = 0; p < D; p++) {
-                                double ja = Ja[rr * D + p], jb = Jb[rr * D + p];
-                                if (fabs(ja) >= 2.220446049250313e-16) s += ja * M2[(oa + p) * ld + col];
-                                if (fabs(jb) >= 2.220446049250313e-16) s += jb * M2[(ob + p) * ld + col];
-                            }
-                            s2 += s * s;
-                        }
+    double *Ng = smem + L.o_Ng;      // n x D orthonormal gauge basis
+    double *tre = smem + L.o_tre;    // per-edge tr(X_e B_e)
+    bool gauge_ok = false;
+    double logdetS = 0.0;
+    double *Sg = M1, *Scr = M3;      // Sigma and scratch for the closed form (swapped on the gauge route)
+    if (!(a.flags & SPG_FLAG_FORCE_EIG)) {
+        // ---- gauge basis
+        for (int v = tid; v < k; v += NT) {
+            const double *X = pose + (m + v) * PSZ;
+            double *Gv = Ng + v * DD;
+            if (D == 6) {
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        // R^T ; -R^T [t]x ; 0 ; 1/2 R^T   (column c of [t]x is t x e_c)
+                        constexpr int A1[3] = {1, 2, 0}, B1[3] = {2, 0, 1};
+                        const int ca = A1[c], cb = B1[c];
+                        double rt = X[c * 3 + rr];
+                        // (t x e_c): component cb = +t[ca]... derive: t x e_c = (t_a e_a + t_b e_b + t_c e_c) x e_c
+                        //   e_a x e_c = -e_b , e_b x e_c = +e_a   (a = c+1, b = c+2 cyclic)
+                        //   => t x e_c = t_b e_a - t_a e_b
+                        double cx_a = X[9 + cb], cx_b = -X[9 + ca];
+                        double val = -(X[ca * 3 + rr] * cx_a + X[cb * 3 + rr] * cx_b);  // -(R^T (t x e_c))[rr]
+                        Gv[rr * 6 + c] = rt;
+                        Gv[rr * 6 + 3 + c] = val;
+                        Gv[(3 + rr) * 6 + c] = 0.0;
+                        Gv[(3 + rr) * 6 + 3 + c] = 0.5 * rt;
                     }
-                    nrm[c] = sqrt(s2);
-                }
-                // mark the D smallest (norm, then sorted position); keep[] doubles as the mark array
-                for (int i = 0; i < n; i++) keep[i] = 0;
-                for (int t = 0; t < D; t++) {
-                    int best = -1;
-                    for (int c = 0; c < smalleigs; c++) {
-                        if (keep[c]) continue;
-                        if (best < 0 || nrm[c] < nrm[best]) best = c;
-                    }
-                    keep[best] = 1;
-                }
-                double lmax = ev[perm[n - 1]];
-                int j = 0;
-                // compact in place: positions are visited in ascending order and j <= i always
-                for (int i = 0; i < n; i++) {
-                    bool dropped = keep[i] != 0;
-                    if (!dropped) {
-                        int idx = perm[i];
-                        keep[j] = idx;
-                        Sv[j] = fmin(fabs(1.0 / ev[idx]), 1e6 / lmax);
-                        j++;
-                    }
-                }
+            } else {
+                Gv[0] = 1; Gv[1] = 0; Gv[2] = -X[1];
+                Gv[3] = 0; Gv[4] = 1; Gv[5] = X[0];
+                Gv[6] = 0; Gv[7] = 0; Gv[8] = 1;
             }
         }
         T.sync();
-    }
-    double logdetS;
-    {
-        double s = 0;
-        for (int j = tid; j < r; j += NT) s += log(Sv[j]);
-        logdetS = T.sum(s);
+        // ---- orthonormalise: N^ = N L^-T with N^T N = L L^T (D x D, one lane, registers)
+        if (tid < DD) {
+            int rr = tid / D, c = tid - rr * D;
+            double s = 0;
+            for (int i = 0; i < n; i++) s += Ng[i * D + rr] * Ng[i * D + c];
+            eT[tid] = s;
+        }
+        T.sync();
+        if (tid == 0) {
+            double Ab[DD], Li[DD];
+#pragma unroll
+            for (int i = 0; i < DD; i++) Ab[i] = eT[i];
+            if (!chol_reg<D>(Ab)) misc[2] = 1;
+#pragma unroll
+            for (int c = 0; c < D; c++)
+#pragma unroll
+                for (int i = 0; i < D; i++) {
+                    if (i < c) Li[i * D + c] = 0.0;
+                    else if (i == c) Li[i * D + c] = 1.0 / Ab[c * D + c];
+                    else {
+                        double s = 0;
+#pragma unroll
+                        for (int q = 0; q < D; q++) if (q >= c && q < i) s += Ab[i * D + q] * Li[q * D + c];
+                        Li[i * D + c] = -s / Ab[i * D + i];
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < DD; i++) eT[DD + i] = Li[i];
+        }
+        T.sync();
+        {
+            double nv_[D];
+            for (int i = tid; i < n; i += NT) {
+#pragma unroll
+                for (int c = 0; c < D; c++) {
+                    double s = 0;
+#pragma unroll
+                    for (int q = 0; q < D; q++) if (q <= c) s += Ng[i * D + q] * eT[DD + c * D + q];
+                    nv_[c] = s;
+                }
+#pragma unroll
+                for (int c = 0; c < D; c++) Ng[i * D + c] = nv_[c];
+            }
+        }
+        T.sync();
+        // ---- C = Lambda_t + N^ N^^T into M3, Cholesky, inverse
+        {
+            int sh = ceil_log2(n), tot = n << sh;
+            for (int it = tid; it < tot; it += NT) {
+                int i = it >> sh, j = it & ((1 << sh) - 1);
+                if (j <= i) {
+                    double s = M1[i * ld + j];
+#pragma unroll
+                    for (int q = 0; q < D; q++) s += Ng[i * D + q] * Ng[j * D + q];
+                    M3[i * ld + j] = s;
+                    M3[j * ld + i] = s;
+                }
+            }
+            T.sync();
+        }
+        chol_lower<NT>(T, M3, n, ld);
+        bool fail = (misc[0] != 0) || (misc[2] != 0);
+        T.sync();
+        if (tid == 0) { misc[0] = 0; misc[2] = 0; }
+        T.sync();
+        if (!fail) {
+            double ldC = chol_logdet<NT>(T, M3, n, ld);
+            tri_inverse_lower<NT>(T, M3, M2, n, ld);
+            // C^-1 = Li^T Li into M3 with its Frobenius norm
+            int sh = ceil_log2(n), tot = n << sh;
+            double f2 = 0;
+            for (int it = tid; it < tot; it += NT) {
+                int i = it >> sh, j = it & ((1 << sh) - 1);
+                if (j <= i) {
+                    double s = 0;
+                    for (int q = i; q < n; q++) s += M2[q * ld + i] * M2[q * ld + j];
+                    M3[i * ld + j] = s;
+                    M3[j * ld + i] = s;
+                    f2 += (i == j) ? s * s : 2.0 * s * s;
+                }
+            }
+            double fro2 = T.sum(f2);
+            if (fro2 < 5e4 * 5e4 && isfinite(fro2)) {
+                gauge_ok = true;
+                logdetS = -ldC;
+                Sg = M3; Scr = M1;
+            }
+        }
     }
 
-    // ---------------------------------------------------------------- Sigma = U S U^T into M1
-    {
-        int sh = ceil_log2(n), tot = n << sh;
-        for (int it = tid; it < tot; it += NT) {
-            int i = it >> sh, j = it & ((1 << sh) - 1);
-            if (j <= i) {
-                double s = 0;
-                for (int q = 0; q < r; q++) { int c = keep[q]; s += M2[i * ld + c] * Sv[q] * M2[j * ld + c]; }
-                M1[i * ld + j] = s;
-                M1[j * ld + i] = s;
-            }
-        }
+    if (!gauge_ok) {
+        // ------------------------------------------------------------ eigen route: spectrum of Lambda_t
+        for (int it = tid; it < n * ld; it += NT) M3[it] = M1[it];
         T.sync();
+        if (!jacobi_eigh<NT>(T, M3, M2, n, ld, cs)) { status = SPG_ST_EIG_FAIL; finish(); return; }
+        for (int i = tid; i < n; i += NT) ev[i] = M3[i * ld + i];
+        T.sync();
+        if (stop_after == 5) { finish(); return; }
+        sort_ascending<NT>(T, ev, 1, n, perm);
+        {
+            double cnt = 0;
+            for (int i = tid; i < n; i += NT) cnt += (ev[i] < 1e-5) ? 1.0 : 0.0;
+            int smalleigs = (int)T.sum(cnt);
+            if (smalleigs <= D) {
+                for (int j = tid; j < r; j += NT) { int idx = perm[D + j]; keep[j] = idx; Sv[j] = 1.0 / ev[idx]; }
+            } else {
+                info |= SPG_INFO_RANK_DEFICIENT;
+                if (tid == 0) {
+                    // chooseDimensions (src/logdet_function.cpp:66-81): drop the D candidates with the
+                    // smallest ||J u||; S clamped as at src/logdet_function.cpp:55
+                    double *nrm = cs;  // smalleigs <= n doubles
+                    for (int c = 0; c < smalleigs; c++) {
+                        int col = perm[c];
+                        double s2 = 0;
+                        for (int e = 0; e < ne; e++) {
+                            int oa = pairs[2 * e] * D, ob = pairs[2 * e + 1] * D;
+                            const double *Ja = nJ + e * 2 * DD, *Jb = Ja + DD;
+                            for (int rr = 0; rr < D; rr++) {
+                                double s = 0;
+                                for (int p = 0; p < D; p++) {
+                                    double ja = Ja[rr * D + p], jb = Jb[rr * D + p];
+                                    if (fabs(ja) >= 2.220446049250313e-16) s += ja * M2[(oa + p) * ld + col];
+                                    if (fabs(jb) >= 2.220446049250313e-16) s += jb * M2[(ob + p) * ld + col];
+                                }
+                                s2 += s * s;
+                            }
+                        }
+                        nrm[c] = sqrt(s2);
+                    }
+                    // mark the D smallest (norm, then sorted position); keep[] doubles as the mark array
+                    for (int i = 0; i < n; i++) keep[i] = 0;
+                    for (int t = 0; t < D; t++) {
+                        int best = -1;
+                        for (int c = 0; c < smalleigs; c++) {
+                            if (keep[c]) continue;
+                            if (best < 0 || nrm[c] < nrm[best]) best = c;
+                        }
+                        keep[best] = 1;
+                    }
+                    double lmax = ev[perm[n - 1]];
+                    int j = 0;
+                    // compact in place: positions are visited in ascending order and j <= i always
+                    for (int i = 0; i < n; i++) {
+                        bool dropped = keep[i] != 0;
+                        if (!dropped) {
+                            int idx = perm[i];
+                            keep[j] = idx;
+                            Sv[j] = fmin(fabs(1.0 / ev[idx]), 1e6 / lmax);
+                            j++;
+                        }
+                    }
+                }
+            }
+            T.sync();
+        }
+        {
+            double s = 0;
+            for (int j = tid; j < r; j += NT) s += log(Sv[j]);
+            logdetS = T.sum(s);
+        }
+        // Sigma = U S U^T into M1
+        {
+            int sh = ceil_log2(n), tot = n << sh;
+            for (int it = tid; it < tot; it += NT) {
+                int i = it >> sh, j = it & ((1 << sh) - 1);
+                if (j <= i) {
+                    double s = 0;
+                    for (int q = 0; q < r; q++) { int c = keep[q]; s += M2[i * ld + c] * Sv[q] * M2[j * ld + c]; }
+                    M1[i * ld + j] = s;
+                    M1[j * ld + i] = s;
+                }
+            }
+            T.sync();
+        }
     }
+    if (stop_after == 6) { finish(); return; }
 
     // ---------------------------------------------------------------- closed form X_e (a11)
     {
-        double *Pw = M3;               // ne x 3 x DD
-        double *Bk = M3 + ne * 3 * DD; // ne x DD
+        double *Pw = Scr;               // ne x 3 x DD
+        double *Bk = Scr + ne * 3 * DD; // ne x DD
         for (int it = tid; it < ne * 3 * DD; it += NT) {
             int e = it / (3 * DD), rem = it - e * 3 * DD, wch = rem / DD, rc = rem - wch * DD, rr = rc / D, c = rc - rr * D;
             int oa = pairs[2 * e] * D, ob = pairs[2 * e + 1] * D;
@@ -491,7 +640,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             int ro = (wch == 2) ? ob : oa, co = (wch == 0) ? oa : ob;
             double s = 0;
 #pragma unroll
-            for (int p = 0; p < D; p++) s += J[rr * D + p] * M1[(ro + p) * ld + co + c];
+            for (int p = 0; p < D; p++) s += J[rr * D + p] * Sg[(ro + p) * ld + co + c];
             Pw[it] = s;
         }
         T.sync();
@@ -515,6 +664,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             double Ab[DD], Xr[DD];
 #pragma unroll
             for (int i = 0; i < DD; i++) Ab[i] = Bk[e * DD + i];
+            double trs = 0;
             if (!chol_reg<D>(Ab)) misc[0] = 1;
             chol_inverse_reg<D>(Ab, Xr);
             double *rec = arena + bd.new_off + (int64_t)e * REC + PS;
@@ -524,17 +674,22 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
 #pragma unroll
                 for (int j = 0; j < D; j++) {
                     X[e * DD + i * D + j] = Xr[i * D + j];
+                    trs += Xr[i * D + j] * Bk[e * DD + ((j <= i) ? (i * D + j) : (j * D + i))];
                     if (j >= i) rec[pidx++] = Xr[i * D + j];
                 }
+            tre[e] = trs;
         }
         T.sync();
         if (misc[0]) { status = SPG_ST_CLOSED_FORM_NOT_PD; finish(); return; }
     }
     n_new = ne;
+    if (stop_after == 7) { finish(); return; }
 
     // ---------------------------------------------------------------- per-blanket KLD (a12)
     {
-        double *XJ = M3;  // ne x 2 x DD
+        // A = J^T X J (upper blocks accumulated, then mirrored) into Am
+        double *Am = gauge_ok ? M2 : M1;
+        double *XJ = gauge_ok ? M1 : M3;  // ne x 2 x DD
         for (int it = tid; it < ne * 2 * DD; it += NT) {
             int e = it / (2 * DD), rem = it - e * 2 * DD, wch = rem / DD, rc = rem - wch * DD, rr = rc / D, c = rc - rr * D;
             const double *J = nJ + e * 2 * DD + wch * DD;
@@ -543,7 +698,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             for (int p = 0; p < D; p++) s += X[e * DD + rr * D + p] * J[p * D + c];
             XJ[it] = s;
         }
-        for (int it = tid; it < n * ld; it += NT) M1[it] = 0.0;
+        for (int it = tid; it < n * ld; it += NT) Am[it] = 0.0;
         T.sync();
         for (int e = 0; e < ne; e++) {
             int oa = pairs[2 * e] * D, ob = pairs[2 * e + 1] * D;
@@ -557,48 +712,77 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
 #pragma unroll
                 for (int p = 0; p < D; p++) s += Jl[p * D + rr] * Xr_[p * D + c];
                 int R = ((blk == 2) ? ob : oa) + rr, Cc = ((blk == 0) ? oa : ob) + c;
-                M1[R * ld + Cc] += s;
+                Am[R * ld + Cc] += s;
             }
             T.sync();
         }
-        mirror_upper<NT>(T, M1, n, ld);
-        // Tm = A * U_kept  (n x r) into M3 ; XJ no longer needed
-        int shr = ceil_log2(r > 0 ? r : 1);
-        for (int it = tid; it < (n << shr); it += NT) {
-            int i = it >> shr, j = it & ((1 << shr) - 1);
-            if (j < r) {
-                int c = keep[j];
-                double s = 0;
-                for (int p = 0; p < n; p++) s += M1[i * ld + p] * M2[p * ld + c];
-                M3[i * ld + j] = s;
+        mirror_upper<NT>(T, Am, n, ld);
+        if (gauge_ok) {
+            // kld = 1/2 ( tr(C^-1 A) - log det(A + N^ N^^T) + log det C - r ), tr(C^-1 A) = sum_e tr(X_e B_e)
+            int sh = ceil_log2(n), tot = n << sh;
+            for (int it = tid; it < tot; it += NT) {
+                int i = it >> sh, j = it & ((1 << sh) - 1);
+                if (j < n) {
+                    double s = 0;
+#pragma unroll
+                    for (int q = 0; q < D; q++) s += Ng[i * D + q] * Ng[j * D + q];
+                    Am[i * ld + j] += s;
+                }
             }
-        }
-        T.sync();
-        // M = U_kept^T Tm  (r x r) into M1 (upper needed, lower mirrored)
-        for (int it = tid; it < (r << shr); it += NT) {
-            int i = it >> shr, j = it & ((1 << shr) - 1);
-            if (j < r && j >= i) {
-                int c = keep[i];
+            T.sync();
+            double tr;
+            {
                 double s = 0;
-                for (int p = 0; p < n; p++) s += M2[p * ld + c] * M3[p * ld + j];
-                M1[i * ld + j] = s;
-                M1[j * ld + i] = s;
+                for (int e = tid; e < ne; e += NT) s += tre[e];
+                tr = T.sum(s);
             }
-        }
-        T.sync();
-        double tr;
-        {
-            double s = 0;
-            for (int i = tid; i < r; i += NT) s += M1[i * ld + i] * Sv[i];
-            tr = T.sum(s);
-        }
-        chol_lower<NT>(T, M1, r, ld);
-        if (misc[0]) {
-            kld = __builtin_inf();
-            status = SPG_ST_KLD_NOT_PD;
+            chol_lower<NT>(T, Am, n, ld);
+            if (misc[0]) {
+                kld = __builtin_inf();
+                status = SPG_ST_KLD_NOT_PD;
+            } else {
+                double ldA = chol_logdet<NT>(T, Am, n, ld);
+                kld = 0.5 * (tr - ldA - logdetS - (double)r);
+            }
         } else {
-            double ldM = chol_logdet<NT>(T, M1, r, ld);
-            kld = 0.5 * (tr - ldM - logdetS - (double)r);
+            // Tm = A * U_kept  (n x r) into M3 ; XJ no longer needed
+            int shr = ceil_log2(r > 0 ? r : 1);
+            for (int it = tid; it < (n << shr); it += NT) {
+                int i = it >> shr, j = it & ((1 << shr) - 1);
+                if (j < r) {
+                    int c = keep[j];
+                    double s = 0;
+                    for (int p = 0; p < n; p++) s += M1[i * ld + p] * M2[p * ld + c];
+                    M3[i * ld + j] = s;
+                }
+            }
+            T.sync();
+            // M = U_kept^T Tm  (r x r) into M1 (upper needed, lower mirrored)
+            for (int it = tid; it < (r << shr); it += NT) {
+                int i = it >> shr, j = it & ((1 << shr) - 1);
+                if (j < r && j >= i) {
+                    int c = keep[i];
+                    double s = 0;
+                    for (int p = 0; p < n; p++) s += M2[p * ld + c] * M3[p * ld + j];
+                    M1[i * ld + j] = s;
+                    M1[j * ld + i] = s;
+                }
+            }
+            T.sync();
+            double tr;
+            {
+                double s = 0;
+                for (int i = tid; i < r; i += NT) s += M1[i * ld + i] * Sv[i];
+                tr = T.sum(s);
+            }
+            chol_lower<NT>(T, M1, r, ld);
+            if (misc[0]) {
+                kld = __builtin_inf();
+                status = SPG_ST_KLD_NOT_PD;
+            } else {
+                double ldM = chol_logdet<NT>(T, M1, r, ld);
+                kld = 0.5 * (tr - ldM - logdetS - (double)r);
+            }
         }
     }
     finish();

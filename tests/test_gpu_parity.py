@@ -12,15 +12,19 @@ pytestmark = pytest.mark.gpu
 NFR_CASES = [c for c in util.golden_cases() if "_nfr_" in c]
 
 
+@pytest.mark.parametrize("route", ["gauge", "eigen"])
 @pytest.mark.parametrize("case", NFR_CASES)
-def test_batch_matches_oracle(case, hip_ctx, oracle):
+def test_batch_matches_oracle(case, route, hip_ctx, oracle):
     """First-round blankets of each fixture through spg_marginalize_batch: target information,
-    tree topology, recovered information and per-blanket KLD vs the oracle."""
+    tree topology, recovered information and per-blanket KLD vs the oracle — once through the
+    default gauge/Cholesky route and once forced through the eigen-decomposition route."""
     g, which, opts, _, _, _ = util.load_golden(case)
     batch, roots = util.first_round_batch(g, which, opts)
     assert len(roots) > 10
     ref = abi.marginalize_batch(oracle, None, opts, batch)
-    got = hip_ctx.marginalize_batch(opts, batch)
+    hopts = abi.make_options(opts.pose_dim, opts.algorithm, opts.topology, opts.lin_point,
+                             abi.FLAG_FORCE_EIG if route == "eigen" else 0)
+    got = hip_ctx.marginalize_batch(hopts, batch)
     assert np.array_equal(ref["status"], got["status"])
     assert np.array_equal(ref["info"], got["info"])
     B = len(roots)
@@ -52,13 +56,16 @@ def test_batch_matches_oracle(case, hip_ctx, oracle):
     assert np.allclose(ref["min_gap"], got["min_gap"], rtol=1e-6, atol=1e-12)
 
 
+@pytest.mark.parametrize("route", ["gauge", "eigen"])
 @pytest.mark.parametrize("case", NFR_CASES)
-def test_graph_matches_golden_and_oracle(case, hip_ctx):
+def test_graph_matches_golden_and_oracle(case, route, hip_ctx):
     """Whole marginalizeNoOptimize on the device (conflict-free rounds) vs the strictly sequential
     oracle: identical final topology, information within 1e-9 relative, KLD sum within 1e-9."""
     g, which, opts, gold_edges, gold_bl, gold_vids = util.load_golden(case)
     hg = GraphWrapperHIP.from_dict(g, ctx=hip_ctx, useGLC=False)
-    st = hg.marginalizeNoOptimize(which, opts)
+    hopts = abi.make_options(opts.pose_dim, opts.algorithm, opts.topology, opts.lin_point,
+                             abi.FLAG_FORCE_EIG if route == "eigen" else 0)
+    st = hg.marginalizeNoOptimize(which, hopts)
     assert st["n_bad_status"] == 0
     assert st["n_removed"] == len(gold_bl["root"])
     ids, _ = hg.vertices()
@@ -73,6 +80,7 @@ def test_graph_matches_golden_and_oracle(case, hip_ctx):
     gorder = np.argsort(gold_bl["root"], kind="stable")
     assert np.array_equal(bl["root"][order], gold_bl["root"][gorder])
     assert np.array_equal(bl["status"][order], gold_bl["status"][gorder])
+    assert np.array_equal(bl["info"][order], gold_bl["info"][gorder])
     k1, k2 = bl["kld"][order], gold_bl["kld"][gorder]
     fin = np.isfinite(k2)
     assert np.max(np.abs(k1[fin] - k2[fin]) / np.maximum(np.abs(k2[fin]), 1.0)) <= 1e-9
