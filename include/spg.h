@@ -182,6 +182,8 @@ typedef struct {
     double kld_sum;        /* sum of finite per-blanket KLD */
     double host_seconds;   /* host scheduling + graph update */
     double device_seconds; /* time blocked on the device (launch -> results visible) */
+    double schedule_seconds; /* part of host_seconds: conflict-free round selection */
+    double commit_seconds;   /* part of host_seconds: graph update */
 } spg_marg_stats;
 
 /* GraphWrapperG2O::marginalizeNoOptimize (src/graph_wrapper_g2o.cpp:398-453): removes `which` with

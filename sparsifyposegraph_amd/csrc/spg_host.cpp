@@ -730,6 +730,7 @@ extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
     if (!g || !g->active || g->round_open) return SPG_ESTATE;
     double t0 = now_s();
     schedule_round(g);
+    g->stats.schedule_seconds += now_s() - t0;
     int B = (int)g->rb.size();
     if (B == 0) { g->stats.host_seconds += now_s() - t0; return 0; }
     const spg_options &o = g->opts;
@@ -912,6 +913,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
     g->round_open = false;
     g->stats.n_rounds = g->round_no;
     g->stats.host_seconds += now_s() - t1;
+    g->stats.commit_seconds += now_s() - t1;
     return 0;
 }
 

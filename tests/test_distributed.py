@@ -1,0 +1,65 @@
+"""CPU: the multi-rank round protocol (sharded blankets + one all-gather per round) at
+world_size 2 over gloo, with the oracle injected as each rank's compute backend. Checks that both
+ranks end with the sequential oracle's graph."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from sparsifyposegraph_amd import abi
+from sparsifyposegraph_amd.graph import GraphWrapperHIP
+from sparsifyposegraph_amd.parallel import marginalize_sharded
+from tests import oracle_lib, util
+dist.init_process_group("gloo")
+rank, ws = dist.get_rank(), dist.get_world_size()
+for case in sys.argv[2:]:
+    g, which, opts, gold_edges, gold_bl, gold_vids = util.load_golden(case)
+    ctx = oracle_lib.injected_context()
+    hg = GraphWrapperHIP.from_dict(g, ctx=ctx, useGLC=bool(opts.algorithm))
+    st = marginalize_sharded(hg, which, opts)
+    ids, _ = hg.vertices()
+    assert np.array_equal(ids, gold_vids), (rank, case)
+    util.compare_edge_sets(g["pose_dim"], gold_edges, hg.edges(), rtol=1e-11)
+    assert st["n_removed"] == len(gold_bl["root"]) and st["n_bad_status"] == 0
+    # every rank computed only its slice: the replicas agree because of the exchange
+    t = torch.tensor([st["kld_sum"]], dtype=torch.float64)
+    lst = [torch.zeros_like(t) for _ in range(ws)]
+    dist.all_gather(lst, t)
+    assert all(abs(float(x) - float(t)) == 0 for x in lst)
+    print(f"rank {rank} {case} ok rounds={st['n_rounds']}")
+dist.destroy_process_group()
+'''
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2",
+               OMP_NUM_THREADS="1")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, "sphere_nfr_tree", "manhattan_glc_tree", "parking_nfr_tree"],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=280)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert all("parking_nfr_tree ok" in o for o in outs)

@@ -1,0 +1,84 @@
+"""CPU: the product's HOST logic (blanket extraction, conflict-free round scheduler, arena / round
+protocol, graph update) driven through the C ABI with the oracle injected as the compute backend,
+checked against the oracle's strictly sequential loop. No GPU, no product arithmetic involved."""
+import numpy as np
+import pytest
+
+from sparsifyposegraph_amd import abi, g2o_io
+from sparsifyposegraph_amd.graph import GraphWrapperHIP
+from tests import oracle_lib, util
+
+
+@pytest.fixture(scope="module")
+def ictx():
+    return oracle_lib.injected_context()
+
+
+@pytest.mark.parametrize("case", util.golden_cases())
+def test_rounds_equal_sequential(case, ictx):
+    g, which, opts, gold_edges, gold_bl, gold_vids = util.load_golden(case)
+    hg = GraphWrapperHIP.from_dict(g, ctx=ictx, useGLC=bool(opts.algorithm))
+    st = hg.marginalizeNoOptimize(which, opts)
+    assert st["n_bad_status"] == 0
+    assert st["n_removed"] == int(np.sum(gold_bl["k"] >= 0)) or opts.topology == abi.TOPO_DENSE
+    ids, _ = hg.vertices()
+    assert np.array_equal(ids, gold_vids)
+    util.compare_edge_sets(g["pose_dim"], gold_edges, hg.edges(), rtol=1e-11)
+    assert st["n_rounds"] < len(gold_bl["root"])  # it did batch
+
+
+def test_rounds_equal_sequential_other_orders(ictx):
+    """Removal lists that are not ascending / not sparsity patterns, and sparsity > 2 (chains of
+    adjacent removed vertices)."""
+    g = g2o_io.synth_sphere(n_poses=1500, ring=50)
+    rng = np.random.default_rng(4)
+    for which in (rng.permutation(np.arange(4, 1500))[:700], np.array([i for i in range(4, 1500) if i % 4]),
+                  np.arange(1499, 3, -1)[:900]):
+        which = which.astype(np.int32)
+        opts = abi.make_options(6)
+        og = oracle_lib.OracleGraph.from_dict(g)
+        assert og.marginalize(which, opts) == 0
+        hg = GraphWrapperHIP.from_dict(g, ctx=ictx)
+        st = hg.marginalizeNoOptimize(which, opts)
+        assert st["n_removed"] == len(which)
+        util.compare_edge_sets(6, og.edges(), hg.edges(), rtol=1e-11)
+
+
+def test_invalid_arguments(ictx):
+    g = g2o_io.synth_sphere(n_poses=100, ring=10)
+    hg = GraphWrapperHIP.from_dict(g, ctx=ictx)
+    from sparsifyposegraph_amd.lib import SpgError
+    with pytest.raises(SpgError):
+        hg.marginalizeNoOptimize(np.array([5000], np.int32), abi.make_options(6))  # "vertex needs to exist"
+    with pytest.raises(SpgError):
+        hg.marginalizeNoOptimize(np.array([5], np.int32), abi.make_options(3))     # pose_dim mismatch
+    with pytest.raises(SpgError):
+        hg.addEdge(1, 9999, np.zeros(7), np.eye(6))
+    st = hg.marginalizeNoOptimize(np.zeros(0, np.int32), abi.make_options(6))      # empty list is a no-op
+    assert st["n_removed"] == 0 and st["n_rounds"] == 0
+
+
+def test_leaf_and_duplicate_edges(ictx):
+    """Ragged inputs: a leaf (k = 1: vertex deleted, no new edge), duplicate i-j edges (manhattan has
+    145), and a vertex listed twice."""
+    d = 3
+    ids = np.arange(6, dtype=np.int32)
+    poses = np.array([[0, 0, 0], [1, 0, 0.1], [2, 0.2, 0.2], [3, 0.1, 0.1], [1, 1, 1.0], [2, 2, -1.0]], float)
+    ij = np.array([[0, 1], [1, 2], [1, 2], [2, 3], [1, 4], [3, 5]], np.int32)
+    info = np.array([50, 0, 0, 50, 0, 100.0])
+    data = []
+    for a, b in ij:
+        c, s = np.cos(poses[a, 2]), np.sin(poses[a, 2])
+        dx, dy = poses[b, :2] - poses[a, :2]
+        data.append(np.concatenate([[c * dx + s * dy, -s * dx + c * dy, poses[b, 2] - poses[a, 2]], info]))
+    g = {"pose_dim": d, "ids": ids, "poses": poses, "edge_ij": ij, "edge_data": np.array(data)}
+    which = np.array([5, 2, 2, 4], np.int32)
+    opts = abi.make_options(3)
+    og = oracle_lib.OracleGraph.from_dict(g)
+    assert og.marginalize(np.array([5, 2, 4], np.int32), opts) == 0
+    hg = GraphWrapperHIP.from_dict(g, ctx=ictx)
+    st = hg.marginalizeNoOptimize(which, opts)
+    assert st["n_removed"] == 3
+    util.compare_edge_sets(3, og.edges(), hg.edges(), rtol=1e-11)
+    ids_left, _ = hg.vertices()
+    assert list(ids_left) == [0, 1, 3]

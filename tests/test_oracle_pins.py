@@ -1,0 +1,276 @@
+"""CPU: pins the oracle's building blocks against independent implementations (numpy/LAPACK,
+central differences) and against the invariants SURVEY.md §8c lists. The reference owns no golden
+vectors for this path ("parity unpinned"), so these are what stands behind the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sparsifyposegraph_amd import abi, g2o_io
+from tests import oracle_lib, util
+
+f64p = C.POINTER(C.c_double)
+
+
+def P(a):
+    return a.ctypes.data_as(f64p)
+
+
+def rand_spd(rng, n, cond=1e3):
+    q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    w = np.exp(rng.uniform(0, np.log(cond), n))
+    return (q * w) @ q.T
+
+
+@pytest.mark.parametrize("n", [1, 3, 6, 12, 24, 37])
+def test_la_against_lapack(oracle, n):
+    rng = np.random.default_rng(n)
+    A = rand_spd(rng, n)
+    L = np.zeros((n, n))
+    assert oracle.spgref_chol(n, P(A), P(L)) == 0
+    assert np.allclose(L, np.linalg.cholesky(A), rtol=1e-12, atol=1e-12)
+    assert abs(oracle.spgref_spd_logdet(n, P(A)) - np.linalg.slogdet(A)[1]) < 1e-10
+    w, V = np.zeros(n), np.zeros((n, n))
+    assert oracle.spgref_eigh(n, P(A), P(w), P(V)) == 0
+    wr = np.linalg.eigvalsh(A)
+    assert np.allclose(w, wr, rtol=1e-12)
+    assert np.allclose(V @ np.diag(w) @ V.T, A, rtol=1e-11, atol=1e-11)
+    assert np.allclose(V.T @ V, np.eye(n), atol=1e-12)
+    B = rng.normal(size=(n, n)) + 3 * np.eye(n)
+    X = np.zeros((n, n))
+    assert oracle.spgref_lu_inverse(n, P(B), P(X)) == 0
+    assert np.allclose(X @ B, np.eye(n), atol=1e-10)
+
+
+def test_eigh_on_singular_gauge_like_matrix(oracle):
+    rng = np.random.default_rng(5)
+    n, d = 24, 6
+    U, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    w = np.concatenate([np.zeros(d), np.exp(rng.uniform(0, 6, n - d))])
+    A = (U * w) @ U.T
+    A = 0.5 * (A + A.T)
+    wv, V = np.zeros(n), np.zeros((n, n))
+    assert oracle.spgref_eigh(n, P(A), P(wv), P(V)) == 0
+    assert np.abs(wv[:d]).max() < 1e-10 * w.max()
+    assert np.allclose(wv[d:], np.sort(w[d:]), rtol=1e-11)
+
+
+def _rq(rng):
+    q = rng.normal(size=4)
+    return q / np.linalg.norm(q)
+
+
+def test_se3_jacobians_by_central_differences(oracle):
+    rng = np.random.default_rng(0)
+    worst = 0
+    for trial in range(300):
+        xi = np.concatenate([rng.normal(size=3) * 3, _rq(rng)])
+        xj = np.concatenate([rng.normal(size=3) * 3, _rq(rng)])
+        z = np.concatenate([rng.normal(size=3) * 3, _rq(rng)])
+        if trial % 2 == 0:  # zero-error linearisation, the new-edge case
+            z = np.zeros(7)
+            oracle.spgref_se3_between(P(xi), P(xj), P(z))
+        err, Ji, Jj = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 6))
+        oracle.spgref_se3_edge(P(xi), P(xj), P(z), P(err), P(Ji), P(Jj))
+        if trial % 2 == 0:
+            assert np.abs(err).max() < 1e-12
+        h, z0 = 1e-6, np.zeros(6)
+        Ni, Nj = np.zeros((6, 6)), np.zeros((6, 6))
+        for c in range(6):
+            d = np.zeros(6)
+            d[c] = h
+            ep, em = np.zeros(6), np.zeros(6)
+            oracle.spgref_se3_error_perturbed(P(xi), P(xj), P(z), P(d), P(z0), P(ep))
+            oracle.spgref_se3_error_perturbed(P(xi), P(xj), P(z), P(-d), P(z0), P(em))
+            Ni[:, c] = (ep - em) / (2 * h)
+            oracle.spgref_se3_error_perturbed(P(xi), P(xj), P(z), P(z0), P(d), P(ep))
+            oracle.spgref_se3_error_perturbed(P(xi), P(xj), P(z), P(z0), P(-d), P(em))
+            Nj[:, c] = (ep - em) / (2 * h)
+        worst = max(worst, np.abs(Ni - Ji).max(), np.abs(Nj - Jj).max())
+    assert worst < 5e-8
+
+
+def test_se2_jacobians_by_central_differences(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(100):
+        xi, xj, z = rng.normal(size=3) * 2, rng.normal(size=3) * 2, rng.normal(size=3)
+        err, Ji, Jj = np.zeros(3), np.zeros((3, 3)), np.zeros((3, 3))
+        oracle.spgref_se2_edge(P(xi), P(xj), P(z), P(err), P(Ji), P(Jj))
+        h = 1e-6
+        for c in range(3):
+            d = np.zeros(3)
+            d[c] = h
+            ep, em = np.zeros(3), np.zeros(3)
+            oracle.spgref_se2_edge(P(xi + d), P(xj), P(z), P(ep), None, None)
+            oracle.spgref_se2_edge(P(xi - d), P(xj), P(z), P(em), None, None)
+            de = ep - em
+            de[2] = (de[2] + np.pi) % (2 * np.pi) - np.pi
+            assert np.abs(de / (2 * h) - Ji[:, c]).max() < 1e-6
+            oracle.spgref_se2_edge(P(xi), P(xj + d), P(z), P(ep), None, None)
+            oracle.spgref_se2_edge(P(xi), P(xj - d), P(z), P(em), None, None)
+            de = ep - em
+            de[2] = (de[2] + np.pi) % (2 * np.pi) - np.pi
+            assert np.abs(de / (2 * h) - Jj[:, c]).max() < 1e-6
+
+
+def test_se2_between_matches_edge_error(oracle):
+    rng = np.random.default_rng(2)
+    xi, xj = rng.normal(size=3), rng.normal(size=3)
+    z = np.zeros(3)
+    oracle.spgref_se2_between(P(xi), P(xj), P(z))
+    err = np.zeros(3)
+    oracle.spgref_se2_edge(P(xi), P(xj), P(z), P(err), None, None)
+    assert np.abs(err).max() < 1e-14
+
+
+# --------------------------------------------------------------------------- blanket level
+def numpy_nfr_blanket(d, poses, m, edges, pairs, oracle):
+    """Independent restatement of computeTargetInformation + closedFormSolution + value with
+    numpy/LAPACK linear algebra (Jacobians through the oracle's unit function, itself pinned above)."""
+    nv = len(poses)
+    N = nv * d
+    ps = abi.pose_stride(d)
+    H = np.zeros((N, N))
+    iu = np.triu_indices(d)
+
+    def jac(xi, xj, z):
+        Ji, Jj = np.zeros((d, d)), np.zeros((d, d))
+        if d == 6:
+            oracle.spgref_se3_edge(P(xi), P(xj), P(z), None, P(Ji), P(Jj))
+        else:
+            oracle.spgref_se2_edge(P(xi), P(xj), P(z), None, P(Ji), P(Jj))
+        return Ji, Jj
+    for (a, b, rec) in edges:
+        Om = np.zeros((d, d))
+        Om[iu] = rec[ps:]
+        Om = Om + Om.T - np.diag(np.diag(Om))
+        Ji, Jj = jac(poses[a], poses[b], np.ascontiguousarray(rec[:ps]))
+        J = np.zeros((d, N))
+        J[:, a * d:(a + 1) * d] = Ji
+        J[:, b * d:(b + 1) * d] = Jj
+        H += J.T @ Om @ J
+    nm = m * d
+    T = H[nm:, nm:] - H[:nm, nm:].T @ np.linalg.solve(H[:nm, :nm], H[:nm, nm:])
+    T = np.triu(T) + np.triu(T, 1).T
+    n = N - nm
+    w, V = np.linalg.eigh(T)
+    U, S = V[:, d:], 1.0 / w[d:]
+    Sigma = (U * S) @ U.T
+    Xs, A = [], np.zeros((n, n))
+    for (a, b) in pairs:
+        z = np.zeros(ps)
+        if d == 6:
+            oracle.spgref_se3_between(P(poses[m + a]), P(poses[m + b]), P(z))
+        else:
+            oracle.spgref_se2_between(P(poses[m + a]), P(poses[m + b]), P(z))
+        Ja, Jb = jac(poses[m + a], poses[m + b], z)
+        J = np.zeros((d, n))
+        J[:, a * d:(a + 1) * d] = Ja
+        J[:, b * d:(b + 1) * d] = Jb
+        X = np.linalg.inv(J @ Sigma @ J.T)
+        Xs.append(X)
+        A += J.T @ X @ J
+    M = U.T @ A @ U
+    kld = 0.5 * (np.sum(np.diag(M) * S) - np.linalg.slogdet(M)[1] - np.sum(np.log(S)) - (n - d))
+    return T, Xs, kld
+
+
+@pytest.mark.parametrize("case", ["sphere_nfr_tree", "manhattan_nfr_tree", "parking_nfr_tree"])
+def test_nfr_blanket_against_numpy_restatement(case, oracle):
+    g, which, opts, _, _, _ = util.load_golden(case)
+    d = g["pose_dim"]
+    batch, roots = util.first_round_batch(g, which, opts, limit=40)
+    ref = abi.marginalize_batch(oracle, None, opts, batch)
+    ps, rec = abi.pose_stride(d), abi.binary_record_len(d)
+    iu = np.triu_indices(d)
+    checked = 0
+    for b in range(len(roots)):
+        if ref["status"][b] != 0 or ref["info"][b] != 0:
+            continue
+        v0, v1 = batch["vert_off"][b], batch["vert_off"][b + 1]
+        poses = [np.ascontiguousarray(batch["pose"][v * ps:(v + 1) * ps]) for v in range(v0, v1)]
+        ids = list(batch["vert_id"][v0:v1])
+        edges = []
+        for e in range(batch["edge_off"][b], batch["edge_off"][b + 1]):
+            a, bb = batch["edge_vert"][2 * e], batch["edge_vert"][2 * e + 1]
+            edges.append((a, bb, batch["edge_data"][e * rec:(e + 1) * rec]))
+        e0, e1 = ref["new_edge_off"][b], ref["new_edge_off"][b + 1]
+        pairs = []
+        for e in range(e0, e1):
+            va, vb = ref["new_edge_vert"][2 * e], ref["new_edge_vert"][2 * e + 1]
+            pairs.append((ids.index(va) - 1, ids.index(vb) - 1))
+        if len(pairs) == 0:
+            continue
+        T, Xs, kld = numpy_nfr_blanket(d, poses, 1, edges, pairs, oracle)
+        lo, hi = ref["target_info_off"][b], ref["target_info_off"][b + 1]
+        n = int(round(np.sqrt(hi - lo)))
+        To = ref["target_info"][lo:hi].reshape(n, n)
+        assert util.rel_err(To, T) < 1e-9
+        # invariants: symmetric, PSD, exact d-dimensional gauge null space
+        assert np.abs(To - To.T).max() == 0
+        w = np.linalg.eigvalsh(To)
+        assert w[0] > -1e-9 * w[-1] and np.abs(w[:d]).max() < 1e-9 * w[-1] and w[d] > 1e-9 * w[-1]
+        for e, X in zip(range(e0, e1), Xs):
+            Xo = np.zeros((d, d))
+            Xo[iu] = ref["new_edge_data"][e * rec + ps:(e + 1) * rec]
+            Xo = Xo + Xo.T - np.diag(np.diag(Xo))
+            assert util.rel_err(Xo, X) < 1e-8
+            assert np.linalg.eigvalsh(Xo).min() > 0
+        assert abs(ref["kld"][b] - kld) < 1e-7 * max(1.0, abs(kld))
+        assert ref["kld"][b] > -1e-9
+        if len(pairs) == 1:  # k = 2: the single edge reproduces the target exactly
+            assert abs(ref["kld"][b]) < 1e-8
+        # spanning tree
+        assert len(pairs) == (v1 - v0) - 2
+        comp = list(range(v1 - v0 - 1))
+        for a, bb in pairs:
+            ca, cb = comp[a], comp[bb]
+            assert ca != cb
+            comp = [ca if c == cb else c for c in comp]
+        checked += 1
+    assert checked >= 20
+
+
+def test_glc_reparam_jacobian_by_central_differences(oracle):
+    rng = np.random.default_rng(3)
+    for d in (3, 6):
+        ps = abi.pose_stride(d)
+        q = 3
+        poses = np.zeros((q, ps))
+        for i in range(q):
+            poses[i, :3 if d == 6 else 2] = rng.normal(size=3 if d == 6 else 2)
+            if d == 6:
+                poses[i, 3:] = _rq(rng)
+            else:
+                poses[i, 2] = rng.uniform(-3, 3)
+        meas, J = np.zeros(d * q), np.zeros((d * q, d * q))
+        oracle.spgref_glc_reparam(d, q, P(poses), None, P(meas), P(J))
+        err = np.zeros(d * q)
+        oracle.spgref_glc_reparam(d, q, P(poses), P(meas), P(err), P(J))
+        assert np.abs(err).max() < 1e-12
+        # block structure: first block absolute, others relative to the first
+        assert np.abs(J[:d, d:]).max() == 0 and np.abs(J[d:2 * d, 2 * d:]).max() == 0
+        if d == 3:
+            h = 1e-6
+            for v in range(q):
+                for c in range(3):
+                    pp, pm = poses.copy(), poses.copy()
+                    pp[v, c] += h
+                    pm[v, c] -= h
+                    ep, em = np.zeros(9), np.zeros(9)
+                    Jd = np.zeros((9, 9))
+                    oracle.spgref_glc_reparam(3, q, P(pp), P(meas), P(ep), P(Jd))
+                    oracle.spgref_glc_reparam(3, q, P(pm), P(meas), P(em), P(Jd))
+                    assert np.abs((ep - em) / (2 * h) - J[:, v * 3 + c]).max() < 1e-6
+
+
+def test_known_glc_edge_from_reference_comment(oracle):
+    """The only numbers the reference ships for this path: the GLC_EDGE line quoted at
+    src/test_marginalize_within_window.cpp:198-206 (vertex 10 at (10,0,0), relative (6,0,0),
+    W 3x6 with a zero absolute block). Its W^T W has rank 3 and no information on the absolute pose."""
+    W = np.array([[0, 6.44942e-14, 7.37069e-14, -5.38607e-12, -0.0781786, -2.09314e-05],
+                  [-0, -2.5976e-16, -3.96149e-14, 0.0782534, -5.39122e-12, -1.42468e-15],
+                  [0, 5.67138e-15, -1.09704e-14, -1.87717e-15, -0.00209596, 7.82839]])
+    G = W.T @ W
+    assert np.abs(G[:3, :]).max() < 1e-10  # gauge: nothing on the absolute first block
+    assert np.linalg.matrix_rank(G[3:, 3:], tol=1e-12) == 3
