@@ -125,7 +125,7 @@ def main():
         flops = FLOP_PER_NODE_K4 * prof["blankets"] / (1e-3 * prof["kernel_ms"]) / 1e12
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None, "kernel": "blanket_kernel<6,64,false>", "launches": prof["launches"],
+            "traffic": None, "kernel": "blanket_kernel<6,64,false,NFR>", "launches": prof["launches"],
             "avg_launch_us": 1e6 * per_launch_s, "alg_bytes_per_launch": per_launch_bytes,
             "blankets_per_launch": prof["blankets"] / prof["launches"],
             "note": "path is fp64-ALU/latency-bound on paper (SURVEY.md 8d: ~110 flop/B); fp64 vector fraction alongside",

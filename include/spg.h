@@ -230,7 +230,7 @@ typedef struct {
     int32_t edge_begin, n_edge;           /* into edge refs */
     int32_t n_new_max;                    /* most new edges this blanket can emit */
     int32_t n_new_vert_max;               /* most endpoints over all its new edges */
-    int32_t pad_;
+    int32_t pad_;                         /* scratch doubles the blanket's n-ary (GLC) edges need during assembly */
     int64_t new_off;                      /* arena offset where new-edge records are packed */
     int64_t new_len;                      /* doubles reserved at new_off */
     int64_t out_off;                      /* arena offset of the per-blanket output record */

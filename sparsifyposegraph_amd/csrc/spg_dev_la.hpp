@@ -305,3 +305,170 @@ __device__ __forceinline__ void chol_inverse_reg(const double *L, double *X) {
 }
 
 }  // namespace spgdev
+
+// ============================================================================================
+// Batched variants: `cnt` independent s x s matrices (matrix b at base + b*stride, leading dim ld)
+// advanced in lockstep by the whole team. Used by the GLC tail, where one blanket produces k-1
+// equally sized 2d x 2d problems (src/topology_provider_glc.cpp:143-182).
+namespace spgdev {
+
+// In-place inverse by Gauss-Jordan with partial pivoting (the reference goes through
+// Eigen::PartialPivLU(J).solve(I), src/topology_provider_glc.cpp:63-64). scratch: cnt*(2*s+2) doubles.
+// Sets *T.flag on a zero / non-finite pivot.
+template <int NT>
+__device__ void gj_inverse_batch(const Team<NT> &T, double *A, int cnt, int s, int ld, int stride, double *scratch) {
+    double *fcol = scratch;                       // cnt * s
+    int *ipiv = reinterpret_cast<int *>(scratch + (size_t)cnt * s);  // cnt * s ints (fits in cnt*s doubles)
+    int sh = ceil_log2(s);
+    for (int j = 0; j < s; j++) {
+        for (int b = T.tid; b < cnt; b += NT) {
+            double *M = A + (size_t)b * stride;
+            int p = j;
+            double best = fabs(M[j * ld + j]);
+            for (int i = j + 1; i < s; i++) { double v = fabs(M[i * ld + j]); if (v > best) { best = v; p = i; } }
+            if (!(best > 0.0) || !isfinite(best)) *T.flag = 1;
+            ipiv[b * s + j] = p;
+        }
+        T.sync();
+        for (int it = T.tid; it < (cnt << sh); it += NT) {
+            int b = it >> sh, c = it & ((1 << sh) - 1);
+            if (c < s) {
+                double *M = A + (size_t)b * stride;
+                int p = ipiv[b * s + j];
+                if (p != j) { double t = M[j * ld + c]; M[j * ld + c] = M[p * ld + c]; M[p * ld + c] = t; }
+            }
+        }
+        T.sync();
+        for (int it = T.tid; it < (cnt << sh); it += NT) {
+            int b = it >> sh, i = it & ((1 << sh) - 1);
+            if (i < s) {
+                double *M = A + (size_t)b * stride;
+                fcol[b * s + i] = (i == j) ? (1.0 / M[j * ld + j]) : M[i * ld + j];
+            }
+        }
+        T.sync();
+        // scale pivot row (with the unit substitution), clear column j elsewhere
+        for (int it = T.tid; it < (cnt << sh); it += NT) {
+            int b = it >> sh, c = it & ((1 << sh) - 1);
+            if (c < s) {
+                double *M = A + (size_t)b * stride;
+                double pv = fcol[b * s + j];
+                M[j * ld + c] = ((c == j) ? 1.0 : M[j * ld + c]) * pv;
+            }
+        }
+        T.sync();
+        for (int it = T.tid; it < ((cnt * s) << sh); it += NT) {
+            int bi = it >> sh, c = it & ((1 << sh) - 1);
+            int b = bi / s, i = bi - b * s;
+            if (c < s && i != j) {
+                double *M = A + (size_t)b * stride;
+                double f = fcol[b * s + i];
+                double base = (c == j) ? 0.0 : M[i * ld + c];
+                M[i * ld + c] = base - f * M[j * ld + c];
+            }
+        }
+        T.sync();
+    }
+    for (int j = s - 1; j >= 0; j--) {
+        for (int it = T.tid; it < (cnt << sh); it += NT) {
+            int b = it >> sh, i = it & ((1 << sh) - 1);
+            if (i < s) {
+                double *M = A + (size_t)b * stride;
+                int p = ipiv[b * s + j];
+                if (p != j) { double t = M[i * ld + j]; M[i * ld + j] = M[i * ld + p]; M[i * ld + p] = t; }
+            }
+        }
+        T.sync();
+    }
+}
+
+// Batched parallel-order Jacobi (see jacobi_eigh). cs: cnt*(s+4) doubles; done: cnt ints.
+// On exit the diagonals hold the eigenvalues, V the eigenvectors. Sets *T.flag if any matrix fails
+// to converge.
+template <int NT>
+__device__ void jacobi_batch(const Team<NT> &T, double *A, double *V, int cnt, int s, int ld, int stride, double *cs,
+                             int *done, int max_sweeps = 60) {
+    int sh = ceil_log2(s);
+    int np = (s + 1) >> 1, n2 = np * 2;
+    for (int it = T.tid; it < ((cnt * s) << sh); it += NT) {
+        int bi = it >> sh, j = it & ((1 << sh) - 1);
+        int b = bi / s, i = bi - b * s;
+        if (j < s) V[(size_t)b * stride + i * ld + j] = (i == j) ? 1.0 : 0.0;
+    }
+    for (int b = T.tid; b < cnt; b += NT) done[b] = (s <= 1) ? 1 : 0;
+    T.sync();
+    for (int sweep = 0; sweep <= max_sweeps; sweep++) {
+        // convergence test per matrix (one lane each)
+        for (int b = T.tid; b < cnt; b += NT) {
+            if (done[b]) continue;
+            const double *M = A + (size_t)b * stride;
+            double off2 = 0, fro2 = 0;
+            for (int i = 0; i < s; i++)
+                for (int j = 0; j < s; j++) { double a = M[i * ld + j]; fro2 += a * a; if (i != j) off2 += a * a; }
+            if (off2 <= 1e-31 * fro2 || fro2 == 0.0) done[b] = 1;
+            else if (sweep == max_sweeps) { done[b] = 1; *T.flag = 1; }
+        }
+        T.sync();
+        int alldone = 1;
+        for (int b = 0; b < cnt; b++) alldone &= done[b];
+        if (alldone) break;
+        for (int st = 0; st < n2 - 1; st++) {
+            for (int it = T.tid; it < cnt * np; it += NT) {
+                int b = it / np, pi = it - b * np;
+                double c = 1.0, sn = 0.0;
+                if (!done[b]) {
+                    const double *M = A + (size_t)b * stride;
+                    int p, q;
+                    rr_pair(st, pi, n2, p, q);
+                    if (q < s) {
+                        double apq = M[p * ld + q];
+                        if (fabs(apq) > 1e-300) {
+                            double tau = (M[q * ld + q] - M[p * ld + p]) / (2.0 * apq);
+                            double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                            c = 1.0 / sqrt(1.0 + t * t);
+                            sn = t * c;
+                        }
+                    }
+                }
+                cs[2 * it] = c; cs[2 * it + 1] = sn;
+            }
+            T.sync();
+            for (int it = T.tid; it < ((cnt * np) << sh); it += NT) {
+                int bp = it >> sh, i = it & ((1 << sh) - 1);
+                if (i >= s) continue;
+                int b = bp / np, pi = bp - b * np;
+                double c = cs[2 * bp], sn = cs[2 * bp + 1];
+                if (sn == 0.0) continue;
+                int p, q;
+                rr_pair(st, pi, n2, p, q);
+                double *M = A + (size_t)b * stride, *W = V + (size_t)b * stride;
+                double aip = M[i * ld + p], aiq = M[i * ld + q];
+                M[i * ld + p] = c * aip - sn * aiq;
+                M[i * ld + q] = sn * aip + c * aiq;
+                double vip = W[i * ld + p], viq = W[i * ld + q];
+                W[i * ld + p] = c * vip - sn * viq;
+                W[i * ld + q] = sn * vip + c * viq;
+            }
+            T.sync();
+            for (int it = T.tid; it < ((cnt * np) << sh); it += NT) {
+                int bp = it >> sh, j = it & ((1 << sh) - 1);
+                if (j >= s) continue;
+                int b = bp / np, pi = bp - b * np;
+                double c = cs[2 * bp], sn = cs[2 * bp + 1];
+                if (sn == 0.0) continue;
+                int p, q;
+                rr_pair(st, pi, n2, p, q);
+                double *M = A + (size_t)b * stride;
+                double apj = M[p * ld + j], aqj = M[q * ld + j];
+                double np_ = c * apj - sn * aqj, nq_ = sn * apj + c * aqj;
+                if (j == q) np_ = 0.0;
+                if (j == p) nq_ = 0.0;
+                M[p * ld + j] = np_;
+                M[q * ld + j] = nq_;
+            }
+            T.sync();
+        }
+    }
+}
+
+}  // namespace spgdev

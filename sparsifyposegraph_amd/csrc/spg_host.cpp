@@ -777,14 +777,17 @@ extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
             for (size_t i = 0; i < r.verts.size(); i++) { g->h_vpo.push_back(g->vpose[r.verts[i]]); lidx[r.verts[i]] = (int32_t)i; }
             bd.edge_begin = (int32_t)g->h_er.size();
             bd.n_edge = (int32_t)r.edges.size();
+            int32_t scratch = 0;
             for (int32_t eid : r.edges) {
                 const GEdge &e = g->edges[eid];
+                if (e.kind == SPG_EDGE_GLC) scratch = std::max(scratch, e.len - d * e.nv + e.nv * 2 * d * d);
                 spg_edge_ref er;
                 er.off = e.off; er.len = e.len; er.kind = e.kind; er.vbegin = (int32_t)g->h_ev.size(); er.nv = e.nv;
                 for (int i = 0; i < e.nv; i++) g->h_ev.push_back(lidx[g->everts[e.vbeg + i]]);
                 g->h_er.push_back(er);
             }
             new_edge_budget(o, d, k, bd.n_new_max, bd.n_new_vert_max, bd.new_len);
+            bd.pad_ = scratch;  // doubles of assembly scratch the blanket's n-ary edges need (r*dq + q*2*d*d)
             bd.out_off = hdr;  // relative for now
             hdr += SPG_OUT_LEN(bd.n_new_max, bd.n_new_vert_max);
             bd.new_off = body;
@@ -995,6 +998,8 @@ extern "C" int spg_marginalize_batch(spg_ctx *ctx, const spg_options *o, const s
         bd.n_edge = bt->edge_off[b + 1] - bt->edge_off[b];
         int k = bd.n_vert - bd.n_remove;
         new_edge_budget(*o, d, std::max(k, 0), bd.n_new_max, bd.n_new_vert_max, bd.new_len);
+        for (int e = bd.edge_begin; e < bd.edge_begin + bd.n_edge; e++)
+            if (er[e].kind == SPG_EDGE_GLC) bd.pad_ = std::max(bd.pad_, er[e].len - d * er[e].nv + er[e].nv * 2 * d * d);
         bd.out_off = cur; cur += SPG_OUT_LEN(bd.n_new_max, bd.n_new_vert_max);
         bd.new_off = cur; cur += bd.new_len;
         if (r->target_info) { int64_t n = (int64_t)d * std::max(k, 0); bd.tinfo_off = cur; cur += n * n; }

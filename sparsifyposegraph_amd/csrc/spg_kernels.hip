@@ -44,10 +44,18 @@ struct Layout {
     int o_M1, o_M2, o_M3, o_Hmm, o_Hmk, mat_doubles;
     // int area offsets (in ints, relative to o_int)
     int i_perm, i_keep, i_sorted, i_comp, i_pairs, i_ev, i_misc, int_count;
+    // GLC tail: CNT problems of size S (tree: k-1 of 2d; dense / k==1: one of n), see glc section
+    int gS, gCNT, gld, gstride;
+    int o_gmeas, o_gev, o_gcs, o_gscr;          // small (LDS)
+    int i_gperm, i_gdone, i_gmeta, i_gverts;    // ints
+    int o_G, o_gA;                              // mat space: 4 batch buffers; GLC-edge assembly scratch
 };
 
-__host__ __device__ inline Layout make_layout(int D, int nt, int k, int m) {
+__host__ __device__ inline Layout make_layout(int D, int nt, int k, int m, int alg = SPG_ALG_NFR, int topo = SPG_TOPO_TREE,
+                                              int scratch = 0) {
     Layout L;
+    const bool glc = (alg == SPG_ALG_GLC);
+    const bool single = (topo == SPG_TOPO_DENSE) || k <= 1;
     int DD = D * D;
     L.n = D * k; L.nm = D * m;
     L.ld = L.n | 1; L.ldm = L.nm | 1;
@@ -70,6 +78,14 @@ __host__ __device__ inline Layout make_layout(int D, int nt, int k, int m) {
     L.o_eT = o; o += 2 * DD;
     L.o_Ng = o; o += L.n * D;
     L.o_tre = o; o += L.NE;
+    L.gS = single ? (k > 0 ? D * k : D) : 2 * D;
+    L.gCNT = single ? 1 : (k - 1);
+    L.gld = L.gS | 1;
+    L.gstride = L.gS * L.gld;
+    L.o_gmeas = o; if (glc) o += L.gCNT * L.gS;
+    L.o_gev = o; if (glc) o += L.gCNT * L.gS;
+    L.o_gcs = o; if (glc) o += L.gCNT * (L.gS + 4);
+    L.o_gscr = o; if (glc) o += L.gCNT * (2 * L.gS + 2);
     L.o_int = o;
     int io = 0;
     L.i_perm = io; io += L.n;
@@ -79,6 +95,10 @@ __host__ __device__ inline Layout make_layout(int D, int nt, int k, int m) {
     L.i_pairs = io; io += 2 * L.NE;
     L.i_ev = io; io += 2 * EC;
     L.i_misc = io; io += 8;
+    L.i_gperm = io; if (glc) io += L.gCNT * L.gS;
+    L.i_gdone = io; if (glc) io += L.gCNT;
+    L.i_gmeta = io; if (glc) io += 3 * (L.NE + 1);
+    L.i_gverts = io; if (glc) io += 2 * L.NE + k + 2;
     L.int_count = io;
     o += (io + 1) / 2;
     L.small_doubles = o;
@@ -88,6 +108,8 @@ __host__ __device__ inline Layout make_layout(int D, int nt, int k, int m) {
     L.o_M3 = mo; mo += L.n * L.ld;
     L.o_Hmm = mo; mo += L.nm * L.ldm;
     L.o_Hmk = mo; mo += L.nm * L.ld;
+    L.o_G = mo; if (glc) mo += 4 * L.gCNT * L.gstride;
+    L.o_gA = mo; if (glc) mo += scratch;
     L.mat_doubles = mo;
     return L;
 }
@@ -108,7 +130,7 @@ struct KArgs {
 // upper-triangular (row-wise) index of (r,c), r <= c
 __device__ __forceinline__ int utri(int r, int c, int D) { return r * D - (r * (r - 1)) / 2 + (c - r); }
 
-template <int D, int NT, bool GWS>
+template <int D, int NT, bool GWS, int ALG>
 __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     extern __shared__ double smem[];
     constexpr int DD = D * D;
@@ -119,7 +141,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     const int b = a.list[blockIdx.x];
     const spg_blanket_desc bd = a.blk[b];
     const int nv = bd.n_vert, m = bd.n_remove, k = nv - m;
-    const Layout L = make_layout(D, NT, k, m);
+    const Layout L = make_layout(D, NT, k, m, ALG, a.topology, bd.pad_);
     const int n = L.n, nm = L.nm, ld = L.ld, ldm = L.ldm;
     double *mat = GWS ? (a.gws + (size_t)blockIdx.x * (size_t)a.gws_stride) : (smem + L.small_doubles);
     double *pose = smem + L.o_pose, *cs = smem + L.o_cs, *ev = smem + L.o_ev, *Sv = smem + L.o_S;
@@ -162,7 +184,11 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     for (int i = tid; i < nm * ld; i += NT) Hmk[i] = 0.0;
     T.sync();
     if (bd.n_edge == 0 || m < 1) { status = SPG_ST_EMPTY_BLANKET; finish(); return; }
-    if (a.algorithm != SPG_ALG_NFR) { status = SPG_ST_UNSUPPORTED; finish(); return; }
+    constexpr bool is_glc = (ALG == SPG_ALG_GLC);  // compile-time: the NFR instantiation carries no GLC code
+    if (is_glc && !(a.topology == SPG_TOPO_DENSE || a.topology == SPG_TOPO_TREE)) {
+        status = SPG_ST_UNSUPPORTED;  // asserts at src/topology_provider_glc.cpp:107-111
+        finish(); return;
+    }
 
     // ---------------------------------------------------------------- assemble H (a6)
     auto hadd = [&](int R, int Cc, double val) {
@@ -189,7 +215,8 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                     se2_edge_jac(pose + vi * PSZ, pose + vj * PSZ, rec, eJ + tid * 2 * DD, eJ + tid * 2 * DD + DD, nullptr);
                 }
             } else {
-                misc[1] = 1;  // GLC edge inside an NFR blanket: no provider applies
+                if (!is_glc) misc[1] = 1;  // GLC edge inside an NFR blanket: no provider applies
+                vi = -1;                    // handled by the n-ary loop below
             }
             echv[2 * tid] = vi; echv[2 * tid + 1] = vj;
         }
@@ -197,10 +224,11 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             int e = it / DD, rc = it - e * DD, r = rc / D, c = rc - r * D;
             const spg_edge_ref er = a.er[bd.edge_begin + base + e];
             int lo = r < c ? r : c, hi = r < c ? c : r;
-            eO[it] = arena[er.off + PS + utri(lo, hi, D)];
+            eO[it] = (er.kind == SPG_EDGE_BINARY) ? arena[er.off + PS + utri(lo, hi, D)] : 0.0;
         }
         T.sync();
         for (int e = 0; e < cnt; e++) {
+            if (echv[2 * e] < 0) continue;
             const double *Ji = eJ + e * 2 * DD, *Jj = Ji + DD, *Om = eO + e * DD;
             for (int it = tid; it < 2 * DD; it += NT) {
                 int wch = it / DD, rc = it - wch * DD, r = rc / D, c = rc - r * D;
@@ -227,6 +255,55 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         }
     }
     if (misc[1]) { status = SPG_ST_UNSUPPORTED; finish(); return; }
+    if constexpr (is_glc) {
+        // n-ary GLC edges already in the blanket (a14): H += (W Jr)^T (W Jr), Jr = reparametrisation
+        // Jacobian at the current estimates (src/glc_edge.cpp:40-49, src/glc_reparam_binary.hpp:78-127)
+        double *gA = mat + L.o_gA;
+        for (int e = 0; e < bd.n_edge; e++) {
+            const spg_edge_ref er = a.er[bd.edge_begin + e];
+            if (er.kind != SPG_EDGE_GLC) continue;
+            const int q = er.nv, dq = D * q, rr_ = (er.len - dq) / dq;
+            const double *rec = arena + er.off;   // meas (dq) then W (rr_ x dq)
+            double *Jb = gA;                      // q x (Ji0 | Jii), 2*DD each
+            double *Aw = gA + q * 2 * DD;         // rr_ x dq
+            for (int i = tid; i < q; i += NT) {
+                int v0 = a.ev[er.vbegin], vi = a.ev[er.vbegin + i];
+                if (D == 6) {
+                    double Z[kIso], Xz[kIso] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+                    iso_from_mqt(rec + 6 * i, Z);
+                    if (i == 0) se3_edge_jac(Xz, pose + v0 * PSZ, Z, Jb, Jb + DD, nullptr);
+                    else se3_edge_jac(pose + v0 * PSZ, pose + vi * PSZ, Z, Jb + i * 2 * DD, Jb + i * 2 * DD + DD, nullptr);
+                } else {
+                    double xz[3] = {0, 0, 0};
+                    if (i == 0) se2_edge_jac(xz, pose + v0 * PSZ, rec, Jb, Jb + DD, nullptr);
+                    else se2_edge_jac(pose + v0 * PSZ, pose + vi * PSZ, rec + 3 * i, Jb + i * 2 * DD, Jb + i * 2 * DD + DD, nullptr);
+                }
+            }
+            T.sync();
+            for (int it = tid; it < rr_ * dq; it += NT) {
+                int row = it / dq, col = it - row * dq, blk = col / D, c = col - blk * D;
+                const double *Wr = rec + dq + (int64_t)row * dq;
+                double sacc = 0;
+                if (blk == 0) {
+                    for (int p = 0; p < D; p++) sacc += Wr[p] * Jb[DD + p * D + c];            // W_0 * J00 (Jj of the mock edge)
+                    for (int i = 1; i < q; i++)
+                        for (int p = 0; p < D; p++) sacc += Wr[i * D + p] * Jb[i * 2 * DD + p * D + c];  // W_i * Ji0
+                } else {
+                    for (int p = 0; p < D; p++) sacc += Wr[blk * D + p] * Jb[blk * 2 * DD + DD + p * D + c];  // W_i * Jii
+                }
+                Aw[it] = sacc;
+            }
+            T.sync();
+            for (int it = tid; it < dq * dq; it += NT) {
+                int R = it / dq, Cc = it - R * dq;
+                double sacc = 0;
+                for (int p = 0; p < rr_; p++) sacc += Aw[p * dq + R] * Aw[p * dq + Cc];
+                int vR = a.ev[er.vbegin + R / D], vC = a.ev[er.vbegin + Cc / D];
+                hadd(vR * D + (R % D), vC * D + (Cc % D), sacc);
+            }
+            T.sync();
+        }
+    }
     const int stop_after = (a.flags >> 8) & 0xff;  // diagnostic: truncate the pipeline (timing breakdowns only)
     if (stop_after == 1) { finish(); return; }
 
@@ -255,35 +332,20 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         double *dst = arena + bd.tinfo_off;
         for (int it = tid; it < n * n; it += NT) { int i = it / n, j = it - i * n; dst[it] = M1[i * ld + j]; }
     }
-    if (k < 2 || stop_after == 2) { finish(); return; }
-
-    // ---------------------------------------------------------------- sparsity pattern (a8)
-    int ne;
-    {
-        int msub = (int)((1 + a.chord_ratio) * (k - 1));
-        bool full = msub >= k * (k - 1) / 2;
-        if (k == 2) ne = 1;
-        else if (a.topology == SPG_TOPO_TREE) ne = k - 1;
-        else if (a.topology == SPG_TOPO_DENSE || (a.topology == SPG_TOPO_SUBGRAPH && full)) ne = k * (k - 1) / 2;
-        else if (a.topology == SPG_TOPO_SUBGRAPH) ne = msub;
-        else { status = SPG_ST_UNSUPPORTED; finish(); return; }
-        if (ne * D != n - D) {
-            // Chow-Liu still runs in the reference before optimizeInformation discovers that no closed
-            // form exists (src/optimizer.cpp:21); the interior-point branch is out of scope.
-            status = SPG_ST_NEEDS_INTERIOR_POINT; finish(); return;
+    // pseudo-Chow-Liu tree of the kept vertices (a8): fills pairs[0..2(k-1)) in pop order, sets min_gap
+    auto chow_liu_tree = [&]() -> int {
+        if (k == 2) {
+            if (tid == 0) { pairs[0] = 0; pairs[1] = 1; }
+            T.sync();
+            return (int)SPG_OK;
         }
-    }
-    if (k == 2) {
-        if (tid == 0) { pairs[0] = 0; pairs[1] = 1; }
-        T.sync();
-    } else {
         // Sigma~ = (Lambda_t + 1 I)^-1 in M2
         for (int it = tid; it < n * ld; it += NT) M2[it] = M1[it];
         T.sync();
         for (int i = tid; i < n; i += NT) M2[i * ld + i] += 1.0;
         T.sync();
         chol_lower<NT>(T, M2, n, ld);
-        if (misc[0]) { status = SPG_ST_TIKHONOV_NOT_PD; finish(); return; }
+        if (misc[0]) return (int)SPG_ST_TIKHONOV_NOT_PD;
         tri_inverse_lower<NT>(T, M2, M3, n, ld);
         gram_lower_inverse<NT>(T, M3, M2, n, ld);
         // per-vertex diagonal blocks: Cholesky + log det
@@ -339,7 +401,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             w[p] = -((ldb[i] + ldb[j]) - lxy);  // stored negated: ascending sort == max-heap pop order
         }
         T.sync();
-        if (misc[0]) { status = SPG_ST_TIKHONOV_NOT_PD; finish(); return; }
+        if (misc[0]) return (int)SPG_ST_TIKHONOV_NOT_PD;
         sort_ascending<NT>(T, w, 1, L.P, sorted);
         if (tid == 0) {
             // Kruskal in pop order (src/pseudo_chow_liu.cpp:253-289); first `ne` of the bin are used
@@ -371,6 +433,32 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         T.sync();
         min_gap = cs[0];
         T.sync();
+        return (int)SPG_OK;
+    };
+    if constexpr (is_glc) {
+#include "spg_glc_tail.inc"
+    }
+    if (k < 2 || stop_after == 2) { finish(); return; }
+
+    // ---------------------------------------------------------------- sparsity pattern (a8)
+    int ne;
+    {
+        int msub = (int)((1 + a.chord_ratio) * (k - 1));
+        bool full = msub >= k * (k - 1) / 2;
+        if (k == 2) ne = 1;
+        else if (a.topology == SPG_TOPO_TREE) ne = k - 1;
+        else if (a.topology == SPG_TOPO_DENSE || (a.topology == SPG_TOPO_SUBGRAPH && full)) ne = k * (k - 1) / 2;
+        else if (a.topology == SPG_TOPO_SUBGRAPH) ne = msub;
+        else { status = SPG_ST_UNSUPPORTED; finish(); return; }
+        if (ne * D != n - D) {
+            // Chow-Liu still runs in the reference before optimizeInformation discovers that no closed
+            // form exists (src/optimizer.cpp:21); the interior-point branch is out of scope.
+            status = SPG_ST_NEEDS_INTERIOR_POINT; finish(); return;
+        }
+    }
+    {
+        int st_ = chow_liu_tree();
+        if (st_ != SPG_OK) { status = st_; finish(); return; }
     }
 
     if (stop_after == 3) { finish(); return; }
@@ -833,10 +921,10 @@ struct HipBackend {
     }
 };
 
-template <int D, int NT, bool GWS>
+template <int D, int NT, bool GWS, int ALG>
 static int launch_bin(HipBackend *hb, const KArgs &ka, int nblocks, size_t lds_bytes, double alg_bytes) {
     char *err = hb->err;
-    auto kern = blanket_kernel<D, NT, GWS>;
+    auto kern = blanket_kernel<D, NT, GWS, ALG>;
     if (lds_bytes > 64 * 1024)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HipBackend::Timed t{};
@@ -877,14 +965,14 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     const int D = o.pose_dim;
     if (D != 3 && D != 6) return SPG_EINVAL;
     // ---- bin this rank's blankets by the LDS their tiles need
-    struct Bin { std::vector<int32_t> list; int kmax = 0, mmax = 0; double bytes = 0; };
+    struct Bin { std::vector<int32_t> list; int kmax = 0, mmax = 0, smax = 0; double bytes = 0; };
     const int NB = 5;
     const size_t lim[NB - 1] = {24 * 1024, 40 * 1024, 80 * 1024, (size_t)hb->lds_limit};
     Bin bins[NB];
     for (int b = rd->first; b < rd->first + rd->count; b++) {
         const spg_blanket_desc &bd = rd->blankets[b];
         int k = bd.n_vert - bd.n_remove, m = bd.n_remove;
-        Layout L = make_layout(D, 64, k, m);
+        Layout L = make_layout(D, 64, k, m, o.algorithm, o.topology, bd.pad_);
         size_t need = (size_t)(L.small_doubles + L.mat_doubles) * 8;
         int bi = NB - 1;
         for (int i = 0; i < NB - 1; i++) if (need <= lim[i]) { bi = i; break; }
@@ -900,6 +988,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         }
         bins[bi].kmax = std::max(bins[bi].kmax, k);
         bins[bi].mmax = std::max(bins[bi].mmax, m);
+        bins[bi].smax = std::max(bins[bi].smax, (int)bd.pad_);
     }
     // ---- upload the round's descriptors (one pinned staging buffer, async copies)
     size_t s_blk = sizeof(spg_blanket_desc) * (size_t)rd->n_blankets;
@@ -955,18 +1044,27 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         list_off += nb;
         int rc;
         if (i < NB - 1) {
-            Layout L = make_layout(D, 64, bins[i].kmax, bins[i].mmax);
+            Layout L = make_layout(D, 64, bins[i].kmax, bins[i].mmax, o.algorithm, o.topology, bins[i].smax);
             size_t lds = (size_t)(L.small_doubles + L.mat_doubles) * 8;
-            rc = (D == 6) ? launch_bin<6, 64, false>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false>(hb, ka, nb, lds, bins[i].bytes);
+            // the (kmax, mmax, smax) envelope can exceed the device limit although every member fits
+            // (each needs <= lim[i] <= lds_limit): clamp, the per-block carve-up uses its own k, m
+            if (lds > (size_t)hb->lds_limit) lds = (size_t)hb->lds_limit;
+            if (o.algorithm == SPG_ALG_GLC)
+                rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_GLC>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_GLC>(hb, ka, nb, lds, bins[i].bytes);
+            else
+                rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_NFR>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_NFR>(hb, ka, nb, lds, bins[i].bytes);
         } else {
-            Layout L = make_layout(D, 256, bins[i].kmax, bins[i].mmax);
+            Layout L = make_layout(D, 256, bins[i].kmax, bins[i].mmax, o.algorithm, o.topology, bins[i].smax);
             size_t lds = (size_t)L.small_doubles * 8;
             if (lds > (size_t)hb->lds_limit) { snprintf(err, sizeof hb->err, "blanket too large for LDS side buffers: k=%d m=%d", bins[i].kmax, bins[i].mmax); return SPG_ECAPACITY; }
             size_t stride = ((size_t)L.mat_doubles + 31) & ~(size_t)31;
             if (int rc2 = hb->ensure(&hb->d_gws, &hb->c_gws, stride * 8 * (size_t)nb)) return rc2;
             ka.gws = (double *)hb->d_gws;
             ka.gws_stride = (int64_t)stride;
-            rc = (D == 6) ? launch_bin<6, 256, true>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true>(hb, ka, nb, lds, bins[i].bytes);
+            if (o.algorithm == SPG_ALG_GLC)
+                rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_GLC>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_GLC>(hb, ka, nb, lds, bins[i].bytes);
+            else
+                rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_NFR>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_NFR>(hb, ka, nb, lds, bins[i].bytes);
         }
         if (rc) return rc;
     }

@@ -10,6 +10,7 @@ from tests import oracle_lib, util
 pytestmark = pytest.mark.gpu
 
 NFR_CASES = [c for c in util.golden_cases() if "_nfr_" in c]
+GLC_CASES = [c for c in util.golden_cases() if "_glc_" in c]
 
 
 @pytest.mark.parametrize("route", ["gauge", "eigen"])
@@ -85,6 +86,47 @@ def test_graph_matches_golden_and_oracle(case, route, hip_ctx):
     fin = np.isfinite(k2)
     assert np.max(np.abs(k1[fin] - k2[fin]) / np.maximum(np.abs(k2[fin]), 1.0)) <= 1e-9
     print(f"{case}: rounds={st['n_rounds']} worst_rel={worst:.2e} kld_sum={st['kld_sum']:.9g}")
+
+
+@pytest.mark.parametrize("case", GLC_CASES)
+def test_glc_batch_matches_oracle(case, hip_ctx, oracle):
+    """GLC edges of first-round blankets: same emitted edges (root edge dropped by the 1e-8 cut in
+    both), measurements and W^T W within 1e-9 (W itself is defined up to an orthogonal factor)."""
+    g, which, opts, _, _, _ = util.load_golden(case)
+    bopts = abi.make_options(opts.pose_dim, abi.ALG_GLC, opts.topology)
+    batch, roots = util.first_round_batch(g, which, bopts)
+    ref = abi.marginalize_batch(oracle, None, bopts, batch)
+    got = hip_ctx.marginalize_batch(bopts, batch)
+    assert np.array_equal(ref["status"], got["status"])
+    assert np.array_equal(ref["info"], got["info"])
+    assert np.array_equal(ref["new_edge_off"], got["new_edge_off"])
+    assert np.array_equal(ref["new_edge_vert_off"], got["new_edge_vert_off"])
+    assert np.array_equal(ref["new_edge_vert"], got["new_edge_vert"])
+    assert np.array_equal(ref["new_edge_data_off"], got["new_edge_data_off"])
+    d = opts.pose_dim
+    worst = 0.0
+    for e in range(len(ref["new_edge_kind"])):
+        ids = ref["new_edge_vert"][ref["new_edge_vert_off"][e]:ref["new_edge_vert_off"][e + 1]]
+        lo, hi = ref["new_edge_data_off"][e], ref["new_edge_data_off"][e + 1]
+        n = d * len(ids)
+        worst = max(worst, util.rel_err(ref["new_edge_data"][lo:lo + n], got["new_edge_data"][lo:lo + n]))
+        worst = max(worst, util.rel_err(util.glc_gram(d, ids, ref["new_edge_data"][lo:hi]), util.glc_gram(d, ids, got["new_edge_data"][lo:hi])))
+    assert worst <= util.RTOL, worst
+    assert len(ref["new_edge_kind"]) > 20
+
+
+@pytest.mark.parametrize("case", GLC_CASES)
+def test_glc_graph_matches_golden(case, hip_ctx):
+    """Whole GLC marginalisation on the device: later blankets contain the n-ary GLC edges produced
+    by earlier ones (a14), Dense mode clusters adjacent removable vertices (m > 1)."""
+    g, which, opts, gold_edges, gold_bl, gold_vids = util.load_golden(case)
+    hg = GraphWrapperHIP.from_dict(g, ctx=hip_ctx, useGLC=True)
+    st = hg.marginalizeNoOptimize(which, opts)
+    assert st["n_bad_status"] == 0
+    ids, _ = hg.vertices()
+    assert np.array_equal(ids, gold_vids)
+    worst = util.compare_edge_sets(g["pose_dim"], gold_edges, hg.edges())
+    print(f"{case}: rounds={st['n_rounds']} worst_rel={worst:.2e}")
 
 
 def test_synthetic_properties(hip_ctx):
