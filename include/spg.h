@@ -259,6 +259,10 @@ typedef struct {
     const spg_edge_ref *edges;
     const int32_t *edge_vert;
     int64_t n_vert_total, n_edge_total, n_edge_vert_total;
+    /* optional host "mailbox": when mail_len > 0 and the backend has one, the out records of the
+     * computed blankets are ALSO delivered to backend->mailbox()[out_off - mail_base] (pinned host
+     * memory written by the kernel), so the host needs no device->host copy to read them */
+    int64_t mail_base, mail_len;
 } spg_round_desc;
 typedef struct {
     void *user;
@@ -268,6 +272,7 @@ typedef struct {
     int (*download)(void *user, double *dst, const void *src, int64_t doubles); /* arena -> host */
     int (*run_round)(void *user, void *arena, const spg_round_desc *round);     /* may be asynchronous */
     int (*synchronize)(void *user);
+    const double *(*mailbox)(void *user);   /* may be NULL: no mailbox, out records are downloaded */
 } spg_backend;
 int spg_ctx_create_injected(spg_ctx **out, const spg_backend *backend);
 

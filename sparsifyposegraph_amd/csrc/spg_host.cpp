@@ -92,6 +92,7 @@ struct spg_graph {
     std::vector<int64_t> chunk_hdr;   // per rank: doubles of out records at the start of its chunk
     spg_round_info rinfo{};
     bool round_open = false;
+    bool used_mailbox = false;
     int round_no = 0;
     spg_marg_stats stats{};
     std::vector<BlanketLog> log;
@@ -606,7 +607,7 @@ static void schedule_round(spg_graph *g) {
     std::vector<int32_t> newpending, B, centres, Dv, tmp;
     std::vector<int32_t> hit;
     bool stop = false;
-    size_t n_deferred = 0;
+    size_t n_deferred = 0, consec = 0;
     auto reg = [&](const std::vector<int32_t> &D) {
         int32_t oid = (int32_t)g->Dsets.size();
         g->Dsets.push_back(D);
@@ -652,6 +653,7 @@ static void schedule_round(spg_graph *g) {
             collect_edges(g, rbk.verts, centres, o.include_intra_clique != 0, rbk.edges);
             reg(B);
             g->rb.push_back(std::move(rbk));
+            consec = 0;
         } else {
             newpending.push_back(v);
             n_deferred++;
@@ -694,7 +696,9 @@ static void schedule_round(spg_graph *g) {
             }
             if (Dv.size() > DCAP) { stop = true; continue; }
             reg(Dv);
-            if (n_deferred > 256 + 2 * g->rb.size()) stop = true;
+            // stop scanning once a long run of list entries had to wait: whatever follows is
+            // (almost always) waiting on them too, and not scanning only defers more
+            if (++consec > 64 + g->rb.size() / 2 || n_deferred > 256 + 2 * g->rb.size()) stop = true;
         }
     }
     g->pending.swap(newpending);
@@ -834,7 +838,7 @@ extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
 extern "C" int spg_graph_round_compute(spg_graph *g) {
     if (!g || !g->active || !g->round_open) return SPG_ESTATE;
     double t0 = now_s();
-    spg_round_desc rd;
+    spg_round_desc rd{};
     rd.opts = &g->opts;
     rd.n_blankets = g->rinfo.n_blankets;
     rd.first = g->rinfo.my_first;
@@ -846,6 +850,10 @@ extern "C" int spg_graph_round_compute(spg_graph *g) {
     rd.n_vert_total = (int64_t)g->h_vpo.size();
     rd.n_edge_total = (int64_t)g->h_er.size();
     rd.n_edge_vert_total = (int64_t)g->h_ev.size();
+    // single rank: let the kernel deliver the out records straight into the backend's host mailbox
+    rd.mail_base = g->rinfo.region_off + g->rinfo.chunk_len * g->rank;
+    rd.mail_len = (g->nranks == 1 && g->ctx->be.mailbox) ? g->chunk_hdr[g->rank] : 0;
+    g->used_mailbox = rd.mail_len > 0;
     int rc = g->ctx->be.run_round(g->ctx->be.user, g->dev, &rd);
     g->stats.device_seconds += now_s() - t0;
     if (rc && g->ctx->is_hip) snprintf(g->ctx->err, sizeof g->ctx->err, "%s", spg::hip_backend_error(&g->ctx->be));
@@ -858,10 +866,12 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
     const int nr = g->nranks;
     int rc = g->ctx->be.synchronize(g->ctx->be.user);
     if (rc) return rc;
-    // read back the out-record part of every rank chunk
+    // read back the out-record part of every rank chunk (mailbox: already in host memory)
+    const double *mail = (g->used_mailbox && g->ctx->be.mailbox) ? g->ctx->be.mailbox(g->ctx->be.user) : nullptr;
     for (int q = 0; q < nr; q++) {
         if (g->chunk_hdr[q] == 0) continue;
         int64_t base = g->rinfo.region_off + g->rinfo.chunk_len * q;
+        if (mail && q == g->rank) { memcpy(g->host.data() + base, mail, (size_t)g->chunk_hdr[q] * 8); continue; }
         rc = g->ctx->be.download(g->ctx->be.user, g->host.data() + base, (char *)g->dev + base * 8, g->chunk_hdr[q]);
         if (rc) return rc;
     }
@@ -1012,7 +1022,7 @@ extern "C" int spg_marginalize_batch(spg_ctx *ctx, const spg_options *o, const s
     void *dev = ctx->be.alloc(ctx->be.user, cur);
     if (!dev) return set_err(ctx, SPG_ENOMEM, "arena allocation failed");
     int rc = ctx->be.upload(ctx->be.user, dev, host.data(), in_len);
-    spg_round_desc rd;
+    spg_round_desc rd{};
     rd.opts = o;
     rd.n_blankets = B; rd.first = 0; rd.count = B;
     rd.blankets = blk.data();

@@ -125,6 +125,8 @@ struct KArgs {
     int64_t gws_stride;
     int topology, algorithm, flags;
     double chord_ratio;
+    double *mail;        // pinned host mailbox for out records (or nullptr)
+    int64_t mail_base;   // arena offset that maps to mail[0]
 };
 
 // upper-triangular (row-wise) index of (r,c), r <= c
@@ -153,7 +155,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     double *M1 = mat + L.o_M1, *M2 = mat + L.o_M2, *M3 = mat + L.o_M3, *Hmm = mat + L.o_Hmm, *Hmk = mat + L.o_Hmk;
     Team<NT> T{tid, smem + L.o_red, misc + 0};
     double *arena = a.arena;
-    double *orec = arena + bd.out_off;
+    double *orec = a.mail ? (a.mail + (bd.out_off - a.mail_base)) : (arena + bd.out_off);
 
     int status = SPG_OK, info = 0, n_new = 0;
     double kld = __builtin_nan(""), min_gap = __builtin_inf();
@@ -888,8 +890,11 @@ struct HipBackend {
     hipStream_t stream = nullptr;
     char err[512] = {0};
     // device-side descriptor buffers (grown on demand)
-    void *d_blk = nullptr, *d_vpo = nullptr, *d_er = nullptr, *d_ev = nullptr, *d_list = nullptr, *d_gws = nullptr;
-    size_t c_blk = 0, c_vpo = 0, c_er = 0, c_ev = 0, c_list = 0, c_gws = 0;
+    void *d_desc = nullptr, *d_gws = nullptr;
+    size_t c_desc = 0, c_gws = 0;
+    // pinned host mailbox the kernel writes out records into (device-visible)
+    void *h_mail = nullptr, *d_mail = nullptr;
+    size_t c_mail = 0;
     // pinned host staging
     void *h_stage = nullptr;
     size_t c_stage = 0;
@@ -997,50 +1002,54 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     size_t s_ev = sizeof(int32_t) * (size_t)rd->n_edge_vert_total;
     size_t s_list = sizeof(int32_t) * (size_t)rd->count;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t tot = al(s_blk) + al(s_vpo) + al(s_er) + al(s_ev) + al(s_list);
+    size_t o_blk = 0, o_vpo = o_blk + al(s_blk), o_er = o_vpo + al(s_vpo), o_ev = o_er + al(s_er), o_list = o_ev + al(s_ev);
+    size_t tot = o_list + al(s_list);
     HIPCHK(hipSetDevice(hb->device));
-    // the previous round's copies must have drained before the staging buffer is rewritten
+    // the previous round's copy must have drained before the staging buffer is rewritten
     HIPCHK(hipStreamSynchronize(hb->stream));
     drain_profile(hb);
     if (int rc = hb->ensure_stage(tot)) return rc;
-    if (int rc = hb->ensure(&hb->d_blk, &hb->c_blk, s_blk)) return rc;
-    if (int rc = hb->ensure(&hb->d_vpo, &hb->c_vpo, s_vpo)) return rc;
-    if (int rc = hb->ensure(&hb->d_er, &hb->c_er, s_er)) return rc;
-    if (int rc = hb->ensure(&hb->d_ev, &hb->c_ev, std::max(s_ev, (size_t)4))) return rc;
-    if (int rc = hb->ensure(&hb->d_list, &hb->c_list, s_list)) return rc;
+    if (int rc = hb->ensure(&hb->d_desc, &hb->c_desc, tot)) return rc;
     char *st = (char *)hb->h_stage;
-    size_t off = 0;
-    auto put = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
-        if (bytes == 0) return hipSuccess;
-        memcpy(st + off, src, bytes);
-        hipError_t e = hipMemcpyAsync(dst, st + off, bytes, hipMemcpyHostToDevice, hb->stream);
-        off += al(bytes);
-        return e;
-    };
-    HIPCHK(put(hb->d_blk, rd->blankets, s_blk));
-    HIPCHK(put(hb->d_vpo, rd->vert_pose_off, s_vpo));
-    HIPCHK(put(hb->d_er, rd->edges, s_er));
-    HIPCHK(put(hb->d_ev, rd->edge_vert, s_ev));
+    memcpy(st + o_blk, rd->blankets, s_blk);
+    memcpy(st + o_vpo, rd->vert_pose_off, s_vpo);
+    memcpy(st + o_er, rd->edges, s_er);
+    if (s_ev) memcpy(st + o_ev, rd->edge_vert, s_ev);
     {
-        std::vector<int32_t> all;
-        all.reserve(rd->count);
-        for (int i = 0; i < NB; i++) all.insert(all.end(), bins[i].list.begin(), bins[i].list.end());
-        HIPCHK(put(hb->d_list, all.data(), s_list));
+        int32_t *lst = (int32_t *)(st + o_list);
+        size_t p = 0;
+        for (int i = 0; i < NB; i++) for (int32_t b : bins[i].list) lst[p++] = b;
+    }
+    // one host->device copy for all descriptors of the round
+    HIPCHK(hipMemcpyAsync(hb->d_desc, st, tot, hipMemcpyHostToDevice, hb->stream));
+    double *mail_dev = nullptr;
+    if (rd->mail_len > 0) {
+        size_t need = (size_t)rd->mail_len * 8;
+        if (need > hb->c_mail) {
+            if (hb->h_mail) HIPCHK(hipHostFree(hb->h_mail));
+            size_t nc = std::max(need, hb->c_mail * 2);
+            HIPCHK(hipHostMalloc(&hb->h_mail, nc, hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer(&hb->d_mail, hb->h_mail, 0));
+            hb->c_mail = nc;
+        }
+        mail_dev = (double *)hb->d_mail;
     }
     // ---- launch each non-empty bin
     KArgs ka;
     ka.arena = (double *)arena;
-    ka.blk = (const spg_blanket_desc *)hb->d_blk;
-    ka.vpo = (const int64_t *)hb->d_vpo;
-    ka.er = (const spg_edge_ref *)hb->d_er;
-    ka.ev = (const int32_t *)hb->d_ev;
+    ka.blk = (const spg_blanket_desc *)((char *)hb->d_desc + o_blk);
+    ka.vpo = (const int64_t *)((char *)hb->d_desc + o_vpo);
+    ka.er = (const spg_edge_ref *)((char *)hb->d_desc + o_er);
+    ka.ev = (const int32_t *)((char *)hb->d_desc + o_ev);
+    ka.mail = mail_dev;
+    ka.mail_base = rd->mail_base;
     ka.gws = nullptr; ka.gws_stride = 0;
     ka.topology = o.topology; ka.algorithm = o.algorithm; ka.flags = o.flags; ka.chord_ratio = o.chord_ratio;
     size_t list_off = 0;
     for (int i = 0; i < NB; i++) {
         int nb = (int)bins[i].list.size();
         if (nb == 0) continue;
-        ka.list = (const int32_t *)hb->d_list + list_off;
+        ka.list = (const int32_t *)((char *)hb->d_desc + o_list) + list_off;
         list_off += nb;
         int rc;
         if (i < NB - 1) {
@@ -1105,6 +1114,8 @@ static int hip_sync(void *user) {
     return 0;
 }
 
+static const double *hip_mailbox(void *user) { return (const double *)((HipBackend *)user)->h_mail; }
+
 int hip_backend_create(int device, spg_backend *out, char *errbuf, size_t errlen) {
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1134,6 +1145,7 @@ int hip_backend_create(int device, spg_backend *out, char *errbuf, size_t errlen
     out->download = hip_download;
     out->run_round = hip_run_round;
     out->synchronize = hip_sync;
+    out->mailbox = hip_mailbox;
     return 0;
 }
 
@@ -1142,12 +1154,9 @@ void hip_backend_destroy(spg_backend *b) {
     if (!hb) return;
     (void)hipSetDevice(hb->device);
     (void)hipStreamSynchronize(hb->stream);
-    if (hb->d_blk) (void)hipFree(hb->d_blk);
-    if (hb->d_vpo) (void)hipFree(hb->d_vpo);
-    if (hb->d_er) (void)hipFree(hb->d_er);
-    if (hb->d_ev) (void)hipFree(hb->d_ev);
-    if (hb->d_list) (void)hipFree(hb->d_list);
+    if (hb->d_desc) (void)hipFree(hb->d_desc);
     if (hb->d_gws) (void)hipFree(hb->d_gws);
+    if (hb->h_mail) (void)hipHostFree(hb->h_mail);
     if (hb->h_stage) (void)hipHostFree(hb->h_stage);
     (void)hipStreamDestroy(hb->stream);
     delete hb;
