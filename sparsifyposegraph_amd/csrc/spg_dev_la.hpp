@@ -37,6 +37,39 @@ struct Team {
     }
 };
 
+// 1/sqrt(x) and 1/x from the hardware seed (v_rsq_f64 / v_rcp_f64) + two Newton steps: fp64 division
+// and sqrt expand to ~40 dependent instructions each on gfx950, and a single wavefront cannot hide
+// that chain; the seeds are good to ~2^-26, two quadratic steps reach rounding level.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * (2.0 - x * y);
+    y = y * (2.0 - x * y);
+    return y;
+}
+
+// sum of logs as the log of a running product with the exponent carried separately (one log per
+// factorisation instead of one per pivot)
+struct LogProd {
+    double m = 1.0;
+    int e = 0;
+    __device__ __forceinline__ void mul(double x) {
+        int ex;
+        double mx = frexp(x, &ex);
+        m *= mx; e += ex;
+        int e2;
+        m = frexp(m, &e2);
+        e += e2;
+    }
+    __device__ __forceinline__ double value() const { return log(m) + (double)e * 0.6931471805599453; }
+};
+
 __device__ __forceinline__ int ceil_log2(int n) {
     int s = 0;
     while ((1 << s) < n) s++;
@@ -44,20 +77,23 @@ __device__ __forceinline__ int ceil_log2(int n) {
 }
 
 // In-place lower Cholesky (right-looking). Reads/writes the lower triangle only. On failure sets
-// *T.flag = 1 (checked by the caller after the call) and stops at the failing column.
+// *T.flag = 1 (checked by the caller after the call). Two barriers per column: every lane derives
+// 1/sqrt(pivot) itself, lane 0 alone stores the pivot. If rdiag != nullptr it receives 1/L_jj.
 template <int NT>
-__device__ void chol_lower(const Team<NT> &T, double *A, int n, int ld) {
+__device__ void chol_lower(const Team<NT> &T, double *A, int n, int ld, double *rdiag = nullptr) {
     for (int j = 0; j < n; j++) {
+        // every lane reads the pivot (ordered after the previous column's trailing update by barrier #2)
+        double d = A[j * ld + j];
+        bool bad = !(d > 0.0) || !isfinite(d);
+        if (bad) d = 1.0;
+        double rs = fast_rsqrt(d);
+        for (int i = j + 1 + T.tid; i < n; i += NT) A[i * ld + j] *= rs;
+        T.sync();  // #1: column j scaled, pivot consumed by everyone
         if (T.tid == 0) {
-            double d = A[j * ld + j];
-            if (!(d > 0.0) || !isfinite(d)) { *T.flag = 1; A[j * ld + j] = 1.0; }
-            else A[j * ld + j] = sqrt(d);
+            if (bad) *T.flag = 1;
+            A[j * ld + j] = d * rs;
+            if (rdiag) rdiag[j] = rs;
         }
-        T.sync();
-        double inv = 1.0 / A[j * ld + j];
-        T.sync();
-        for (int i = j + 1 + T.tid; i < n; i += NT) A[i * ld + j] *= inv;
-        T.sync();
         // trailing update: rows i > j, cols j < c <= i
         int m = n - j - 1;
         int sh = ceil_log2(m > 0 ? m : 1);
@@ -69,28 +105,33 @@ __device__ void chol_lower(const Team<NT> &T, double *A, int n, int ld) {
                 A[i * ld + cc] -= A[i * ld + j] * A[cc * ld + j];
             }
         }
-        T.sync();
+        T.sync();  // #2
     }
 }
 
 // 2 * sum(log L_ii) of a Cholesky factor
 template <int NT>
 __device__ double chol_logdet(const Team<NT> &T, const double *L, int n, int ld) {
-    double s = 0;
-    for (int i = T.tid; i < n; i += NT) s += log(L[i * ld + i]);
-    return 2.0 * T.sum(s);
+    // one lane walks the diagonal (n <= a few hundred): a single log of the running product
+    double v = 0;
+    if (T.tid == 0) {
+        LogProd lp;
+        for (int i = 0; i < n; i++) lp.mul(L[i * ld + i]);
+        v = 2.0 * lp.value();
+    }
+    return T.sum(v);
 }
 
 // Linv = L^-1 (lower), one lane per column; Linv may not alias L. Strict upper of Linv is zeroed.
 template <int NT>
-__device__ void tri_inverse_lower(const Team<NT> &T, const double *L, double *Li, int n, int ld) {
+__device__ void tri_inverse_lower(const Team<NT> &T, const double *L, double *Li, int n, int ld, const double *rdiag = nullptr) {
     for (int c = T.tid; c < n; c += NT) {
         for (int i = 0; i < c; i++) Li[i * ld + c] = 0.0;
-        Li[c * ld + c] = 1.0 / L[c * ld + c];
+        Li[c * ld + c] = rdiag ? rdiag[c] : fast_rcp(L[c * ld + c]);
         for (int i = c + 1; i < n; i++) {
             double s = 0;
             for (int k = c; k < i; k++) s += L[i * ld + k] * Li[k * ld + c];
-            Li[i * ld + c] = -s / L[i * ld + i];
+            Li[i * ld + c] = -s * (rdiag ? rdiag[i] : fast_rcp(L[i * ld + i]));
         }
     }
     T.sync();
@@ -120,7 +161,7 @@ __device__ void tri_solve_lower(const Team<NT> &T, const double *L, int n, int l
         for (int i = 0; i < n; i++) {
             double s = Y[i * ldy + c];
             for (int k = 0; k < i; k++) s -= L[i * ld + k] * Y[k * ldy + c];
-            Y[i * ldy + c] = s / L[i * ld + i];
+            Y[i * ldy + c] = s * fast_rcp(L[i * ld + i]);
         }
     }
     T.sync();
@@ -260,9 +301,8 @@ __device__ __forceinline__ bool chol_reg(double *a /*D*D row-major, lower used, 
 #pragma unroll
         for (int k = 0; k < D; k++) if (k < j) d -= a[j * D + k] * a[j * D + k];
         if (!(d > 0.0) || !isfinite(d)) { ok = false; d = 1.0; }
-        double l = sqrt(d);
-        a[j * D + j] = l;
-        double inv = 1.0 / l;
+        double inv = fast_rsqrt(d);
+        a[j * D + j] = d * inv;
 #pragma unroll
         for (int i = 0; i < D; i++) if (i > j) {
             double s = a[i * D + j];
@@ -283,12 +323,12 @@ __device__ __forceinline__ void chol_inverse_reg(const double *L, double *X) {
 #pragma unroll
         for (int i = 0; i < D; i++) {
             if (i < c) Li[i * D + c] = 0.0;
-            else if (i == c) Li[i * D + c] = 1.0 / L[c * D + c];
+            else if (i == c) Li[i * D + c] = fast_rcp(L[c * D + c]);
             else {
                 double s = 0;
 #pragma unroll
                 for (int k = 0; k < D; k++) if (k >= c && k < i) s += L[i * D + k] * Li[k * D + c];
-                Li[i * D + c] = -s / L[i * D + i];
+                Li[i * D + c] = -s * fast_rcp(L[i * D + i]);
             }
         }
     }

@@ -38,6 +38,31 @@ inline double now_s() {
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 }  // namespace
 
+// Host mirror of the arena: grows without value-initialising (the regions the device produces are
+// never read before they are downloaded), unlike std::vector<double>::resize.
+struct HostMirror {
+    double *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~HostMirror() { free(p); }
+    HostMirror() {}
+    HostMirror(const HostMirror &) = delete;
+    HostMirror &operator=(const HostMirror &) = delete;
+    double *data() { return p; }
+    const double *data() const { return p; }
+    size_t size() const { return n; }
+    double &operator[](size_t i) { return p[i]; }
+    const double &operator[](size_t i) const { return p[i]; }
+    void resize(size_t m) {
+        if (m > cap) {
+            size_t nc = std::max(m, cap * 2);
+            p = (double *)realloc(p, nc * sizeof(double));
+            if (!p) abort();
+            cap = nc;
+        }
+        n = m;
+    }
+};
+
 struct spg_ctx {
     spg_backend be{};
     bool is_hip = false;
@@ -75,7 +100,7 @@ struct spg_graph {
     // arena
     void *dev = nullptr;
     int64_t cap = 0, used = 0;
-    std::vector<double> host;      // mirror of [0, used)
+    HostMirror host;               // mirror of [0, used)
     int64_t dev_synced = 0;        // device holds [0, dev_synced)
     int64_t stale_lo = 0, stale_hi = 0;  // host mirror range that only the device holds
     // marginalisation state
@@ -556,7 +581,6 @@ static void collect_edges(spg_graph *g, const std::vector<int32_t> &verts, const
     next_stamp(g);
     int32_t st = g->stamp;
     for (int32_t v : verts) g->vstamp[v] = st;
-    std::vector<uint8_t> dummy;
     out.clear();
     for (int32_t v : verts)
         for (int32_t eid : g->adj[v]) {
@@ -604,7 +628,7 @@ static void schedule_round(spg_graph *g) {
     g->touched.clear();
     g->Dsets.clear();
     g->ocnt.clear();
-    std::vector<int32_t> newpending, B, centres, Dv, tmp;
+    std::vector<int32_t> newpending, B, centres, Dv, tmp, work, seen_owner;
     std::vector<int32_t> hit;
     bool stop = false;
     size_t n_deferred = 0, consec = 0;
@@ -663,10 +687,9 @@ static void schedule_round(spg_graph *g) {
             Dv.clear();
             auto addv = [&](int32_t x) { if (g->vstamp[x] != st) { g->vstamp[x] = st; Dv.push_back(x); } };
             for (int32_t x : B) addv(x);
-            std::vector<int32_t> work(centres.begin(), centres.end());
-            std::vector<uint8_t> dummy;
+            work.assign(centres.begin(), centres.end());
             size_t wi = 0;
-            std::vector<int32_t> seen_owner;
+            seen_owner.clear();
             while (wi < work.size() && Dv.size() <= DCAP) {
                 int32_t c = work[wi++];
                 for (int32_t oid : g->vowners[c]) {
@@ -698,7 +721,7 @@ static void schedule_round(spg_graph *g) {
             reg(Dv);
             // stop scanning once a long run of list entries had to wait: whatever follows is
             // (almost always) waiting on them too, and not scanning only defers more
-            if (++consec > 64 + g->rb.size() / 2 || n_deferred > 256 + 2 * g->rb.size()) stop = true;
+            if (++consec > 48 + g->rb.size() / 8 || n_deferred > 256 + 2 * g->rb.size()) stop = true;
         }
     }
     g->pending.swap(newpending);

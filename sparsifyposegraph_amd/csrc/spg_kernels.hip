@@ -28,6 +28,7 @@
 #include "../../include/spg.h"
 #include "spg_dev_geom.hpp"
 #include "spg_dev_la.hpp"
+#include "spg_dev_wave.hpp"
 #include "spg_internal.h"
 
 using namespace spgdev;
@@ -154,6 +155,8 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     int *pairs = ints + L.i_pairs, *echv = ints + L.i_ev, *misc = ints + L.i_misc;
     double *M1 = mat + L.o_M1, *M2 = mat + L.o_M2, *M3 = mat + L.o_M3, *Hmm = mat + L.o_Hmm, *Hmk = mat + L.o_Hmk;
     Team<NT> T{tid, smem + L.o_red, misc + 0};
+    // register-resident single-wavefront SPD kernels (spg_dev_wave.hpp) when the tile fits
+    const bool use_wave = (NT == 64) && !GWS && (n <= kWaveMax) && !((a.flags >> 17) & 1);
     double *arena = a.arena;
     double *orec = a.mail ? (a.mail + (bd.out_off - a.mail_base)) : (arena + bd.out_off);
 
@@ -174,6 +177,15 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         }
     };
 
+    // diagnostic cycle stamps (flags bit 16, needs tinfo_off >= 0): written only to the debug region
+    const bool stamping = ((a.flags >> 16) & 1) && bd.tinfo_off >= 0;
+    auto STAMP = [&](int idx) {
+        if (stamping) {
+            T.sync();
+            if (tid == 0) arena[bd.tinfo_off + idx] = (double)__builtin_amdgcn_s_memtime();
+        }
+    };
+    STAMP(0);  //
     // ---------------------------------------------------------------- gather poses, clear H
     if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0; }
     for (int v = tid; v < nv; v += NT) {
@@ -306,6 +318,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             T.sync();
         }
     }
+    STAMP(1);  // assembled
     const int stop_after = (a.flags >> 8) & 0xff;  // diagnostic: truncate the pipeline (timing breakdowns only)
     if (stop_after == 1) { finish(); return; }
 
@@ -330,7 +343,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         mirror_upper<NT>(T, M1, n, ld);
         if (anybad > 0) { status = SPG_ST_NONFINITE; finish(); return; }
     }
-    if (bd.tinfo_off >= 0) {
+    if (bd.tinfo_off >= 0 && !stamping) {
         double *dst = arena + bd.tinfo_off;
         for (int it = tid; it < n * n; it += NT) { int i = it / n, j = it - i * n; dst[it] = M1[i * ld + j]; }
     }
@@ -342,14 +355,24 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             return (int)SPG_OK;
         }
         // Sigma~ = (Lambda_t + 1 I)^-1 in M2
-        for (int it = tid; it < n * ld; it += NT) M2[it] = M1[it];
-        T.sync();
-        for (int i = tid; i < n; i += NT) M2[i * ld + i] += 1.0;
-        T.sync();
-        chol_lower<NT>(T, M2, n, ld);
-        if (misc[0]) return (int)SPG_ST_TIKHONOV_NOT_PD;
-        tri_inverse_lower<NT>(T, M2, M3, n, ld);
-        gram_lower_inverse<NT>(T, M3, M2, n, ld);
+        if (use_wave) {
+            double ld_, tr_;
+            bool ok_ = wave_spd_inverse(M1, ld, n, tid, 1.0, M2, ld_, tr_);
+            if (!ok_) return (int)SPG_ST_TIKHONOV_NOT_PD;
+            T.sync();
+        } else {
+            for (int it = tid; it < n * ld; it += NT) M2[it] = M1[it];
+            T.sync();
+            for (int i = tid; i < n; i += NT) M2[i * ld + i] += 1.0;
+            T.sync();
+            chol_lower<NT>(T, M2, n, ld, ev);
+            if (misc[0]) return (int)SPG_ST_TIKHONOV_NOT_PD;
+            STAMP(3);  // cl chol
+            tri_inverse_lower<NT>(T, M2, M3, n, ld, ev);
+            STAMP(4);  // cl triinv
+            gram_lower_inverse<NT>(T, M3, M2, n, ld);
+        }
+        STAMP(5);  // cl gram
         // per-vertex diagonal blocks: Cholesky + log det
         for (int v = tid; v < k; v += NT) {
             double Ab[DD];
@@ -358,16 +381,18 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
 #pragma unroll
                 for (int c = 0; c < D; c++) Ab[r * D + c] = M2[(v * D + r) * ld + v * D + c];
             if (!chol_reg<D>(Ab)) misc[0] = 1;
-            double s = 0;
+            LogProd lp;
 #pragma unroll
             for (int r = 0; r < D; r++) {
-                s += log(Ab[r * D + r]);
+                lp.mul(Ab[r * D + r]);
+                // keep 1/L_rr on the diagonal of the staged factor: the pair solves below multiply by it
 #pragma unroll
-                for (int c = 0; c < D; c++) Lb[v * DD + r * D + c] = Ab[r * D + c];
+                for (int c = 0; c < D; c++) Lb[v * DD + r * D + c] = (r == c) ? fast_rcp(Ab[r * D + r]) : Ab[r * D + c];
             }
-            ldb[v] = 2.0 * s;
+            ldb[v] = 2.0 * lp.value();
         }
         T.sync();
+        STAMP(6);  // cl vertex chol
         // pair weights w = ld_i + ld_j - ld_{ij}, ld_{ij} = ld_i + logdet(S_jj - S_ji S_ii^-1 S_ij)
         for (int p = tid; p < L.P; p += NT) {
             int i = 0, rem = p;
@@ -382,7 +407,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                     double s = M2[(i * D + r) * ld + j * D + c];
 #pragma unroll
                     for (int q = 0; q < D; q++) if (q < r) s -= Li[r * D + q] * Y[q * D + c];
-                    Y[r * D + c] = s / Li[r * D + r];
+                    Y[r * D + c] = s * Li[r * D + r];  // diagonal holds the reciprocal
                 }
             }
             double Sb[DD];
@@ -396,15 +421,17 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                     Sb[r * D + c] = s;
                 }
             if (!chol_reg<D>(Sb)) misc[0] = 1;
-            double s = 0;
+            LogProd lp;
 #pragma unroll
-            for (int r = 0; r < D; r++) s += log(Sb[r * D + r]);
-            double lxy = ldb[i] + 2.0 * s;
+            for (int r = 0; r < D; r++) lp.mul(Sb[r * D + r]);
+            double lxy = ldb[i] + 2.0 * lp.value();
             w[p] = -((ldb[i] + ldb[j]) - lxy);  // stored negated: ascending sort == max-heap pop order
         }
         T.sync();
         if (misc[0]) return (int)SPG_ST_TIKHONOV_NOT_PD;
+        STAMP(7);  // cl pair weights
         sort_ascending<NT>(T, w, 1, L.P, sorted);
+        STAMP(8);  // cl sort
         if (tid == 0) {
             // Kruskal in pop order (src/pseudo_chow_liu.cpp:253-289); first `ne` of the bin are used
             for (int v = 0; v < k; v++) comp[v] = v;
@@ -440,6 +467,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     if constexpr (is_glc) {
 #include "spg_glc_tail.inc"
     }
+    STAMP(2);  // schur
     if (k < 2 || stop_after == 2) { finish(); return; }
 
     // ---------------------------------------------------------------- sparsity pattern (a8)
@@ -463,6 +491,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         if (st_ != SPG_OK) { status = st_; finish(); return; }
     }
 
+    STAMP(9);  // kruskal
     if (stop_after == 3) { finish(); return; }
     // ---------------------------------------------------------------- new edge skeleton (a9, a10)
     for (int e = tid; e < ne; e += NT) {
@@ -489,6 +518,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         T.sync();
     }
 
+    STAMP(10);  // new edges
     if (stop_after == 4) { finish(); return; }
 
     // ================================================================ information recovery (a11, a12)
@@ -542,6 +572,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             }
         }
         T.sync();
+        STAMP(11);  // gauge basis
         // ---- orthonormalise: N^ = N L^-T with N^T N = L L^T (D x D, one lane, registers)
         if (tid < DD) {
             int rr = tid / D, c = tid - rr * D;
@@ -587,6 +618,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             }
         }
         T.sync();
+        STAMP(12);  // orthonormalised
         // ---- C = Lambda_t + N^ N^^T into M3, Cholesky, inverse
         {
             int sh = ceil_log2(n), tot = n << sh;
@@ -602,32 +634,51 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             }
             T.sync();
         }
-        chol_lower<NT>(T, M3, n, ld);
-        bool fail = (misc[0] != 0) || (misc[2] != 0);
-        T.sync();
-        if (tid == 0) { misc[0] = 0; misc[2] = 0; }
-        T.sync();
-        if (!fail) {
-            double ldC = chol_logdet<NT>(T, M3, n, ld);
-            tri_inverse_lower<NT>(T, M3, M2, n, ld);
-            // C^-1 = Li^T Li into M3 with its Frobenius norm
-            int sh = ceil_log2(n), tot = n << sh;
-            double f2 = 0;
-            for (int it = tid; it < tot; it += NT) {
-                int i = it >> sh, j = it & ((1 << sh) - 1);
-                if (j <= i) {
-                    double s = 0;
-                    for (int q = i; q < n; q++) s += M2[q * ld + i] * M2[q * ld + j];
-                    M3[i * ld + j] = s;
-                    M3[j * ld + i] = s;
-                    f2 += (i == j) ? s * s : 2.0 * s * s;
-                }
-            }
-            double fro2 = T.sum(f2);
-            if (fro2 < 5e4 * 5e4 && isfinite(fro2)) {
+        STAMP(13);  // C formed
+        if (use_wave) {
+            double ldC, trC;
+            bool ok_ = wave_spd_inverse(M3, ld, n, tid, 0.0, M3, ldC, trC);
+            bool fail = !ok_ || (misc[2] != 0);
+            T.sync();
+            if (tid == 0) { misc[0] = 0; misc[2] = 0; }
+            T.sync();
+            // trace(C^-1) >= lambda_max(C^-1): below 5e4 proves lambda_{d+1}(Lambda_t) > 1e-5
+            if (!fail && trC < 5e4 && isfinite(trC)) {
                 gauge_ok = true;
                 logdetS = -ldC;
                 Sg = M3; Scr = M1;
+            }
+        } else {
+            chol_lower<NT>(T, M3, n, ld, ev);
+            STAMP(14);  // C chol
+            bool fail = (misc[0] != 0) || (misc[2] != 0);
+            T.sync();
+            if (tid == 0) { misc[0] = 0; misc[2] = 0; }
+            T.sync();
+            if (!fail) {
+                double ldC = chol_logdet<NT>(T, M3, n, ld);
+                STAMP(15);  // logdet
+                tri_inverse_lower<NT>(T, M3, M2, n, ld, ev);
+                STAMP(16);  // triinv
+                // C^-1 = Li^T Li into M3 with its Frobenius norm
+                int sh = ceil_log2(n), tot = n << sh;
+                double f2 = 0;
+                for (int it = tid; it < tot; it += NT) {
+                    int i = it >> sh, j = it & ((1 << sh) - 1);
+                    if (j <= i) {
+                        double s = 0;
+                        for (int q = i; q < n; q++) s += M2[q * ld + i] * M2[q * ld + j];
+                        M3[i * ld + j] = s;
+                        M3[j * ld + i] = s;
+                        f2 += (i == j) ? s * s : 2.0 * s * s;
+                    }
+                }
+                double fro2 = T.sum(f2);
+                if (fro2 < 5e4 * 5e4 && isfinite(fro2)) {
+                    gauge_ok = true;
+                    logdetS = -ldC;
+                    Sg = M3; Scr = M1;
+                }
             }
         }
     }
@@ -717,6 +768,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             T.sync();
         }
     }
+    STAMP(17);  // Cinv+guard
     if (stop_after == 6) { finish(); return; }
 
     // ---------------------------------------------------------------- closed form X_e (a11)
@@ -773,6 +825,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         if (misc[0]) { status = SPG_ST_CLOSED_FORM_NOT_PD; finish(); return; }
     }
     n_new = ne;
+    STAMP(18);  // closed form
     if (stop_after == 7) { finish(); return; }
 
     // ---------------------------------------------------------------- per-blanket KLD (a12)
@@ -807,6 +860,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             T.sync();
         }
         mirror_upper<NT>(T, Am, n, ld);
+        STAMP(19);  // A assembled
         if (gauge_ok) {
             // kld = 1/2 ( tr(C^-1 A) - log det(A + N^ N^^T) + log det C - r ), tr(C^-1 A) = sum_e tr(X_e B_e)
             int sh = ceil_log2(n), tot = n << sh;
@@ -826,14 +880,23 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                 for (int e = tid; e < ne; e += NT) s += tre[e];
                 tr = T.sum(s);
             }
-            chol_lower<NT>(T, Am, n, ld);
-            if (misc[0]) {
-                kld = __builtin_inf();
-                status = SPG_ST_KLD_NOT_PD;
+            STAMP(20);  // A + NN
+            if (use_wave) {
+                double ldA;
+                bool ok_ = wave_spd_logdet(Am, ld, n, tid, ldA);
+                if (!ok_) { kld = __builtin_inf(); status = SPG_ST_KLD_NOT_PD; }
+                else kld = 0.5 * (tr - ldA - logdetS - (double)r);
             } else {
-                double ldA = chol_logdet<NT>(T, Am, n, ld);
-                kld = 0.5 * (tr - ldA - logdetS - (double)r);
+                chol_lower<NT>(T, Am, n, ld);
+                if (misc[0]) {
+                    kld = __builtin_inf();
+                    status = SPG_ST_KLD_NOT_PD;
+                } else {
+                    double ldA = chol_logdet<NT>(T, Am, n, ld);
+                    kld = 0.5 * (tr - ldA - logdetS - (double)r);
+                }
             }
+            STAMP(21);  // chol A
         } else {
             // Tm = A * U_kept  (n x r) into M3 ; XJ no longer needed
             int shr = ceil_log2(r > 0 ? r : 1);
@@ -875,6 +938,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             }
         }
     }
+    STAMP(22);  // end
     finish();
 }
 
