@@ -78,8 +78,9 @@ struct GEdge {
 struct RoundBlanket {
     int32_t root;                 // vertex index
     int32_t n_remove;
-    std::vector<int32_t> verts;   // vertex indices, removed first (asc id) then kept (asc id)
-    std::vector<int32_t> edges;   // edge ids, ascending
+    // flat pools (spg_graph::rb_verts / rb_edges) instead of per-blanket vectors: no allocation per blanket
+    int32_t vbeg = 0, nv = 0;     // vertex indices, removed first (asc id) then kept (asc id)
+    int32_t ebeg = 0, ne = 0;     // edge ids, ascending
     int32_t rank = 0;
     spg_blanket_desc desc{};
 };
@@ -110,6 +111,9 @@ struct spg_graph {
     std::vector<int32_t> pending;
     std::vector<uint8_t> in_set;   // vertex index is in the removal list
     std::vector<RoundBlanket> rb;
+    std::vector<int32_t> rb_verts, rb_edges;
+    std::vector<int32_t> Dpool;                       // owner sets, flat
+    std::vector<std::pair<int32_t, int32_t>> Dspan;   // (offset, length) per owner
     std::vector<spg_blanket_desc> h_blk;
     std::vector<int64_t> h_vpo;
     std::vector<spg_edge_ref> h_er;
@@ -127,7 +131,6 @@ struct spg_graph {
     int32_t stamp = 0;
     std::vector<std::vector<int32_t>> vowners;
     std::vector<int32_t> touched;
-    std::vector<std::vector<int32_t>> Dsets;
     std::vector<int32_t> ocnt;
     std::vector<int32_t> lidx;
 };
@@ -576,13 +579,14 @@ static void extended_blanket(spg_graph *g, int32_t root, std::vector<int32_t> &v
 static bool dense_mode(const spg_options &o) { return o.topology == SPG_TOPO_DENSE || o.topology == SPG_TOPO_CLIQUEY_DENSE; }
 
 // markovBlanketEdges (src/vertex_remover.cpp:225-251) for a selected blanket. `verts` must be stamped.
-static void collect_edges(spg_graph *g, const std::vector<int32_t> &verts, const std::vector<int32_t> &centres,
+static void collect_edges(spg_graph *g, const int32_t *verts, int nverts, const std::vector<int32_t> &centres,
                           bool intra, std::vector<int32_t> &out) {
     next_stamp(g);
     int32_t st = g->stamp;
-    for (int32_t v : verts) g->vstamp[v] = st;
+    for (int i = 0; i < nverts; i++) g->vstamp[verts[i]] = st;
     out.clear();
-    for (int32_t v : verts)
+    for (int vi_ = 0; vi_ < nverts; vi_++) {
+        int32_t v = verts[vi_];
         for (int32_t eid : g->adj[v]) {
             if (g->estamp[eid] == st) continue;
             g->estamp[eid] = st;
@@ -595,6 +599,7 @@ static void collect_edges(spg_graph *g, const std::vector<int32_t> &verts, const
             }
             if (ok && (intra || hub)) out.push_back(eid);
         }
+    }
     std::sort(out.begin(), out.end());
 }
 
@@ -623,18 +628,22 @@ static void schedule_round(spg_graph *g) {
     const bool dense = dense_mode(o);
     const size_t DCAP = 512;
     g->rb.clear();
+    g->rb_verts.clear();
+    g->rb_edges.clear();
     if (g->vowners.size() < g->vid.size()) g->vowners.resize(g->vid.size());
     for (int32_t v : g->touched) g->vowners[v].clear();
     g->touched.clear();
-    g->Dsets.clear();
+    g->Dpool.clear();
+    g->Dspan.clear();
     g->ocnt.clear();
     std::vector<int32_t> newpending, B, centres, Dv, tmp, work, seen_owner;
     std::vector<int32_t> hit;
     bool stop = false;
     size_t n_deferred = 0, consec = 0;
     auto reg = [&](const std::vector<int32_t> &D) {
-        int32_t oid = (int32_t)g->Dsets.size();
-        g->Dsets.push_back(D);
+        int32_t oid = (int32_t)g->Dspan.size();
+        g->Dspan.push_back({(int32_t)g->Dpool.size(), (int32_t)D.size()});
+        g->Dpool.insert(g->Dpool.end(), D.begin(), D.end());
         g->ocnt.push_back(0);
         for (int32_t x : D) {
             if (g->vowners[x].empty()) g->touched.push_back(x);
@@ -665,7 +674,6 @@ static void schedule_round(spg_graph *g) {
             rbk.n_remove = (int32_t)centres.size();
             auto byid = [g](int32_t a, int32_t b) { return g->vid[a] < g->vid[b]; };
             std::sort(centres.begin(), centres.end(), byid);
-            rbk.verts = centres;
             tmp.clear();
             for (int32_t x : B) {
                 bool is_c = false;
@@ -673,8 +681,14 @@ static void schedule_round(spg_graph *g) {
                 if (!is_c) tmp.push_back(x);
             }
             std::sort(tmp.begin(), tmp.end(), byid);
-            rbk.verts.insert(rbk.verts.end(), tmp.begin(), tmp.end());
-            collect_edges(g, rbk.verts, centres, o.include_intra_clique != 0, rbk.edges);
+            rbk.vbeg = (int32_t)g->rb_verts.size();
+            g->rb_verts.insert(g->rb_verts.end(), centres.begin(), centres.end());
+            g->rb_verts.insert(g->rb_verts.end(), tmp.begin(), tmp.end());
+            rbk.nv = (int32_t)(centres.size() + tmp.size());
+            collect_edges(g, g->rb_verts.data() + rbk.vbeg, rbk.nv, centres, o.include_intra_clique != 0, work);
+            rbk.ebeg = (int32_t)g->rb_edges.size();
+            rbk.ne = (int32_t)work.size();
+            g->rb_edges.insert(g->rb_edges.end(), work.begin(), work.end());
             reg(B);
             g->rb.push_back(std::move(rbk));
             consec = 0;
@@ -697,7 +711,8 @@ static void schedule_round(spg_graph *g) {
                     for (int32_t so : seen_owner) seen |= (so == oid);
                     if (seen) continue;
                     seen_owner.push_back(oid);
-                    for (int32_t y : g->Dsets[oid]) {
+                    for (int32_t yi = g->Dspan[oid].first; yi < g->Dspan[oid].first + g->Dspan[oid].second; yi++) {
+                        int32_t y = g->Dpool[yi];
                         bool fresh = g->vstamp[y] != st;
                         addv(y);
                         // Dense: a newly reachable removable vertex is itself absorbed and brings its neighbourhood
@@ -767,8 +782,8 @@ extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
     double total = 0;
     for (int b = 0; b < B; b++) {
         RoundBlanket &r = g->rb[b];
-        double nn = (double)d * (r.verts.size() - r.n_remove);
-        cost[b] = nn * nn * nn + (double)r.edges.size() * d * d * d + 1.0;
+        double nn = (double)d * (r.nv - r.n_remove);
+        cost[b] = nn * nn * nn + (double)r.ne * d * d * d + 1.0;
         total += cost[b];
     }
     std::vector<int> first(nr + 1, B);
@@ -795,17 +810,20 @@ extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
         for (int b = first[q]; b < first[q + 1]; b++) {
             RoundBlanket &r = g->rb[b];
             r.rank = q;
-            int k = (int)r.verts.size() - r.n_remove;
+            int k = r.nv - r.n_remove;
+            const int32_t *rverts = g->rb_verts.data() + r.vbeg;
+            const int32_t *redges = g->rb_edges.data() + r.ebeg;
             spg_blanket_desc &bd = g->h_blk[b];
             memset(&bd, 0, sizeof bd);
             bd.vert_begin = (int32_t)g->h_vpo.size();
-            bd.n_vert = (int32_t)r.verts.size();
+            bd.n_vert = r.nv;
             bd.n_remove = r.n_remove;
-            for (size_t i = 0; i < r.verts.size(); i++) { g->h_vpo.push_back(g->vpose[r.verts[i]]); lidx[r.verts[i]] = (int32_t)i; }
+            for (int i = 0; i < r.nv; i++) { g->h_vpo.push_back(g->vpose[rverts[i]]); lidx[rverts[i]] = (int32_t)i; }
             bd.edge_begin = (int32_t)g->h_er.size();
-            bd.n_edge = (int32_t)r.edges.size();
+            bd.n_edge = r.ne;
             int32_t scratch = 0;
-            for (int32_t eid : r.edges) {
+            for (int ei_ = 0; ei_ < r.ne; ei_++) {
+                int32_t eid = redges[ei_];
                 const GEdge &e = g->edges[eid];
                 if (e.kind == SPG_EDGE_GLC) scratch = std::max(scratch, e.len - d * e.nv + e.nv * 2 * d * d);
                 spg_edge_ref er;
@@ -907,17 +925,21 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
         else { g->stale_lo = std::min(g->stale_lo, lo); g->stale_hi = std::max(g->stale_hi, hi); }
     }
     // updateInputGraph (src/vertex_remover.cpp:500-546), in list order
+    std::vector<int32_t> vix;
     for (size_t b = 0; b < g->rb.size(); b++) {
         RoundBlanket &r = g->rb[b];
         const spg_blanket_desc &bd = r.desc;
         const double *rec = g->host.data() + bd.out_off;
         int status = (int)rec[0], inf = (int)rec[1], n_new = (int)rec[4];
         g->log.push_back({g->vid[r.root], g->round_no, status, inf, rec[2], rec[3]});
-        g->stats.max_blanket = std::max(g->stats.max_blanket, (int32_t)r.verts.size());
+        g->stats.max_blanket = std::max(g->stats.max_blanket, r.nv);
+        const int32_t *rverts = g->rb_verts.data() + r.vbeg;
+        const int32_t *redges = g->rb_edges.data() + r.ebeg;
         bool fine = (status == SPG_OK || status == SPG_ST_KLD_NOT_PD);
         if (!fine) { g->stats.n_bad_status++; continue; }
         if (std::isfinite(rec[2])) g->stats.kld_sum += rec[2];
-        for (int32_t eid : r.edges) {
+        for (int ei_ = 0; ei_ < r.ne; ei_++) {
+            int32_t eid = redges[ei_];
             GEdge &e = g->edges[eid];
             e.alive = 0;
             g->n_live_e--;
@@ -927,7 +949,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
             }
         }
         for (int i = 0; i < r.n_remove; i++) {
-            int32_t v = r.verts[i];
+            int32_t v = rverts[i];
             g->valive[v] = 0;
             g->adj[v].clear();
             g->n_live_v--;
@@ -939,8 +961,8 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
             int64_t rel = (int64_t)rec[SPG_OUT_HDR + 4 * e + 1];
             int32_t len = (int32_t)rec[SPG_OUT_HDR + 4 * e + 2];
             int nv = (int)rec[SPG_OUT_HDR + 4 * e + 3];
-            std::vector<int32_t> vix(nv);
-            for (int i = 0; i < nv; i++) vix[i] = r.verts[(int)rec[SPG_OUT_HDR + 4 * bd.n_new_max + vpos + i]];
+            vix.resize(nv);
+            for (int i = 0; i < nv; i++) vix[i] = rverts[(int)rec[SPG_OUT_HDR + 4 * bd.n_new_max + vpos + i]];
             vpos += nv;
             add_edge_idx(g, kind, nv, vix.data(), bd.new_off + rel, len);
             g->stats.n_new_edges++;

@@ -35,7 +35,7 @@ using namespace spgdev;
 
 namespace {
 
-constexpr int EC = 4;  // edges whose Jacobians are staged per chunk
+constexpr int EC = 8;  // edges whose Jacobians are staged per chunk
 
 // LDS / workspace carve-up for one blanket (all offsets in doubles). Monotone in k and m, so the
 // layout of the largest blanket of a launch bounds every blanket in it.
@@ -44,7 +44,7 @@ struct Layout {
     int o_pose, o_red, o_cs, o_ev, o_S, o_w, o_ldb, o_Lb, o_nJ, o_X, o_eJ, o_eO, o_eT, o_Ng, o_tre, o_int, small_doubles;
     int o_M1, o_M2, o_M3, o_Hmm, o_Hmk, mat_doubles;
     // int area offsets (in ints, relative to o_int)
-    int i_perm, i_keep, i_sorted, i_comp, i_pairs, i_ev, i_misc, int_count;
+    int i_perm, i_keep, i_sorted, i_pij, i_comp, i_pairs, i_ev, i_misc, int_count;
     // GLC tail: CNT problems of size S (tree: k-1 of 2d; dense / k==1: one of n), see glc section
     int gS, gCNT, gld, gstride;
     int o_gmeas, o_gev, o_gcs, o_gscr;          // small (LDS)
@@ -76,7 +76,7 @@ __host__ __device__ inline Layout make_layout(int D, int nt, int k, int m, int a
     L.o_X = o; o += L.NE * DD;
     L.o_eJ = o; o += EC * 2 * DD;
     L.o_eO = o; o += EC * DD;
-    L.o_eT = o; o += 2 * DD;
+    L.o_eT = o; o += EC * 2 * DD;
     L.o_Ng = o; o += L.n * D;
     L.o_tre = o; o += L.NE;
     L.gS = single ? (k > 0 ? D * k : D) : 2 * D;
@@ -92,6 +92,7 @@ __host__ __device__ inline Layout make_layout(int D, int nt, int k, int m, int a
     L.i_perm = io; io += L.n;
     L.i_keep = io; io += L.n;
     L.i_sorted = io; io += (L.P > 0 ? L.P : 1);
+    L.i_pij = io; io += 2 * (L.P > 0 ? L.P : 1);
     L.i_comp = io; io += k + 1;
     L.i_pairs = io; io += 2 * L.NE;
     L.i_ev = io; io += 2 * EC;
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     double *eJ = smem + L.o_eJ, *eO = smem + L.o_eO, *eT = smem + L.o_eT;
     int *ints = reinterpret_cast<int *>(smem + L.o_int);
     int *perm = ints + L.i_perm, *keep = ints + L.i_keep, *sorted = ints + L.i_sorted, *comp = ints + L.i_comp;
-    int *pairs = ints + L.i_pairs, *echv = ints + L.i_ev, *misc = ints + L.i_misc;
+    int *pairs = ints + L.i_pairs, *echv = ints + L.i_ev, *misc = ints + L.i_misc, *pij = ints + L.i_pij;
     double *M1 = mat + L.o_M1, *M2 = mat + L.o_M2, *M3 = mat + L.o_M3, *Hmm = mat + L.o_Hmm, *Hmk = mat + L.o_Hmk;
     Team<NT> T{tid, smem + L.o_red, misc + 0};
     // register-resident single-wavefront SPD kernels (spg_dev_wave.hpp) when the tile fits
@@ -241,23 +242,25 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             eO[it] = (er.kind == SPG_EDGE_BINARY) ? arena[er.off + PS + utri(lo, hi, D)] : 0.0;
         }
         T.sync();
+        // T_e = Omega_e [Ji | Jj] for every staged edge at once
+        for (int it = tid; it < cnt * 2 * DD; it += NT) {
+            int e = it / (2 * DD), rem = it - e * 2 * DD, wch = rem / DD, rc = rem - wch * DD, r = rc / D, c = rc - r * D;
+            const double *J = eJ + e * 2 * DD + wch * DD, *Om = eO + e * DD;
+            double s = 0;
+#pragma unroll
+            for (int p = 0; p < D; p++) s += Om[r * D + p] * J[p * D + c];
+            eT[it] = s;
+        }
+        T.sync();
+        // accumulate edge by edge (blocks of different edges overlap on the shared vertices)
         for (int e = 0; e < cnt; e++) {
             if (echv[2 * e] < 0) continue;
-            const double *Ji = eJ + e * 2 * DD, *Jj = Ji + DD, *Om = eO + e * DD;
-            for (int it = tid; it < 2 * DD; it += NT) {
-                int wch = it / DD, rc = it - wch * DD, r = rc / D, c = rc - r * D;
-                const double *J = wch ? Jj : Ji;
-                double s = 0;
-#pragma unroll
-                for (int p = 0; p < D; p++) s += Om[r * D + p] * J[p * D + c];
-                eT[it] = s;
-            }
-            T.sync();
+            const double *Ji = eJ + e * 2 * DD, *Jj = Ji + DD, *Te = eT + e * 2 * DD;
             int vi = echv[2 * e], vj = echv[2 * e + 1];
             for (int it = tid; it < 3 * DD; it += NT) {
                 int blk = it / DD, rc = it - blk * DD, r = rc / D, c = rc - r * D;
                 const double *Ja = (blk == 2) ? Jj : Ji;
-                const double *Tb = (blk == 0) ? eT : eT + DD;
+                const double *Tb = (blk == 0) ? Te : Te + DD;
                 double s = 0;
 #pragma unroll
                 for (int p = 0; p < D; p++) s += Ja[p * D + r] * Tb[p * D + c];
@@ -323,17 +326,47 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     if (stop_after == 1) { finish(); return; }
 
     // ---------------------------------------------------------------- Schur complement (a7)
-    chol_lower<NT>(T, Hmm, nm, ldm);
-    if (misc[0]) { status = SPG_ST_HMM_NOT_PD; finish(); return; }
-    tri_solve_lower<NT>(T, Hmm, nm, ldm, Hmk, n, ld);
+    if (m == 1) {
+        // H_mm is a single d x d block: one lane inverts it in registers (LLT(H_mm).solve, :444-447),
+        // then Lambda_t = H_kk - H_mk^T (H_mm^-1 H_mk) as two small products
+        if (tid == 0) {
+            double Ab[DD], Xr[DD];
+#pragma unroll
+            for (int i = 0; i < D; i++)
+#pragma unroll
+                for (int j = 0; j < D; j++) Ab[i * D + j] = Hmm[i * ldm + j];
+            if (!chol_reg<D>(Ab)) misc[0] = 1;
+            chol_inverse_reg<D>(Ab, Xr);
+#pragma unroll
+            for (int i = 0; i < D; i++)
+#pragma unroll
+                for (int j = 0; j < D; j++) Hmm[i * ldm + j] = Xr[i * D + j];
+        }
+        T.sync();
+        if (misc[0]) { status = SPG_ST_HMM_NOT_PD; finish(); return; }
+        // Y = H_mm^-1 H_mk into M2 rows 0..D-1 (M2 is free until Chow-Liu)
+        for (int it = tid; it < D * n; it += NT) {
+            int r = it / n, c = it - r * n;
+            double s = 0;
+#pragma unroll
+            for (int p = 0; p < D; p++) s += Hmm[r * ldm + p] * Hmk[p * ld + c];
+            M2[r * ld + c] = s;
+        }
+        T.sync();
+    } else {
+        chol_lower<NT>(T, Hmm, nm, ldm);
+        if (misc[0]) { status = SPG_ST_HMM_NOT_PD; finish(); return; }
+        tri_solve_lower<NT>(T, Hmm, nm, ldm, Hmk, n, ld);
+    }
     {
         int sh = ceil_log2(n), tot = n << sh;
         double bad = 0;
+        const double *Yl = (m == 1) ? M2 : Hmk;   // m == 1: Hmk^T (Hmm^-1 Hmk) ; else (L^-1 Hmk)^T (L^-1 Hmk)
         for (int it = tid; it < tot; it += NT) {
             int i = it >> sh, j = it & ((1 << sh) - 1);
             if (j < n) {
                 double s = 0;
-                for (int p = 0; p < nm; p++) s += Hmk[p * ld + i] * Hmk[p * ld + j];
+                for (int p = 0; p < nm; p++) s += Hmk[p * ld + i] * Yl[p * ld + j];
                 double v = M1[i * ld + j] - s;
                 M1[i * ld + j] = v;
                 if (!isfinite(v)) bad = 1;
@@ -398,6 +431,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             int i = 0, rem = p;
             while (rem >= k - 1 - i) { rem -= k - 1 - i; i++; }
             int j = i + 1 + rem;
+            pij[2 * p] = i; pij[2 * p + 1] = j;
             const double *Li = Lb + i * DD;
             double Y[DD];
 #pragma unroll
@@ -439,9 +473,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             // accepted edges first; rejected ones are only needed when ne > k-1, which has no closed form
             for (int s = 0; s < L.P && nacc < k - 1; s++) {
                 int p = sorted[s];
-                int i = 0, rem = p;
-                while (rem >= k - 1 - i) { rem -= k - 1 - i; i++; }
-                int j = i + 1 + rem;
+                int i = pij[2 * p], j = pij[2 * p + 1];
                 int ci = comp[i], cj = comp[j];
                 if (ci != cj) {
                     pairs[2 * nacc] = i; pairs[2 * nacc + 1] = j;
@@ -455,7 +487,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             for (int s = 0; s < upto; s++) {
                 double x = -w[sorted[s]], y = -w[sorted[s + 1]];
                 double den = fmax(fmax(fabs(x), fabs(y)), 1e-300);
-                g = fmin(g, (x - y) / den);
+                g = fmin(g, (x - y) * fast_rcp(den));
             }
             cs[0] = g;
         }
