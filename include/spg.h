@@ -206,9 +206,16 @@ typedef struct {
     int32_t my_first, my_count; /* this rank's slice */
     int64_t region_off;       /* arena offset (doubles) of the round's output region */
     int64_t chunk_len;        /* doubles per rank chunk; region = nranks * chunk_len, rank r owns chunk r */
+    int32_t exchange;         /* 1: blankets are sharded, the caller must all-gather the region before commit;
+                                 0: the round is small (latency-bound), every rank computes all of it redundantly
+                                    (bit-identical: no atomics, fixed reduction orders) and nothing is exchanged */
+    int32_t pad_;
 } spg_round_info;
 int spg_graph_marginalize_begin(spg_graph *g, const int32_t *which, int n, const spg_options *opts,
                                 int rank, int nranks);
+/* rounds with fewer blankets than this are computed redundantly on every rank instead of being
+ * sharded + exchanged (default 2048; 0 = always shard) */
+int spg_graph_set_shard_threshold(spg_graph *g, int min_blankets);
 /* returns 1 if a round was prepared (info filled), 0 when the removal list is exhausted */
 int spg_graph_round_prepare(spg_graph *g, spg_round_info *info);
 int spg_graph_round_compute(spg_graph *g);   /* asynchronous on the context stream */

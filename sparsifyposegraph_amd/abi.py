@@ -63,7 +63,7 @@ class MargStats(C.Structure):
 
 class RoundInfo(C.Structure):
     _fields_ = [("n_blankets", C.c_int32), ("my_first", C.c_int32), ("my_count", C.c_int32),
-                ("region_off", C.c_int64), ("chunk_len", C.c_int64)]
+                ("region_off", C.c_int64), ("chunk_len", C.c_int64), ("exchange", C.c_int32), ("pad_", C.c_int32)]
 
 
 class BlanketDesc(C.Structure):

@@ -122,6 +122,8 @@ struct spg_graph {
     spg_round_info rinfo{};
     bool round_open = false;
     bool used_mailbox = false;
+    int shard_threshold = 2048;
+    int eff_ranks = 1, eff_rank = 0;   // ranks the current round is split over (1 = replicated round)
     int round_no = 0;
     spg_marg_stats stats{};
     std::vector<BlanketLog> log;
@@ -768,6 +770,12 @@ extern "C" int spg_graph_marginalize_begin(spg_graph *g, const int32_t *which, i
     return 0;
 }
 
+extern "C" int spg_graph_set_shard_threshold(spg_graph *g, int min_blankets) {
+    if (!g || min_blankets < 0) return SPG_EINVAL;
+    g->shard_threshold = min_blankets;
+    return 0;
+}
+
 extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
     if (!g || !g->active || g->round_open) return SPG_ESTATE;
     double t0 = now_s();
@@ -776,7 +784,11 @@ extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
     int B = (int)g->rb.size();
     if (B == 0) { g->stats.host_seconds += now_s() - t0; return 0; }
     const spg_options &o = g->opts;
-    const int d = g->d, nr = g->nranks;
+    // small rounds are latency-bound: every rank computes them whole, nothing is exchanged
+    const bool sharded = g->nranks > 1 && B >= g->shard_threshold;
+    g->eff_ranks = sharded ? g->nranks : 1;
+    g->eff_rank = sharded ? g->rank : 0;
+    const int d = g->d, nr = g->eff_ranks;
     // ---- contiguous, cost-balanced slices (cost ~ n^3 + E d^3)
     std::vector<double> cost(B);
     double total = 0;
@@ -865,10 +877,12 @@ extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
     g->used = need;
     g->dev_synced = need;  // the region is produced on the device
     g->rinfo.n_blankets = B;
-    g->rinfo.my_first = first[g->rank];
-    g->rinfo.my_count = first[g->rank + 1] - first[g->rank];
+    g->rinfo.my_first = first[g->eff_rank];
+    g->rinfo.my_count = first[g->eff_rank + 1] - first[g->eff_rank];
     g->rinfo.region_off = region;
     g->rinfo.chunk_len = clen;
+    g->rinfo.exchange = sharded ? 1 : 0;
+    g->rinfo.pad_ = 0;
     if (info) *info = g->rinfo;
     g->round_open = true;
     g->round_no++;
@@ -892,8 +906,8 @@ extern "C" int spg_graph_round_compute(spg_graph *g) {
     rd.n_edge_total = (int64_t)g->h_er.size();
     rd.n_edge_vert_total = (int64_t)g->h_ev.size();
     // single rank: let the kernel deliver the out records straight into the backend's host mailbox
-    rd.mail_base = g->rinfo.region_off + g->rinfo.chunk_len * g->rank;
-    rd.mail_len = (g->nranks == 1 && g->ctx->be.mailbox) ? g->chunk_hdr[g->rank] : 0;
+    rd.mail_base = g->rinfo.region_off + g->rinfo.chunk_len * g->eff_rank;
+    rd.mail_len = (g->eff_ranks == 1 && g->ctx->be.mailbox) ? g->chunk_hdr[g->eff_rank] : 0;
     g->used_mailbox = rd.mail_len > 0;
     int rc = g->ctx->be.run_round(g->ctx->be.user, g->dev, &rd);
     g->stats.device_seconds += now_s() - t0;
@@ -904,7 +918,7 @@ extern "C" int spg_graph_round_compute(spg_graph *g) {
 extern "C" int spg_graph_round_commit(spg_graph *g) {
     if (!g || !g->active || !g->round_open) return SPG_ESTATE;
     double t0 = now_s();
-    const int nr = g->nranks;
+    const int nr = g->eff_ranks;
     int rc = g->ctx->be.synchronize(g->ctx->be.user);
     if (rc) return rc;
     // read back the out-record part of every rank chunk (mailbox: already in host memory)
@@ -912,7 +926,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
     for (int q = 0; q < nr; q++) {
         if (g->chunk_hdr[q] == 0) continue;
         int64_t base = g->rinfo.region_off + g->rinfo.chunk_len * q;
-        if (mail && q == g->rank) { memcpy(g->host.data() + base, mail, (size_t)g->chunk_hdr[q] * 8); continue; }
+        if (mail && q == g->eff_rank) { memcpy(g->host.data() + base, mail, (size_t)g->chunk_hdr[q] * 8); continue; }
         rc = g->ctx->be.download(g->ctx->be.user, g->host.data() + base, (char *)g->dev + base * 8, g->chunk_hdr[q]);
         if (rc) return rc;
     }

@@ -144,6 +144,9 @@ class GraphWrapperHIP:
         self._opts = opts
         check(self.L.spg_graph_marginalize_begin(self.h, _p(which, C.c_int32), len(which), C.byref(opts), rank, nranks), self.ctx.h, "marginalize_begin")
 
+    def set_shard_threshold(self, min_blankets):
+        check(self.L.spg_graph_set_shard_threshold(self.h, int(min_blankets)), self.ctx.h, "set_shard_threshold")
+
     def round_prepare(self):
         info = abi.RoundInfo()
         rc = check(self.L.spg_graph_round_prepare(self.h, C.byref(info)), self.ctx.h, "round_prepare")

@@ -50,6 +50,7 @@ SYMBOLS = {
     "spg_graph_last_blanket_count": (C.c_int, [C.c_void_p]),
     "spg_graph_last_blankets": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _f64p, _f64p]),
     "spg_graph_marginalize_begin": (C.c_int, [C.c_void_p, _i32p, C.c_int, C.POINTER(abi.Options), C.c_int, C.c_int]),
+    "spg_graph_set_shard_threshold": (C.c_int, [C.c_void_p, C.c_int]),
     "spg_graph_round_prepare": (C.c_int, [C.c_void_p, C.POINTER(abi.RoundInfo)]),
     "spg_graph_round_compute": (C.c_int, [C.c_void_p]),
     "spg_graph_round_commit": (C.c_int, [C.c_void_p]),
@@ -74,6 +75,14 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+        # One HIP runtime per process: torch wheels bundle their own libamdhip64.so.7 (same SONAME as
+        # /opt/rocm's). Whichever copy is loaded first serves both, and torch does not find its GPUs
+        # on the system copy — so in a process that also uses torch (bench.py, parallel.py: RCCL and
+        # device synchronisation) torch must be loaded before libspg_hip.so.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # raises AttributeError if the export is missing

@@ -7,6 +7,10 @@ a rank computed for its slice: the recovered edge records and the per-blanket ou
 live in a rank-chunked region of the arena (`spg_round_info`: region = nranks * chunk_len, rank r
 owns chunk r), so the exchange is an in-place all-gather of equal-sized chunks — over RCCL/xGMI on
 the GPU box (`torch.distributed` backend "nccl"), over gloo in the CPU tests.
+
+Rounds that are too small to be worth an exchange (latency-bound: a few hundred blankets finish in
+one kernel latency however they are split) are computed redundantly by every rank instead
+(`spg_round_info.exchange == 0`); the kernels are bit-deterministic, so the replicas stay identical.
 """
 import ctypes as C
 
@@ -51,7 +55,7 @@ def marginalize_sharded(graph, which, opts, device=None, group=None):
             if info is None:
                 break
             graph.round_compute()
-            if ws > 1:
+            if ws > 1 and info.exchange:
                 ptr, _ = graph.arena()
                 if ptr != view_ptr:  # the arena may be re-allocated while a round is prepared
                     view, view_ptr = arena_tensor(graph, device), ptr

@@ -152,3 +152,52 @@ def test_synthetic_properties(hip_ctx):
     assert (bl["kld"][np.isfinite(bl["kld"])] > -1e-9).all()
     assert hg.numVertices() == 6000 - len(which)
     assert hg.numEdges() >= hg.numVertices() - 1
+
+
+def test_arena_tensor_and_inplace_allgather_on_device(hip_ctx):
+    """The multi-GPU exchange path on real hardware, as far as one GPU allows: the zero-copy torch view
+    of the device arena (CUDA array interface) really aliases it, and an in-place RCCL
+    all_gather_into_tensor on a round's region (world_size 1) leaves a graph identical to the oracle's."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from sparsifyposegraph_amd.parallel import arena_tensor
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = False
+    if not dist.is_initialized():
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        g = g2o_io.synth_sphere(n_poses=600, ring=30)
+        which = np.array([i for i in range(4, 600) if i % 2], np.int32)
+        opts = abi.make_options(6)
+        hg = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+        hg.reserve(4_000_000)
+        view = arena_tensor(hg, "cuda:0")
+        assert np.array_equal(view[:600 * 7].cpu().numpy(), g["poses"].ravel())
+        hg.begin(which, opts, 0, 1)
+        rounds = 0
+        while True:
+            info = hg.round_prepare()
+            if info is None:
+                break
+            hg.round_compute()
+            hip_ctx.synchronize()
+            ptr, _ = hg.arena()
+            assert ptr == view.data_ptr()
+            region = view[info.region_off:info.region_off + info.chunk_len]
+            dist.all_gather_into_tensor(region, region[:info.chunk_len])
+            torch.cuda.synchronize()
+            hg.round_commit()
+            rounds += 1
+        st = hg.end()
+        og = oracle_lib.OracleGraph.from_dict(g)
+        assert og.marginalize(which, opts) == 0
+        util.compare_edge_sets(6, og.edges(), hg.edges())
+        assert st["n_removed"] == len(which) and rounds == st["n_rounds"]
+    finally:
+        if created:
+            dist.destroy_process_group()
