@@ -625,11 +625,54 @@ inline void run_glc(const spg_options &o, const BlanketIn &in, BlanketOut &out) 
     }
 }
 
+// buildSubgraph, Local linearisation point (src/vertex_remover.cpp:304-381): a closed-form estimate
+// exists iff every vertex other than the first removed one appears in exactly one blanket edge and
+// every edge can propagate an estimate (pose-pose edges can, GLC edges cannot:
+// src/glc_edge.cpp:58-63). The removed vertex is placed at the origin and every neighbour is set from
+// its edge's measurement (g2o EdgeSE2/EdgeSE3::initialEstimate: to = from * z, or from = to * z^-1).
+inline bool local_linearization_point(const BlanketIn &in, std::vector<double> &pose) {
+    int ps = pose_stride(in.d);
+    std::vector<int> cnt(in.nv, 0);
+    for (const EdgeIn &e : in.edges) {
+        if (e.kind != SPG_EDGE_BINARY) return false;
+        for (int v : e.v) if (v != 0) cnt[v]++;
+    }
+    for (int v = 1; v < in.nv; v++) if (cnt[v] > 1) return false;
+    pose.assign(in.pose, in.pose + (size_t)in.nv * ps);
+    if (in.d == 3) { pose[0] = pose[1] = pose[2] = 0; }
+    else { double I7[7] = {0, 0, 0, 0, 0, 0, 1}; std::memcpy(pose.data(), I7, sizeof I7); }
+    for (const EdgeIn &e : in.edges) {
+        int vi = e.v[0], vj = e.v[1];
+        if (vi == 0 && vj == 0) continue;
+        if (in.d == 3) {
+            if (vi == 0) se2_compose(&pose[0], e.data, &pose[(size_t)vj * ps]);
+            else { double zi[3]; se2_inverse(e.data, zi); se2_compose(&pose[(size_t)vj * ps], zi, &pose[(size_t)vi * ps]); }
+        } else {
+            Iso3 Z = iso_from_tq(e.data);
+            if (vi == 0) iso_to_tq(iso_mul(iso_from_tq(&pose[0]), Z), &pose[(size_t)vj * ps]);
+            else iso_to_tq(iso_mul(iso_from_tq(&pose[(size_t)vj * ps]), iso_inv(Z)), &pose[(size_t)vi * ps]);
+        }
+    }
+    return true;
+}
+
+inline BlanketOut run_blanket_at(const spg_options &o, const BlanketIn &in);
+
 // One iteration of VertexRemover::remove (src/vertex_remover.cpp:108-132) on a gathered blanket.
 inline BlanketOut run_blanket(const spg_options &o, const BlanketIn &in) {
     BlanketOut out;
     if (in.edges.empty() || in.m < 1) { out.status = SPG_ST_EMPTY_BLANKET; return out; }
-    if (o.lin_point != SPG_LIN_GLOBAL) { out.status = SPG_ST_UNSUPPORTED; return out; }
+    BlanketIn local = in;
+    std::vector<double> local_pose;
+    if (o.lin_point != SPG_LIN_GLOBAL) {
+        if (!local_linearization_point(in, local_pose)) { out.status = SPG_ST_NEEDS_LOCAL_OPTIMIZATION; return out; }
+        local.pose = local_pose.data();
+    }
+    return run_blanket_at(o, local);
+}
+
+inline BlanketOut run_blanket_at(const spg_options &o, const BlanketIn &in) {
+    BlanketOut out;
     if (o.algorithm == SPG_ALG_NFR)  // binary providers reject GLC edges (src/topology_provider_base.h:23-27)
         for (const EdgeIn &e : in.edges) if (e.kind != SPG_EDGE_BINARY) { out.status = SPG_ST_UNSUPPORTED; return out; }
     Mat H = assemble_hessian(in);

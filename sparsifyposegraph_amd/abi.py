@@ -14,7 +14,8 @@ TOPO_TREE, TOPO_SUBGRAPH, TOPO_CLIQUEY_SUBGRAPH, TOPO_DENSE, TOPO_CLIQUEY_DENSE 
 LIN_LOCAL, LIN_GLOBAL = 0, 1
 EDGE_BINARY, EDGE_GLC = 0, 1
 ST_OK, ST_HMM_NOT_PD, ST_EIG_FAIL, ST_NONFINITE, ST_TIKHONOV_NOT_PD, ST_CLOSED_FORM_NOT_PD, \
-    ST_KLD_NOT_PD, ST_NEEDS_INTERIOR_POINT, ST_MARGINAL_NOT_PD, ST_EMPTY_BLANKET, ST_UNSUPPORTED = range(11)
+    ST_KLD_NOT_PD, ST_NEEDS_INTERIOR_POINT, ST_MARGINAL_NOT_PD, ST_EMPTY_BLANKET, ST_UNSUPPORTED, \
+    ST_NEEDS_LOCAL_OPTIMIZATION = range(12)
 INFO_RANK_DEFICIENT, INFO_GLC_ROOT_EDGE = 1, 2
 FLAG_GLC_KLD = 1
 FLAG_FORCE_EIG = 2

@@ -125,7 +125,7 @@ struct KArgs {
     const int32_t *list;
     double *gws;
     int64_t gws_stride;
-    int topology, algorithm, flags;
+    int topology, algorithm, flags, lin_point;
     double chord_ratio;
     double *mail;        // pinned host mailbox for out records (or nullptr)
     int64_t mail_base;   // arena offset that maps to mail[0]
@@ -205,6 +205,55 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         finish(); return;
     }
 
+    if (a.lin_point != SPG_LIN_GLOBAL) {
+        // Local linearisation point, closed-form branch of buildSubgraph (src/vertex_remover.cpp:304-381):
+        // possible iff every vertex but the first removed one sits in exactly one (pose-pose) blanket edge;
+        // then the removed vertex goes to the origin and each neighbour to z (or z^-1) of its edge.
+        if (is_glc) { status = SPG_ST_UNSUPPORTED; finish(); return; }  // src/topology_provider_glc.cpp:110-111
+        int *cntv = perm;  // n >= nv ints whenever k >= 1 (D >= 3); k == 0 has no kept vertex to place
+        for (int v = tid; v < nv; v += NT) cntv[v] = 0;
+        T.sync();
+        for (int e = tid; e < bd.n_edge; e += NT) {
+            const spg_edge_ref er = a.er[bd.edge_begin + e];
+            if (er.kind != SPG_EDGE_BINARY) { misc[1] = 1; continue; }
+            int vi = a.ev[er.vbegin], vj = a.ev[er.vbegin + 1];
+            if (vi != 0) atomicAdd(&cntv[vi], 1);
+            if (vj != 0) atomicAdd(&cntv[vj], 1);
+        }
+        T.sync();
+        for (int v = 1 + tid; v < nv; v += NT) if (cntv[v] > 1) misc[1] = 1;
+        T.sync();
+        if (misc[1] || n < nv) { status = SPG_ST_NEEDS_LOCAL_OPTIMIZATION; finish(); return; }
+        if (tid == 0) {
+            if (D == 6) { double I12[kIso] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}; for (int t_ = 0; t_ < kIso; t_++) pose[t_] = I12[t_]; }
+            else { pose[0] = 0; pose[1] = 0; pose[2] = 0; }
+        }
+        for (int e = tid; e < bd.n_edge; e += NT) {
+            const spg_edge_ref er = a.er[bd.edge_begin + e];
+            int vi = a.ev[er.vbegin], vj = a.ev[er.vbegin + 1];
+            const double *rec = arena + er.off;
+            if (vi == 0 && vj == 0) continue;
+            if (D == 6) {
+                double Z[kIso];
+                iso_from_tq(rec, Z);
+                if (vi == 0) { for (int t_ = 0; t_ < kIso; t_++) pose[vj * PSZ + t_] = Z[t_]; }
+                else {
+                    double I12[kIso] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, Zi[kIso];
+                    iso_inv_mul(Z, I12, Zi);
+                    for (int t_ = 0; t_ < kIso; t_++) pose[vi * PSZ + t_] = Zi[t_];
+                }
+            } else {
+                if (vi == 0) { pose[vj * PSZ] = rec[0]; pose[vj * PSZ + 1] = rec[1]; pose[vj * PSZ + 2] = normalize_theta(rec[2]); }
+                else {
+                    double c = cos(rec[2]), sn = sin(rec[2]);
+                    pose[vi * PSZ] = -(c * rec[0] + sn * rec[1]);
+                    pose[vi * PSZ + 1] = -(-sn * rec[0] + c * rec[1]);
+                    pose[vi * PSZ + 2] = normalize_theta(-rec[2]);
+                }
+            }
+        }
+        T.sync();
+    }
     // ---------------------------------------------------------------- assemble H (a6)
     auto hadd = [&](int R, int Cc, double val) {
         if (R < nm) {
@@ -1140,7 +1189,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     ka.mail = mail_dev;
     ka.mail_base = rd->mail_base;
     ka.gws = nullptr; ka.gws_stride = 0;
-    ka.topology = o.topology; ka.algorithm = o.algorithm; ka.flags = o.flags; ka.chord_ratio = o.chord_ratio;
+    ka.topology = o.topology; ka.algorithm = o.algorithm; ka.flags = o.flags; ka.chord_ratio = o.chord_ratio; ka.lin_point = o.lin_point;
     size_t list_off = 0;
     for (int i = 0; i < NB; i++) {
         int nb = (int)bins[i].list.size();

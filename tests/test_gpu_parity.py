@@ -129,6 +129,27 @@ def test_glc_graph_matches_golden(case, hip_ctx):
     print(f"{case}: rounds={st['n_rounds']} worst_rel={worst:.2e}")
 
 
+@pytest.mark.parametrize("case", ["sphere_nfr_tree", "manhattan_nfr_tree"])
+def test_local_linearization_point_matches_oracle(case, hip_ctx, oracle):
+    """{Local, Tree} (the reference's default linPoint, src/sparsity_options.h:26): closed-form local
+    estimates on star blankets, SPG_ST_NEEDS_LOCAL_OPTIMIZATION where the reference would run LM."""
+    g, which, opts, _, _, _ = util.load_golden(case)
+    lopts = abi.make_options(opts.pose_dim, abi.ALG_NFR, abi.TOPO_TREE, abi.LIN_LOCAL)
+    batch, roots = util.first_round_batch(g, which, lopts)
+    ref = abi.marginalize_batch(oracle, None, lopts, batch)
+    got = hip_ctx.marginalize_batch(lopts, batch)
+    assert np.array_equal(ref["status"], got["status"])
+    assert (ref["status"] == 0).sum() > 10
+    assert np.array_equal(ref["new_edge_off"], got["new_edge_off"])
+    assert np.array_equal(ref["new_edge_vert"], got["new_edge_vert"])
+    assert util.rel_err(ref["new_edge_data"], got["new_edge_data"]) <= util.RTOL
+    fin = np.isfinite(ref["kld"])
+    assert np.max(np.abs(ref["kld"][fin] - got["kld"][fin]) / np.maximum(np.abs(ref["kld"][fin]), 1.0)) <= 1e-9
+    glob = hip_ctx.marginalize_batch(abi.make_options(opts.pose_dim), batch)
+    if len(glob["new_edge_data"]) == len(got["new_edge_data"]):  # (blankets needing LM emit no edges under Local)
+        assert util.rel_err(glob["new_edge_data"], got["new_edge_data"]) > 1e-6  # it really is a different point
+
+
 def test_synthetic_properties(hip_ctx):
     """Size-independent properties on a synthetic SE3 graph the oracle would need minutes for at full
     size: every recovered information is symmetric PD, KLD >= 0, the graph stays connected with

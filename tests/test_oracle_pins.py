@@ -274,3 +274,45 @@ def test_known_glc_edge_from_reference_comment(oracle):
     G = W.T @ W
     assert np.abs(G[:3, :]).max() < 1e-10  # gauge: nothing on the absolute first block
     assert np.linalg.matrix_rank(G[3:, 3:], tol=1e-12) == 3
+
+
+def test_local_linearization_point_chain(oracle):
+    """src/test_marginalize_se3.cpp:20-48 with fixed numbers: 3-pose SE3 chain, middle pose removed,
+    {Local, Tree}. Closed-form local estimate: the removed pose at the origin, neighbours at z^-1 / z,
+    so the new edge's measurement is exactly z01 * z12 and (k = 2) the KLD is 0."""
+    def q(v):
+        v = np.asarray(v, float)
+        return v / np.linalg.norm(v)
+    z01 = np.concatenate([[0.10, 0.11, 0.12], q([0.05, 0.04, 0.06, 0.99])])
+    z12 = np.concatenate([[0.09, 0.13, 0.08], q([0.03, 0.06, 0.02, 0.99])])
+    x0 = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    x1 = np.concatenate([[0.3, -0.2, 0.1], q([0.1, 0.0, 0.2, 0.97])])   # far from z01: Local must ignore it
+    x2 = np.concatenate([[0.7, 0.1, 0.3], q([0.2, 0.1, 0.1, 0.96])])
+    info = np.eye(6)[np.triu_indices(6)]
+    batch = {"vert_off": np.array([0, 3], np.int32), "n_remove": np.array([1], np.int32), "vert_id": np.array([1, 0, 2], np.int32),
+             "pose": np.concatenate([x1, x0, x2]), "edge_off": np.array([0, 2], np.int32), "edge_kind": np.zeros(2, np.int32),
+             "edge_vert_off": np.array([0, 2, 4], np.int32), "edge_vert": np.array([1, 0, 0, 2], np.int32),
+             "edge_data_off": np.array([0, 28, 56], np.int64), "edge_data": np.concatenate([z01, info, z12, info])}
+    opts = abi.make_options(6, abi.ALG_NFR, abi.TOPO_TREE, abi.LIN_LOCAL)
+    out = abi.marginalize_batch(oracle, None, opts, batch)
+    assert out["status"][0] == 0 and list(out["new_edge_vert"]) == [0, 2]
+    z02 = np.zeros(7)
+    from sparsifyposegraph_amd.g2o_io import quat_mul, quat_rotate
+    t = z01[:3] + quat_rotate(z01[3:], z12[:3])
+    qq = quat_mul(z01[3:], z12[3:])
+    assert np.allclose(out["new_edge_data"][:3], t, atol=1e-14)
+    assert np.allclose(np.abs(out["new_edge_data"][3:7] @ qq), 1.0, atol=1e-14)
+    assert abs(out["kld"][0]) < 1e-9
+    # Global at the (inconsistent) stored estimates gives a different measurement
+    outg = abi.marginalize_batch(oracle, None, abi.make_options(6), batch)
+    assert not np.allclose(outg["new_edge_data"][:3], t, atol=1e-3)
+    # an extra edge between the two neighbours breaks the closed form: the reference would run LM
+    batch2 = dict(batch)
+    batch2["edge_off"] = np.array([0, 3], np.int32)
+    batch2["edge_kind"] = np.zeros(3, np.int32)
+    batch2["edge_vert_off"] = np.array([0, 2, 4, 6], np.int32)
+    batch2["edge_vert"] = np.array([1, 0, 0, 2, 1, 2], np.int32)
+    batch2["edge_data_off"] = np.array([0, 28, 56, 84], np.int64)
+    batch2["edge_data"] = np.concatenate([z01, info, z12, info, z12, info])
+    out2 = abi.marginalize_batch(oracle, None, opts, batch2)
+    assert out2["status"][0] == abi.ST_NEEDS_LOCAL_OPTIMIZATION
