@@ -199,6 +199,13 @@ int spg_graph_last_blanket_count(const spg_graph *g);
 int spg_graph_last_blankets(const spg_graph *g, int32_t *root_id, int32_t *round, int32_t *status,
                             int32_t *info, double *kld, double *min_gap);
 
+/* computeSubstituteEdge (src/compute_substitute_edge.cpp:13-96), host-side: for the online / cluster
+ * replay harness, when a new edge (*from,*to) points at an already marginalised vertex. g is the FULL
+ * source graph; marginalized = ids removed so far; maxid = newest vertex. On return the marginalised
+ * endpoint is replaced by the nearest surviving vertex, meas (3|7) and info_upper (6|21) are filled. */
+int spg_graph_substitute_edge(spg_graph *g, const int32_t *marginalized, int n_marg, int maxid,
+                              int *from, int *to, double *meas, double *info_upper);
+
 /* ---- round-stepping form of the same call, for multi-GPU sharding ---------------------------
  * All ranks hold a replica and run the same deterministic scheduler; rank r computes its slice of
  * each round's blankets; the caller exchanges the round's output region of the arena between

@@ -1133,3 +1133,161 @@ extern "C" int spg_marginalize_batch(spg_ctx *ctx, const spg_options *o, const s
     }
     return 0;
 }
+
+// ================================================================================= substitute edge
+// computeSubstituteEdge (src/compute_substitute_edge.cpp:13-96): online / cluster replay only. When a
+// new edge points at a vertex that was already marginalised, walk breadth-first (ids <= maxid, never
+// through vertex 0) to the nearest surviving vertex with the smallest id, compose the measurements
+// along the way back and add the covariances. Host-side: 3x3 / 6x6 arithmetic once per such edge.
+// Where the reference takes "the first edge of `reach` that touches the previous frontier" in g2o's
+// pointer order, this build takes the lowest edge index.
+namespace {
+struct HPose { double t[3]; double q[4]; double th; };  // SE3: t,q ; SE2: t[0..1], th
+
+void q_mul(const double *a, const double *b, double *o) {
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+void q_rot(const double *q, const double *v, double *o) {
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    double tx = 2 * (y * v[2] - z * v[1]), ty = 2 * (z * v[0] - x * v[2]), tz = 2 * (x * v[1] - y * v[0]);
+    o[0] = v[0] + w * tx + (y * tz - z * ty);
+    o[1] = v[1] + w * ty + (z * tx - x * tz);
+    o[2] = v[2] + w * tz + (x * ty - y * tx);
+}
+double wrap_theta(double th) {
+    const double PI = 3.14159265358979323846;
+    if (th >= -PI && th < PI) return th;
+    double m = std::fmod(th, 2 * PI);
+    if (m >= PI) m -= 2 * PI;
+    if (m < -PI) m += 2 * PI;
+    return m;
+}
+void pose_compose(int d, const double *a, const double *b, double *o) {  // o = a * b (o may alias neither)
+    if (d == 3) {
+        double c = std::cos(a[2]), s = std::sin(a[2]);
+        o[0] = a[0] + c * b[0] - s * b[1]; o[1] = a[1] + s * b[0] + c * b[1]; o[2] = wrap_theta(a[2] + b[2]);
+    } else {
+        double r[3];
+        q_rot(a + 3, b, r);
+        o[0] = a[0] + r[0]; o[1] = a[1] + r[1]; o[2] = a[2] + r[2];
+        q_mul(a + 3, b + 3, o + 3);
+        double n = std::sqrt(o[3] * o[3] + o[4] * o[4] + o[5] * o[5] + o[6] * o[6]);
+        for (int i = 3; i < 7; i++) o[i] /= n;
+    }
+}
+void pose_inverse(int d, const double *a, double *o) {
+    if (d == 3) {
+        double c = std::cos(a[2]), s = std::sin(a[2]);
+        o[0] = -(c * a[0] + s * a[1]); o[1] = -(-s * a[0] + c * a[1]); o[2] = wrap_theta(-a[2]);
+    } else {
+        double qi[4] = {-a[3], -a[4], -a[5], a[6]}, r[3];
+        q_rot(qi, a, r);
+        o[0] = -r[0]; o[1] = -r[1]; o[2] = -r[2];
+        o[3] = qi[0]; o[4] = qi[1]; o[5] = qi[2]; o[6] = qi[3];
+    }
+}
+bool dense_inverse(int n, std::vector<double> &A) {  // Gauss-Jordan, partial pivoting (Eigen .inverse())
+    std::vector<double> X((size_t)n * n, 0.0);
+    for (int i = 0; i < n; i++) X[(size_t)i * n + i] = 1.0;
+    for (int k = 0; k < n; k++) {
+        int p = k;
+        for (int i = k + 1; i < n; i++) if (std::fabs(A[(size_t)i * n + k]) > std::fabs(A[(size_t)p * n + k])) p = i;
+        if (A[(size_t)p * n + k] == 0.0) return false;
+        if (p != k) for (int j = 0; j < n; j++) { std::swap(A[(size_t)k * n + j], A[(size_t)p * n + j]); std::swap(X[(size_t)k * n + j], X[(size_t)p * n + j]); }
+        double ip = 1.0 / A[(size_t)k * n + k];
+        for (int j = 0; j < n; j++) { A[(size_t)k * n + j] *= ip; X[(size_t)k * n + j] *= ip; }
+        for (int i = 0; i < n; i++) {
+            if (i == k) continue;
+            double f = A[(size_t)i * n + k];
+            if (f == 0.0) continue;
+            for (int j = 0; j < n; j++) { A[(size_t)i * n + j] -= f * A[(size_t)k * n + j]; X[(size_t)i * n + j] -= f * X[(size_t)k * n + j]; }
+        }
+    }
+    A.swap(X);
+    return true;
+}
+}  // namespace
+
+extern "C" int spg_graph_substitute_edge(spg_graph *g, const int32_t *marginalized, int n_marg, int maxid,
+                                         int *from, int *to, double *meas, double *info_upper) {
+    if (!g || !from || !to || !meas || !info_upper || (n_marg > 0 && !marginalized)) return SPG_EINVAL;
+    if (int rc = sync_host(g)) return rc;
+    const int d = g->d, ps = g->ps;
+    std::set<int> marg(marginalized, marginalized + n_marg), visited;
+    std::vector<std::set<int>> frontiers;  // used as a deque: front = index 0
+    std::set<int> newFrontier;
+    const int NONE = 0x7fffffff;
+    int minid = NONE;
+    int toConnect = std::max(*from, *to), toReplace = std::min(*from, *to);
+    auto vix = [&](int id) -> int { auto it = g->vidx.find(id); return (it == g->vidx.end() || !g->valive[it->second]) ? -1 : it->second; };
+    if (vix(toConnect) < 0 || vix(toReplace) < 0) return set_err(g->ctx, SPG_EINVAL, "substitute edge endpoint does not exist");
+    newFrontier.insert(toReplace);
+    visited.insert(toConnect);
+    visited.insert(toReplace);
+    do {
+        if (newFrontier.empty()) return set_err(g->ctx, SPG_EINVAL, "no surviving vertex reachable");
+        frontiers.push_back(newFrontier);
+        newFrontier.clear();
+        for (int r : frontiers.back()) {
+            if (marg.count(r) == 0 && r != *from && r != *to) {
+                minid = std::min(minid, r);
+            } else {
+                int v = vix(r);
+                visited.insert(r);
+                if (v < 0) continue;
+                for (int32_t eid : g->adj[v]) {
+                    const GEdge &e = g->edges[eid];
+                    if (e.nv != 2) continue;
+                    int a = g->vid[g->everts[e.vbeg]], b = g->vid[g->everts[e.vbeg + 1]];
+                    int other = (a == r) ? b : a;
+                    if (visited.count(other) == 0 && other <= maxid && other != 0) newFrontier.insert(other);
+                }
+            }
+        }
+    } while (minid == NONE);
+    frontiers.insert(frontiers.begin(), std::set<int>{toConnect});
+    frontiers.pop_back();
+    std::vector<double> covsum((size_t)d * d, 0.0);
+    std::vector<double> m(ps, 0.0), tmp(ps), zi(ps);
+    if (d == 6) m[6] = 1.0;
+    int reach = minid;
+    while (!frontiers.empty()) {
+        std::set<int> last = frontiers.back();
+        frontiers.pop_back();
+        int v = vix(reach);
+        if (v < 0) return set_err(g->ctx, SPG_EINVAL, "substitute path broken");
+        std::vector<int32_t> es(g->adj[v].begin(), g->adj[v].end());
+        std::sort(es.begin(), es.end());
+        for (int32_t eid : es) {
+            const GEdge &e = g->edges[eid];
+            if (e.nv != 2 || e.kind != SPG_EDGE_BINARY) continue;
+            int a = g->vid[g->everts[e.vbeg]], b = g->vid[g->everts[e.vbeg + 1]];
+            if (!(last.count(a) || last.count(b))) continue;
+            const double *rec = g->host.data() + e.off;
+            std::vector<double> info((size_t)d * d);
+            int pidx = 0;
+            for (int i = 0; i < d; i++) for (int j = i; j < d; j++) { info[(size_t)i * d + j] = info[(size_t)j * d + i] = rec[ps + pidx]; pidx++; }
+            if (!dense_inverse(d, info)) return set_err(g->ctx, SPG_EINVAL, "singular edge information on the substitute path");
+            for (int i = 0; i < d * d; i++) covsum[i] += info[i];
+            if (*from == toConnect) {
+                if (b == reach) pose_compose(d, rec, m.data(), tmp.data());                       // meas = z * meas
+                else { pose_inverse(d, rec, zi.data()); pose_compose(d, zi.data(), m.data(), tmp.data()); }
+            } else {
+                if (b == reach) { pose_inverse(d, rec, zi.data()); pose_compose(d, m.data(), zi.data(), tmp.data()); }  // meas *= z^-1
+                else pose_compose(d, m.data(), rec, tmp.data());
+            }
+            m = tmp;
+            reach = (b == reach) ? a : b;
+            break;
+        }
+    }
+    if (!dense_inverse(d, covsum)) return set_err(g->ctx, SPG_EINVAL, "singular covariance sum");
+    int pidx = 0;
+    for (int i = 0; i < d; i++) for (int j = i; j < d; j++) info_upper[pidx++] = 0.5 * (covsum[(size_t)i * d + j] + covsum[(size_t)j * d + i]);
+    for (int i = 0; i < ps; i++) meas[i] = m[i];
+    if (*from == toConnect) *to = minid; else *from = minid;
+    return 0;
+}

@@ -138,6 +138,16 @@ class GraphWrapperHIP:
         accelerated path."""
         return self.marginalizeNoOptimize(which, options, flags)
 
+    def computeSubstituteEdge(self, marginalized, maxid, frm, to):
+        """src/compute_substitute_edge.cpp:13-96 -> (from, to, meas, info_upper)"""
+        marg = np.ascontiguousarray(sorted(marginalized), np.int32)
+        f, t = C.c_int(int(frm)), C.c_int(int(to))
+        meas = np.zeros(abi.pose_stride(self.d))
+        info = np.zeros(self.d * (self.d + 1) // 2)
+        check(self.L.spg_graph_substitute_edge(self.h, _p(marg, C.c_int32), len(marg), int(maxid), C.byref(f), C.byref(t),
+                                               _p(meas, C.c_double), _p(info, C.c_double)), self.ctx.h, "computeSubstituteEdge")
+        return f.value, t.value, meas, info
+
     # round-stepping form (multi-GPU driver in parallel.py)
     def begin(self, which, opts, rank, nranks):
         which = np.ascontiguousarray(which, np.int32)
