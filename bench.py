@@ -124,9 +124,19 @@ def main():
         per_launch_s = 1e-3 * prof["kernel_ms"] / prof["launches"]
         achieved = per_launch_bytes / per_launch_s / 1e9
         flops = FLOP_PER_NODE_K4 * prof["blankets"] / (1e-3 * prof["kernel_ms"]) / 1e12
+        # HBM traffic cannot be read inside this process: it comes from separate rocprofv3 --pmc passes
+        # of this same command (FETCH_SIZE, WRITE_SIZE), summarised under profiles/
+        traffic, traffic_note = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            if world == 1 and args.poses == 100000 and args.ring == 400:
+                traffic = pm["traffic_bytes_per_launch_uncorrected"]
+                traffic_note = "profiles/r01_pmc_summary.json: (FETCH_SIZE + WRITE_SIZE) * 1024 per launch, separate --pmc passes, uncorrected (8 B/lane gathers are outside the guide's calibration; includes instruction fetch)"
+        except Exception:
+            pass
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None, "kernel": "blanket_kernel<6,64,false,NFR>", "launches": prof["launches"],
+            "traffic": traffic, "traffic_note": traffic_note, "kernel": "blanket_kernel<6,64,false,NFR>", "launches": prof["launches"],
             "avg_launch_us": 1e6 * per_launch_s, "alg_bytes_per_launch": per_launch_bytes,
             "blankets_per_launch": prof["blankets"] / prof["launches"],
             "note": "path is fp64-ALU/latency-bound on paper (SURVEY.md 8d: ~110 flop/B); fp64 vector fraction alongside",

@@ -5,7 +5,7 @@
 // This is what makes a 24x24 Cholesky cost ~7k cycles instead of ~44k on a lone wavefront (the
 // LDS-cooperative versions in spg_dev_la.hpp pay one exposed ~100-cycle LDS latency per inner step;
 // measured with tools/stamp_bench.py). Rows beyond the true size n hold identity rows, so three
-// instantiations (N = 12, 24, 36) serve every blanket up to k = 6 (SE3) / k = 12 (SE2).
+// instantiations (N = 12, 24) serve every blanket up to k = 4 (SE3) / k = 8 (SE2).
 //
 // Same arithmetic as the Eigen calls they stand in for (LLT, LLT::solve(I), LDLT log-det):
 // src/pseudo_chow_liu.cpp:189-190, src/logdet_function.cpp:123-127,246-247.
@@ -148,16 +148,17 @@ __device__ __forceinline__ bool wave_spd_logdet_n(const double *src, int ld, int
 __device__ __forceinline__ bool wave_spd_inverse(const double *src, int ld, int n, int lane, double shift, double *dst,
                                                  double &logdet, double &trace_inv) {
     if (n <= 12) return wave_spd_inverse_n<12>(src, ld, n, lane, shift, dst, logdet, trace_inv);
-    if (n <= 24) return wave_spd_inverse_n<24>(src, ld, n, lane, shift, dst, logdet, trace_inv);
-    return wave_spd_inverse_n<36>(src, ld, n, lane, shift, dst, logdet, trace_inv);
+    return wave_spd_inverse_n<24>(src, ld, n, lane, shift, dst, logdet, trace_inv);
 }
 
 __device__ __forceinline__ bool wave_spd_logdet(const double *src, int ld, int n, int lane, double &logdet) {
     if (n <= 12) return wave_spd_logdet_n<12>(src, ld, n, lane, logdet);
-    if (n <= 24) return wave_spd_logdet_n<24>(src, ld, n, lane, logdet);
-    return wave_spd_logdet_n<36>(src, ld, n, lane, logdet);
+    return wave_spd_logdet_n<24>(src, ld, n, lane, logdet);
 }
 
-constexpr int kWaveMax = 36;
+// N = 36 would serve k <= 6 (SE3) too, but its 72 live fp64 registers push the whole kernel to 256
+// VGPRs + scratch spills (rocprofv3: 8.3 MB of spill writes per 200-blanket launch); larger tiles use
+// the LDS-cooperative routines instead.
+constexpr int kWaveMax = 24;
 
 }  // namespace spgdev

@@ -225,7 +225,10 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         T.sync();
         if (misc[1] || n < nv) { status = SPG_ST_NEEDS_LOCAL_OPTIMIZATION; finish(); return; }
         if (tid == 0) {
-            if (D == 6) { double I12[kIso] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}; for (int t_ = 0; t_ < kIso; t_++) pose[t_] = I12[t_]; }
+            if (D == 6) {
+#pragma unroll
+                for (int t_ = 0; t_ < kIso; t_++) pose[t_] = (t_ == 0 || t_ == 4 || t_ == 8) ? 1.0 : 0.0;
+            }
             else { pose[0] = 0; pose[1] = 0; pose[2] = 0; }
         }
         for (int e = tid; e < bd.n_edge; e += NT) {
@@ -236,10 +239,14 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             if (D == 6) {
                 double Z[kIso];
                 iso_from_tq(rec, Z);
-                if (vi == 0) { for (int t_ = 0; t_ < kIso; t_++) pose[vj * PSZ + t_] = Z[t_]; }
+                if (vi == 0) {
+#pragma unroll
+                    for (int t_ = 0; t_ < kIso; t_++) pose[vj * PSZ + t_] = Z[t_];
+                }
                 else {
                     double I12[kIso] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, Zi[kIso];
                     iso_inv_mul(Z, I12, Zi);
+#pragma unroll
                     for (int t_ = 0; t_ < kIso; t_++) pose[vi * PSZ + t_] = Zi[t_];
                 }
             } else {
