@@ -17,10 +17,20 @@ namespace spgdev {
 
 template <int NT>
 struct Team {
+    static constexpr int size = NT;
     int tid;
     double *red;  // NT doubles of LDS for reductions
     int *flag;    // one int of LDS (sticky failure / broadcast)
-    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // NT == 64: the team is one wavefront; its LDS operations execute in program order, so a "barrier"
+    // only has to stop the compiler from moving memory operations across it (no s_barrier is issued)
+    __device__ __forceinline__ void sync() const {
+        if (NT == 64) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+        }
+    }
 
     // deterministic sum of one value per lane (fixed butterfly order), result broadcast to all lanes
     __device__ __forceinline__ double sum(double v) const {

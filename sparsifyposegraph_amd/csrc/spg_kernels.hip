@@ -22,6 +22,7 @@
 // the algorithmic minimum: every pose and edge record is read once, every new record written once.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <algorithm>
@@ -41,7 +42,7 @@ constexpr int EC = 8;  // edges whose Jacobians are staged per chunk
 // layout of the largest blanket of a launch bounds every blanket in it.
 struct Layout {
     int n, nm, ld, ldm, P, NE;
-    int o_pose, o_red, o_cs, o_ev, o_S, o_w, o_ldb, o_Lb, o_nJ, o_X, o_eJ, o_eO, o_eT, o_Ng, o_tre, o_int, small_doubles;
+    int o_pose, o_red, o_cs, o_ev, o_S, o_w, o_ldb, o_Lb, o_nJ, o_X, o_eJ, o_eO, o_eT, o_Ng, o_tre, o_xch, o_int, small_doubles;
     int o_M1, o_M2, o_M3, o_Hmm, o_Hmk, mat_doubles;
     // int area offsets (in ints, relative to o_int)
     int i_perm, i_keep, i_sorted, i_pij, i_comp, i_pairs, i_ev, i_misc, int_count;
@@ -79,6 +80,7 @@ __host__ __device__ inline Layout make_layout(int D, int nt, int k, int m, int a
     L.o_eT = o; o += EC * 2 * DD;
     L.o_Ng = o; o += L.n * D;
     L.o_tre = o; o += L.NE;
+    L.o_xch = o; o += 4;
     L.gS = single ? (k > 0 ? D * k : D) : 2 * D;
     L.gCNT = single ? 1 : (k - 1);
     L.gld = L.gS | 1;
@@ -96,7 +98,7 @@ __host__ __device__ inline Layout make_layout(int D, int nt, int k, int m, int a
     L.i_comp = io; io += k + 1;
     L.i_pairs = io; io += 2 * L.NE;
     L.i_ev = io; io += 2 * EC;
-    L.i_misc = io; io += 8;
+    L.i_misc = io; io += 12;
     L.i_gperm = io; if (glc) io += L.gCNT * L.gS;
     L.i_gdone = io; if (glc) io += L.gCNT;
     L.i_gmeta = io; if (glc) io += 3 * (L.NE + 1);
@@ -157,7 +159,11 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     double *M1 = mat + L.o_M1, *M2 = mat + L.o_M2, *M3 = mat + L.o_M3, *Hmm = mat + L.o_Hmm, *Hmk = mat + L.o_Hmk;
     Team<NT> T{tid, smem + L.o_red, misc + 0};
     // register-resident single-wavefront SPD kernels (spg_dev_wave.hpp) when the tile fits
-    const bool use_wave = (NT == 64) && !GWS && (n <= kWaveMax) && !((a.flags >> 17) & 1);
+    const bool use_wave_hw = !GWS && (n <= kWaveMax) && !((a.flags >> 17) & 1);
+    const bool use_wave = use_wave_hw && (NT == 64);
+    // two wavefronts per blanket: the Chow-Liu chain and the gauge chain run side by side (NFR only)
+    const bool split = (NT == 128) && (ALG == SPG_ALG_NFR) && use_wave_hw && !(a.flags & SPG_FLAG_FORCE_EIG);
+    double *xch = smem + L.o_xch;
     double *arena = a.arena;
     double *orec = a.mail ? (a.mail + (bd.out_off - a.mail_base)) : (arena + bd.out_off);
 
@@ -188,7 +194,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     };
     STAMP(0);  //
     // ---------------------------------------------------------------- gather poses, clear H
-    if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0; }
+    if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0; misc[6] = 0; misc[7] = 0; }
     for (int v = tid; v < nv; v += NT) {
         const double *p = arena + a.vpo[bd.vert_begin + v];
         if (D == 6) iso_from_tq(p, pose + v * PSZ);
@@ -198,6 +204,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     for (int i = tid; i < nm * ldm; i += NT) Hmm[i] = 0.0;
     for (int i = tid; i < nm * ld; i += NT) Hmk[i] = 0.0;
     T.sync();
+    STAMP(23);  // gathered + cleared
     if (bd.n_edge == 0 || m < 1) { status = SPG_ST_EMPTY_BLANKET; finish(); return; }
     constexpr bool is_glc = (ALG == SPG_ALG_GLC);  // compile-time: the NFR instantiation carries no GLC code
     if (is_glc && !(a.topology == SPG_TOPO_DENSE || a.topology == SPG_TOPO_TREE)) {
@@ -298,6 +305,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             eO[it] = (er.kind == SPG_EDGE_BINARY) ? arena[er.off + PS + utri(lo, hi, D)] : 0.0;
         }
         T.sync();
+        STAMP(24);  // jacobians + omega staged
         // T_e = Omega_e [Ji | Jj] for every staged edge at once
         for (int it = tid; it < cnt * 2 * DD; it += NT) {
             int e = it / (2 * DD), rem = it - e * 2 * DD, wch = rem / DD, rc = rem - wch * DD, r = rc / D, c = rc - r * D;
@@ -308,6 +316,39 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             eT[it] = s;
         }
         T.sync();
+        STAMP(25);  // T = Omega J
+        if (NT == 64) {
+            // One wavefront: LDS atomics retire in program order and every ds_add_f64 below carries the
+            // items of a single edge (128-slot stride, 108 used), so no two lanes of one instruction hit
+            // the same address and contributions land in ascending edge order — deterministic, without a
+            // barrier per edge.
+            auto hadd_atomic = [&](int R, int Cc, double val) {
+                double *dst = nullptr;
+                if (R < nm) dst = (Cc < nm) ? &Hmm[R * ldm + Cc] : &Hmk[R * ld + (Cc - nm)];
+                else if (Cc >= nm) dst = &M1[(R - nm) * ld + (Cc - nm)];
+                if (dst) __hip_atomic_fetch_add(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            constexpr int SLOT = (3 * DD + 63) / 64 * 64;
+            for (int it = tid; it < cnt * SLOT; it += NT) {
+                int e = it / SLOT, loc = it - e * SLOT;
+                if (loc >= 3 * DD || echv[2 * e] < 0) continue;
+                const double *Ji = eJ + e * 2 * DD, *Jj = Ji + DD, *Te = eT + e * 2 * DD;
+                int vi = echv[2 * e], vj = echv[2 * e + 1];
+                int blk = loc / DD, rc = loc - blk * DD, r = rc / D, c = rc - r * D;
+                const double *Ja = (blk == 2) ? Jj : Ji;
+                const double *Tb = (blk == 0) ? Te : Te + DD;
+                double s = 0;
+#pragma unroll
+                for (int p = 0; p < D; p++) s += Ja[p * D + r] * Tb[p * D + c];
+                if (blk == 0) hadd_atomic(vi * D + r, vi * D + c, s);
+                else if (blk == 2) hadd_atomic(vj * D + r, vj * D + c, s);
+                else if (vi != vj) {
+                    hadd_atomic(vi * D + r, vj * D + c, s);
+                    hadd_atomic(vj * D + c, vi * D + r, s);
+                }
+            }
+            T.sync();
+        } else {
         // accumulate edge by edge (blocks of different edges overlap on the shared vertices)
         for (int e = 0; e < cnt; e++) {
             if (echv[2 * e] < 0) continue;
@@ -325,6 +366,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                 else if (vi != vj) { hadd(vi * D + r, vj * D + c, s); hadd(vj * D + c, vi * D + r, s); }
             }
             T.sync();
+        }
         }
     }
     if (misc[1]) { status = SPG_ST_UNSUPPORTED; finish(); return; }
@@ -399,6 +441,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                 for (int j = 0; j < D; j++) Hmm[i * ldm + j] = Xr[i * D + j];
         }
         T.sync();
+        STAMP(26);  // Hmm inverse
         if (misc[0]) { status = SPG_ST_HMM_NOT_PD; finish(); return; }
         // Y = H_mm^-1 H_mk into M2 rows 0..D-1 (M2 is free until Chow-Liu)
         for (int it = tid; it < D * n; it += NT) {
@@ -409,6 +452,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             M2[r * ld + c] = s;
         }
         T.sync();
+        STAMP(27);  // Y
     } else {
         chol_lower<NT>(T, Hmm, nm, ldm);
         if (misc[0]) { status = SPG_ST_HMM_NOT_PD; finish(); return; }
@@ -422,13 +466,19 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             int i = it >> sh, j = it & ((1 << sh) - 1);
             if (j < n) {
                 double s = 0;
-                for (int p = 0; p < nm; p++) s += Hmk[p * ld + i] * Yl[p * ld + j];
+                if (m == 1) {
+#pragma unroll
+                    for (int p = 0; p < D; p++) s += Hmk[p * ld + i] * Yl[p * ld + j];
+                } else {
+                    for (int p = 0; p < nm; p++) s += Hmk[p * ld + i] * Yl[p * ld + j];
+                }
                 double v = M1[i * ld + j] - s;
                 M1[i * ld + j] = v;
                 if (!isfinite(v)) bad = 1;
             }
         }
         double anybad = T.sum(bad);
+        STAMP(28);  // Lambda update
         mirror_upper<NT>(T, M1, n, ld);
         if (anybad > 0) { status = SPG_ST_NONFINITE; finish(); return; }
     }
@@ -437,39 +487,39 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         for (int it = tid; it < n * n; it += NT) { int i = it / n, j = it - i * n; dst[it] = M1[i * ld + j]; }
     }
     // pseudo-Chow-Liu tree of the kept vertices (a8): fills pairs[0..2(k-1)) in pop order, sets min_gap
-    auto chow_liu_tree = [&]() -> int {
+    auto chow_liu_tree = [&](auto &TT) -> int {
         if (k == 2) {
-            if (tid == 0) { pairs[0] = 0; pairs[1] = 1; }
-            T.sync();
+            if (TT.tid == 0) { pairs[0] = 0; pairs[1] = 1; }
+            TT.sync();
             return (int)SPG_OK;
         }
         // Sigma~ = (Lambda_t + 1 I)^-1 in M2
-        if (use_wave) {
+        if ((use_wave_hw && TT.size == 64)) {
             double ld_, tr_;
-            bool ok_ = wave_spd_inverse(M1, ld, n, tid, 1.0, M2, ld_, tr_);
+            bool ok_ = wave_spd_inverse(M1, ld, n, TT.tid, 1.0, M2, ld_, tr_);
             if (!ok_) return (int)SPG_ST_TIKHONOV_NOT_PD;
-            T.sync();
+            TT.sync();
         } else {
-            for (int it = tid; it < n * ld; it += NT) M2[it] = M1[it];
-            T.sync();
-            for (int i = tid; i < n; i += NT) M2[i * ld + i] += 1.0;
-            T.sync();
-            chol_lower<NT>(T, M2, n, ld, ev);
-            if (misc[0]) return (int)SPG_ST_TIKHONOV_NOT_PD;
-            STAMP(3);  // cl chol
-            tri_inverse_lower<NT>(T, M2, M3, n, ld, ev);
-            STAMP(4);  // cl triinv
-            gram_lower_inverse<NT>(T, M3, M2, n, ld);
+            for (int it = TT.tid; it < n * ld; it += TT.size) M2[it] = M1[it];
+            TT.sync();
+            for (int i = TT.tid; i < n; i += TT.size) M2[i * ld + i] += 1.0;
+            TT.sync();
+            chol_lower(TT, M2, n, ld, ev);
+            if ((*TT.flag)) return (int)SPG_ST_TIKHONOV_NOT_PD;
+            if (!split) STAMP(3);  // cl chol
+            tri_inverse_lower(TT, M2, M3, n, ld, ev);
+            if (!split) STAMP(4);  // cl triinv
+            gram_lower_inverse(TT, M3, M2, n, ld);
         }
-        STAMP(5);  // cl gram
+        if (!split) STAMP(5);  // cl gram
         // per-vertex diagonal blocks: Cholesky + log det
-        for (int v = tid; v < k; v += NT) {
+        for (int v = TT.tid; v < k; v += TT.size) {
             double Ab[DD];
 #pragma unroll
             for (int r = 0; r < D; r++)
 #pragma unroll
                 for (int c = 0; c < D; c++) Ab[r * D + c] = M2[(v * D + r) * ld + v * D + c];
-            if (!chol_reg<D>(Ab)) misc[0] = 1;
+            if (!chol_reg<D>(Ab)) (*TT.flag) = 1;
             LogProd lp;
 #pragma unroll
             for (int r = 0; r < D; r++) {
@@ -480,10 +530,10 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             }
             ldb[v] = 2.0 * lp.value();
         }
-        T.sync();
-        STAMP(6);  // cl vertex chol
+        TT.sync();
+        if (!split) STAMP(6);  // cl vertex chol
         // pair weights w = ld_i + ld_j - ld_{ij}, ld_{ij} = ld_i + logdet(S_jj - S_ji S_ii^-1 S_ij)
-        for (int p = tid; p < L.P; p += NT) {
+        for (int p = TT.tid; p < L.P; p += TT.size) {
             int i = 0, rem = p;
             while (rem >= k - 1 - i) { rem -= k - 1 - i; i++; }
             int j = i + 1 + rem;
@@ -510,19 +560,19 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                     for (int q = 0; q < D; q++) s -= Y[q * D + r] * Y[q * D + c];
                     Sb[r * D + c] = s;
                 }
-            if (!chol_reg<D>(Sb)) misc[0] = 1;
+            if (!chol_reg<D>(Sb)) (*TT.flag) = 1;
             LogProd lp;
 #pragma unroll
             for (int r = 0; r < D; r++) lp.mul(Sb[r * D + r]);
             double lxy = ldb[i] + 2.0 * lp.value();
             w[p] = -((ldb[i] + ldb[j]) - lxy);  // stored negated: ascending sort == max-heap pop order
         }
-        T.sync();
-        if (misc[0]) return (int)SPG_ST_TIKHONOV_NOT_PD;
-        STAMP(7);  // cl pair weights
-        sort_ascending<NT>(T, w, 1, L.P, sorted);
-        STAMP(8);  // cl sort
-        if (tid == 0) {
+        TT.sync();
+        if ((*TT.flag)) return (int)SPG_ST_TIKHONOV_NOT_PD;
+        if (!split) STAMP(7);  // cl pair weights
+        sort_ascending(TT, w, 1, L.P, sorted);
+        if (!split) STAMP(8);  // cl sort
+        if (TT.tid == 0) {
             // Kruskal in pop order (src/pseudo_chow_liu.cpp:253-289); first `ne` of the bin are used
             for (int v = 0; v < k; v++) comp[v] = v;
             int nacc = 0, last = 0;
@@ -547,9 +597,9 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             }
             cs[0] = g;
         }
-        T.sync();
+        TT.sync();
         min_gap = cs[0];
-        T.sync();
+        TT.sync();
         return (int)SPG_OK;
     };
     if constexpr (is_glc) {
@@ -574,12 +624,190 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             status = SPG_ST_NEEDS_INTERIOR_POINT; finish(); return;
         }
     }
-    {
-        int st_ = chow_liu_tree();
-        if (st_ != SPG_OK) { status = st_; finish(); return; }
-    }
 
-    STAMP(9);  // kruskal
+    // ================================================================ information recovery (a11, a12)
+    // Two routes to the same numbers.
+    //  * eigen route — the reference's own: eig(Lambda_t), drop the d gauge directions, Sigma = U S U^T
+    //    (src/logdet_function.cpp:14-64,236-279), KLD through M = U^T A U (src/logdet_function.cpp:119-133).
+    //  * gauge route — Lambda_t of a blanket of relative-pose edges has an exactly known d-dimensional
+    //    null space: the rigid motions of the whole blanket, N = [G_1; ...; G_k] in the vertices' update
+    //    coordinates. With N^ an orthonormal basis of it and C = Lambda_t + N^ N^^T (SPD):
+    //        U S U^T = C^-1 - N^ N^^T,   J_e N^ = 0  =>  J_e Sigma J_e^T = J_e C^-1 J_e^T,
+    //        log det S = -log det C,  tr(S M) = tr(C^-1 A),  log det(U^T A U) = log det(A + N^ N^^T),
+    //    so three Cholesky factorisations replace the Jacobi eigen-decomposition (~10x fewer dependent
+    //    steps). It is taken only when ||C^-1||_F < 5e4, which proves lambda_{d+1}(Lambda_t) > 1e-5, i.e.
+    //    the reference's `smalleigs <= dim` branch; anything else (rank-deficient blankets, failed
+    //    factorisations) goes through the eigen route. tests/test_gpu_parity.py checks both routes
+    //    against the oracle to 1e-9.
+    const int r = n - D;
+    double *Ng = smem + L.o_Ng;      // n x D orthonormal gauge basis
+    double *tre = smem + L.o_tre;    // per-edge tr(X_e B_e)
+    bool gauge_ok = false;
+    double logdetS = 0.0;
+    double *Sg = M1, *Scr = M3;      // Sigma and scratch for the closed form (swapped on the gauge route)
+    auto gauge_chain = [&](auto &TT) {
+        // ---- gauge basis
+        for (int v = TT.tid; v < k; v += TT.size) {
+            const double *X = pose + (m + v) * PSZ;
+            double *Gv = Ng + v * DD;
+            if (D == 6) {
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        // R^T ; -R^T [t]x ; 0 ; 1/2 R^T   (column c of [t]x is t x e_c)
+                        constexpr int A1[3] = {1, 2, 0}, B1[3] = {2, 0, 1};
+                        const int ca = A1[c], cb = B1[c];
+                        double rt = X[c * 3 + rr];
+                        // (t x e_c): component cb = +t[ca]... derive: t x e_c = (t_a e_a + t_b e_b + t_c e_c) x e_c
+                        //   e_a x e_c = -e_b , e_b x e_c = +e_a   (a = c+1, b = c+2 cyclic)
+                        //   => t x e_c = t_b e_a - t_a e_b
+                        double cx_a = X[9 + cb], cx_b = -X[9 + ca];
+                        double val = -(X[ca * 3 + rr] * cx_a + X[cb * 3 + rr] * cx_b);  // -(R^T (t x e_c))[rr]
+                        Gv[rr * 6 + c] = rt;
+                        Gv[rr * 6 + 3 + c] = val;
+                        Gv[(3 + rr) * 6 + c] = 0.0;
+                        Gv[(3 + rr) * 6 + 3 + c] = 0.5 * rt;
+                    }
+            } else {
+                Gv[0] = 1; Gv[1] = 0; Gv[2] = -X[1];
+                Gv[3] = 0; Gv[4] = 1; Gv[5] = X[0];
+                Gv[6] = 0; Gv[7] = 0; Gv[8] = 1;
+            }
+        }
+        TT.sync();
+        if (!split) STAMP(11);  // gauge basis
+        // ---- orthonormalise: N^ = N L^-T with N^T N = L L^T (D x D, one lane, registers)
+        if (TT.tid < DD) {
+            int rr = TT.tid / D, c = TT.tid - rr * D;
+            double s = 0;
+            for (int i = 0; i < n; i++) s += Ng[i * D + rr] * Ng[i * D + c];
+            eT[TT.tid] = s;
+        }
+        TT.sync();
+        if (TT.tid == 0) {
+            double Ab[DD], Li[DD];
+#pragma unroll
+            for (int i = 0; i < DD; i++) Ab[i] = eT[i];
+            if (!chol_reg<D>(Ab)) (*TT.flag) = 1;
+#pragma unroll
+            for (int c = 0; c < D; c++)
+#pragma unroll
+                for (int i = 0; i < D; i++) {
+                    if (i < c) Li[i * D + c] = 0.0;
+                    else if (i == c) Li[i * D + c] = 1.0 / Ab[c * D + c];
+                    else {
+                        double s = 0;
+#pragma unroll
+                        for (int q = 0; q < D; q++) if (q >= c && q < i) s += Ab[i * D + q] * Li[q * D + c];
+                        Li[i * D + c] = -s / Ab[i * D + i];
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < DD; i++) eT[DD + i] = Li[i];
+        }
+        TT.sync();
+        {
+            double nv_[D];
+            for (int i = TT.tid; i < n; i += TT.size) {
+#pragma unroll
+                for (int c = 0; c < D; c++) {
+                    double s = 0;
+#pragma unroll
+                    for (int q = 0; q < D; q++) if (q <= c) s += Ng[i * D + q] * eT[DD + c * D + q];
+                    nv_[c] = s;
+                }
+#pragma unroll
+                for (int c = 0; c < D; c++) Ng[i * D + c] = nv_[c];
+            }
+        }
+        TT.sync();
+        if (!split) STAMP(12);  // orthonormalised
+        // ---- C = Lambda_t + N^ N^^T into M3, Cholesky, inverse
+        {
+            int sh = ceil_log2(n), tot = n << sh;
+            for (int it = TT.tid; it < tot; it += TT.size) {
+                int i = it >> sh, j = it & ((1 << sh) - 1);
+                if (j <= i) {
+                    double s = M1[i * ld + j];
+#pragma unroll
+                    for (int q = 0; q < D; q++) s += Ng[i * D + q] * Ng[j * D + q];
+                    M3[i * ld + j] = s;
+                    M3[j * ld + i] = s;
+                }
+            }
+            TT.sync();
+        }
+        if (!split) STAMP(13);  // C formed
+        if ((use_wave_hw && TT.size == 64)) {
+            double ldC, trC;
+            bool ok_ = wave_spd_inverse(M3, ld, n, TT.tid, 0.0, M3, ldC, trC);
+            bool fail = !ok_ || ((*TT.flag) != 0);
+            TT.sync();
+            if (TT.tid == 0) { (*TT.flag) = 0; }
+            TT.sync();
+            // trace(C^-1) >= lambda_max(C^-1): below 5e4 proves lambda_{d+1}(Lambda_t) > 1e-5
+            if (!fail && trC < 5e4 && isfinite(trC)) {
+                if (TT.tid == 0) { xch[0] = 1.0; xch[1] = -ldC; }
+            }
+        } else {
+            chol_lower(TT, M3, n, ld, Sv);
+            if (!split) STAMP(14);  // C chol
+            bool fail = ((*TT.flag) != 0);
+            TT.sync();
+            if (TT.tid == 0) { (*TT.flag) = 0; }
+            TT.sync();
+            if (!fail) {
+                double ldC = chol_logdet(TT, M3, n, ld);
+                if (!split) STAMP(15);  // logdet
+                tri_inverse_lower(TT, M3, M2, n, ld, Sv);
+                if (!split) STAMP(16);  // triinv
+                // C^-1 = Li^T Li into M3 with its Frobenius norm
+                int sh = ceil_log2(n), tot = n << sh;
+                double f2 = 0;
+                for (int it = TT.tid; it < tot; it += TT.size) {
+                    int i = it >> sh, j = it & ((1 << sh) - 1);
+                    if (j <= i) {
+                        double s = 0;
+                        for (int q = i; q < n; q++) s += M2[q * ld + i] * M2[q * ld + j];
+                        M3[i * ld + j] = s;
+                        M3[j * ld + i] = s;
+                        f2 += (i == j) ? s * s : 2.0 * s * s;
+                    }
+                }
+                double fro2 = TT.sum(f2);
+                if (fro2 < 5e4 * 5e4 && isfinite(fro2)) {
+                    if (TT.tid == 0) { xch[0] = 1.0; xch[1] = -ldC; }
+                }
+            }
+        }
+    };
+    // ---- run the two independent chains: Chow-Liu (Lambda_t + I)^-1 ... Kruskal, and the gauge route's
+    // C^-1. With two wavefronts per blanket (NT == 128) they run side by side, each wavefront as its own
+    // team with wave-local barriers; otherwise one after the other on the whole team.
+    if (tid == 0) { xch[0] = 0.0; xch[1] = 0.0; }
+    T.sync();
+    {
+        int st_ = SPG_OK;
+        if (split) {
+            Team<64> S{tid & 63, nullptr, misc + ((tid < 64) ? 6 : 2)};
+            if (tid < 64) { int s2 = chow_liu_tree(S); if (S.tid == 0) misc[7] = s2; }
+            else gauge_chain(S);
+            T.sync();
+            st_ = misc[7];
+            min_gap = (k > 2) ? cs[0] : min_gap;
+        } else {
+            st_ = chow_liu_tree(T);
+            if (st_ == SPG_OK && !(a.flags & SPG_FLAG_FORCE_EIG)) gauge_chain(T);
+        }
+        if (st_ != SPG_OK) { status = st_; finish(); return; }
+        T.sync();
+        if (xch[0] != 0.0) { gauge_ok = true; logdetS = xch[1]; Sg = M3; Scr = M1; }
+        T.sync();
+        if (tid == 0) { misc[0] = 0; misc[2] = 0; misc[6] = 0; }
+        T.sync();
+    }
+    STAMP(9);  // both chains done
     if (stop_after == 3) { finish(); return; }
     // ---------------------------------------------------------------- new edge skeleton (a9, a10)
     for (int e = tid; e < ne; e += NT) {
@@ -608,169 +836,6 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
 
     STAMP(10);  // new edges
     if (stop_after == 4) { finish(); return; }
-
-    // ================================================================ information recovery (a11, a12)
-    // Two routes to the same numbers.
-    //  * eigen route — the reference's own: eig(Lambda_t), drop the d gauge directions, Sigma = U S U^T
-    //    (src/logdet_function.cpp:14-64,236-279), KLD through M = U^T A U (src/logdet_function.cpp:119-133).
-    //  * gauge route — Lambda_t of a blanket of relative-pose edges has an exactly known d-dimensional
-    //    null space: the rigid motions of the whole blanket, N = [G_1; ...; G_k] in the vertices' update
-    //    coordinates. With N^ an orthonormal basis of it and C = Lambda_t + N^ N^^T (SPD):
-    //        U S U^T = C^-1 - N^ N^^T,   J_e N^ = 0  =>  J_e Sigma J_e^T = J_e C^-1 J_e^T,
-    //        log det S = -log det C,  tr(S M) = tr(C^-1 A),  log det(U^T A U) = log det(A + N^ N^^T),
-    //    so three Cholesky factorisations replace the Jacobi eigen-decomposition (~10x fewer dependent
-    //    steps). It is taken only when ||C^-1||_F < 5e4, which proves lambda_{d+1}(Lambda_t) > 1e-5, i.e.
-    //    the reference's `smalleigs <= dim` branch; anything else (rank-deficient blankets, failed
-    //    factorisations) goes through the eigen route. tests/test_gpu_parity.py checks both routes
-    //    against the oracle to 1e-9.
-    const int r = n - D;
-    double *Ng = smem + L.o_Ng;      // n x D orthonormal gauge basis
-    double *tre = smem + L.o_tre;    // per-edge tr(X_e B_e)
-    bool gauge_ok = false;
-    double logdetS = 0.0;
-    double *Sg = M1, *Scr = M3;      // Sigma and scratch for the closed form (swapped on the gauge route)
-    if (!(a.flags & SPG_FLAG_FORCE_EIG)) {
-        // ---- gauge basis
-        for (int v = tid; v < k; v += NT) {
-            const double *X = pose + (m + v) * PSZ;
-            double *Gv = Ng + v * DD;
-            if (D == 6) {
-#pragma unroll
-                for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        // R^T ; -R^T [t]x ; 0 ; 1/2 R^T   (column c of [t]x is t x e_c)
-                        constexpr int A1[3] = {1, 2, 0}, B1[3] = {2, 0, 1};
-                        const int ca = A1[c], cb = B1[c];
-                        double rt = X[c * 3 + rr];
-                        // (t x e_c): component cb = +t[ca]... derive: t x e_c = (t_a e_a + t_b e_b + t_c e_c) x e_c
-                        //   e_a x e_c = -e_b , e_b x e_c = +e_a   (a = c+1, b = c+2 cyclic)
-                        //   => t x e_c = t_b e_a - t_a e_b
-                        double cx_a = X[9 + cb], cx_b = -X[9 + ca];
-                        double val = -(X[ca * 3 + rr] * cx_a + X[cb * 3 + rr] * cx_b);  // -(R^T (t x e_c))[rr]
-                        Gv[rr * 6 + c] = rt;
-                        Gv[rr * 6 + 3 + c] = val;
-                        Gv[(3 + rr) * 6 + c] = 0.0;
-                        Gv[(3 + rr) * 6 + 3 + c] = 0.5 * rt;
-                    }
-            } else {
-                Gv[0] = 1; Gv[1] = 0; Gv[2] = -X[1];
-                Gv[3] = 0; Gv[4] = 1; Gv[5] = X[0];
-                Gv[6] = 0; Gv[7] = 0; Gv[8] = 1;
-            }
-        }
-        T.sync();
-        STAMP(11);  // gauge basis
-        // ---- orthonormalise: N^ = N L^-T with N^T N = L L^T (D x D, one lane, registers)
-        if (tid < DD) {
-            int rr = tid / D, c = tid - rr * D;
-            double s = 0;
-            for (int i = 0; i < n; i++) s += Ng[i * D + rr] * Ng[i * D + c];
-            eT[tid] = s;
-        }
-        T.sync();
-        if (tid == 0) {
-            double Ab[DD], Li[DD];
-#pragma unroll
-            for (int i = 0; i < DD; i++) Ab[i] = eT[i];
-            if (!chol_reg<D>(Ab)) misc[2] = 1;
-#pragma unroll
-            for (int c = 0; c < D; c++)
-#pragma unroll
-                for (int i = 0; i < D; i++) {
-                    if (i < c) Li[i * D + c] = 0.0;
-                    else if (i == c) Li[i * D + c] = 1.0 / Ab[c * D + c];
-                    else {
-                        double s = 0;
-#pragma unroll
-                        for (int q = 0; q < D; q++) if (q >= c && q < i) s += Ab[i * D + q] * Li[q * D + c];
-                        Li[i * D + c] = -s / Ab[i * D + i];
-                    }
-                }
-#pragma unroll
-            for (int i = 0; i < DD; i++) eT[DD + i] = Li[i];
-        }
-        T.sync();
-        {
-            double nv_[D];
-            for (int i = tid; i < n; i += NT) {
-#pragma unroll
-                for (int c = 0; c < D; c++) {
-                    double s = 0;
-#pragma unroll
-                    for (int q = 0; q < D; q++) if (q <= c) s += Ng[i * D + q] * eT[DD + c * D + q];
-                    nv_[c] = s;
-                }
-#pragma unroll
-                for (int c = 0; c < D; c++) Ng[i * D + c] = nv_[c];
-            }
-        }
-        T.sync();
-        STAMP(12);  // orthonormalised
-        // ---- C = Lambda_t + N^ N^^T into M3, Cholesky, inverse
-        {
-            int sh = ceil_log2(n), tot = n << sh;
-            for (int it = tid; it < tot; it += NT) {
-                int i = it >> sh, j = it & ((1 << sh) - 1);
-                if (j <= i) {
-                    double s = M1[i * ld + j];
-#pragma unroll
-                    for (int q = 0; q < D; q++) s += Ng[i * D + q] * Ng[j * D + q];
-                    M3[i * ld + j] = s;
-                    M3[j * ld + i] = s;
-                }
-            }
-            T.sync();
-        }
-        STAMP(13);  // C formed
-        if (use_wave) {
-            double ldC, trC;
-            bool ok_ = wave_spd_inverse(M3, ld, n, tid, 0.0, M3, ldC, trC);
-            bool fail = !ok_ || (misc[2] != 0);
-            T.sync();
-            if (tid == 0) { misc[0] = 0; misc[2] = 0; }
-            T.sync();
-            // trace(C^-1) >= lambda_max(C^-1): below 5e4 proves lambda_{d+1}(Lambda_t) > 1e-5
-            if (!fail && trC < 5e4 && isfinite(trC)) {
-                gauge_ok = true;
-                logdetS = -ldC;
-                Sg = M3; Scr = M1;
-            }
-        } else {
-            chol_lower<NT>(T, M3, n, ld, ev);
-            STAMP(14);  // C chol
-            bool fail = (misc[0] != 0) || (misc[2] != 0);
-            T.sync();
-            if (tid == 0) { misc[0] = 0; misc[2] = 0; }
-            T.sync();
-            if (!fail) {
-                double ldC = chol_logdet<NT>(T, M3, n, ld);
-                STAMP(15);  // logdet
-                tri_inverse_lower<NT>(T, M3, M2, n, ld, ev);
-                STAMP(16);  // triinv
-                // C^-1 = Li^T Li into M3 with its Frobenius norm
-                int sh = ceil_log2(n), tot = n << sh;
-                double f2 = 0;
-                for (int it = tid; it < tot; it += NT) {
-                    int i = it >> sh, j = it & ((1 << sh) - 1);
-                    if (j <= i) {
-                        double s = 0;
-                        for (int q = i; q < n; q++) s += M2[q * ld + i] * M2[q * ld + j];
-                        M3[i * ld + j] = s;
-                        M3[j * ld + i] = s;
-                        f2 += (i == j) ? s * s : 2.0 * s * s;
-                    }
-                }
-                double fro2 = T.sum(f2);
-                if (fro2 < 5e4 * 5e4 && isfinite(fro2)) {
-                    gauge_ok = true;
-                    logdetS = -ldC;
-                    Sg = M3; Scr = M1;
-                }
-            }
-        }
-    }
-
     if (!gauge_ok) {
         // ------------------------------------------------------------ eigen route: spectrum of Lambda_t
         for (int it = tid; it < n * ld; it += NT) M3[it] = M1[it];
@@ -969,11 +1034,16 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                 tr = T.sum(s);
             }
             STAMP(20);  // A + NN
-            if (use_wave) {
-                double ldA;
-                bool ok_ = wave_spd_logdet(Am, ld, n, tid, ldA);
-                if (!ok_) { kld = __builtin_inf(); status = SPG_ST_KLD_NOT_PD; }
-                else kld = 0.5 * (tr - ldA - logdetS - (double)r);
+            if (use_wave_hw && NT <= 128) {
+                // the first wavefront factorises in registers; the result reaches every lane through LDS
+                if (tid < 64) {
+                    double ldA_;
+                    bool ok_ = wave_spd_logdet(Am, ld, n, tid, ldA_);
+                    if (tid == 0) { xch[2] = ok_ ? 1.0 : 0.0; xch[3] = ldA_; }
+                }
+                T.sync();
+                if (xch[2] == 0.0) { kld = __builtin_inf(); status = SPG_ST_KLD_NOT_PD; }
+                else kld = 0.5 * (tr - xch[3] - logdetS - (double)r);
             } else {
                 chol_lower<NT>(T, Am, n, ld);
                 if (misc[0]) {
@@ -1052,6 +1122,7 @@ struct HipBackend {
     size_t c_stage = 0;
     int lds_limit = 160 * 1024;
     int n_launches = 0;
+    bool force_one_wave = false;  // SPG_ONE_WAVE=1: never use the two-wavefront latency variant (A/B timing)
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
     bool profiling = false;
     struct Timed { hipEvent_t a, b; double bytes; int blankets; };
@@ -1210,7 +1281,14 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
             // the (kmax, mmax, smax) envelope can exceed the device limit although every member fits
             // (each needs <= lim[i] <= lds_limit): clamp, the per-block carve-up uses its own k, m
             if (lds > (size_t)hb->lds_limit) lds = (size_t)hb->lds_limit;
-            if (o.algorithm == SPG_ALG_GLC)
+            // latency mode: a launch that cannot fill the chip (<= 2 blankets per CU) gives every blanket
+            // two wavefronts so the Chow-Liu and gauge chains overlap; throughput mode keeps one
+            const bool two_waves = (o.algorithm == SPG_ALG_NFR) && nb <= 512 && D * bins[i].kmax <= kWaveMax && !hb->force_one_wave;
+            if (two_waves) {
+                Layout L2 = make_layout(D, 128, bins[i].kmax, bins[i].mmax, o.algorithm, o.topology, bins[i].smax);
+                size_t lds2 = std::min((size_t)(L2.small_doubles + L2.mat_doubles) * 8, (size_t)hb->lds_limit);
+                rc = (D == 6) ? launch_bin<6, 128, false, SPG_ALG_NFR>(hb, ka, nb, lds2, bins[i].bytes) : launch_bin<3, 128, false, SPG_ALG_NFR>(hb, ka, nb, lds2, bins[i].bytes);
+            } else if (o.algorithm == SPG_ALG_GLC)
                 rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_GLC>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_GLC>(hb, ka, nb, lds, bins[i].bytes);
             else
                 rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_NFR>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_NFR>(hb, ka, nb, lds, bins[i].bytes);
@@ -1289,6 +1367,7 @@ int hip_backend_create(int device, spg_backend *out, char *errbuf, size_t errlen
         delete hb;
         return SPG_EHIP;
     }
+    { const char *e1 = getenv("SPG_ONE_WAVE"); hb->force_one_wave = e1 && e1[0] == '1'; }
     hb->lds_limit = (int)prop.sharedMemPerBlock > 0 ? (int)std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024) : 64 * 1024;
     out->user = hb;
     out->alloc = hip_alloc;
