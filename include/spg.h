@@ -279,6 +279,8 @@ typedef struct {
      * computed blankets are ALSO delivered to backend->mailbox()[out_off - mail_base] (pinned host
      * memory written by the kernel), so the host needs no device->host copy to read them */
     int64_t mail_base, mail_len;
+    int32_t slot;   /* launch slot (0 | 1): batches in different slots may be in flight at the same time */
+    int32_t pad2_;
 } spg_round_desc;
 typedef struct {
     void *user;
@@ -289,6 +291,10 @@ typedef struct {
     int (*run_round)(void *user, void *arena, const spg_round_desc *round);     /* may be asynchronous */
     int (*synchronize)(void *user);
     const double *(*mailbox)(void *user);   /* may be NULL: no mailbox, out records are downloaded */
+    /* optional: two launch slots for overlapping the host work of one batch with the device work of
+     * another. NULL = the backend runs one batch at a time */
+    int (*synchronize_slot)(void *user, int slot);
+    const double *(*mailbox_slot)(void *user, int slot);
 } spg_backend;
 int spg_ctx_create_injected(spg_ctx **out, const spg_backend *backend);
 

@@ -83,7 +83,7 @@ class RoundDesc(C.Structure):
     _fields_ = [("opts", C.POINTER(Options)), ("n_blankets", C.c_int32), ("first", C.c_int32),
                 ("count", C.c_int32), ("blankets", C.POINTER(BlanketDesc)), ("vert_pose_off", _i64p),
                 ("edges", C.POINTER(EdgeRef)), ("edge_vert", _i32p), ("n_vert_total", C.c_int64),
-                ("n_edge_total", C.c_int64), ("n_edge_vert_total", C.c_int64), ("mail_base", C.c_int64), ("mail_len", C.c_int64)]
+                ("n_edge_total", C.c_int64), ("n_edge_vert_total", C.c_int64), ("mail_base", C.c_int64), ("mail_len", C.c_int64), ("slot", C.c_int32), ("pad2_", C.c_int32)]
 
 
 _ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int64)
@@ -93,11 +93,14 @@ _DOWNLOAD = C.CFUNCTYPE(C.c_int, C.c_void_p, _f64p, C.c_void_p, C.c_int64)
 _RUN_ROUND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(RoundDesc))
 _SYNC = C.CFUNCTYPE(C.c_int, C.c_void_p)
 _MAILBOX = C.CFUNCTYPE(C.c_void_p, C.c_void_p)
+_SYNC_SLOT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+_MAILBOX_SLOT = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int)
 
 
 class Backend(C.Structure):
     _fields_ = [("user", C.c_void_p), ("alloc", _ALLOC), ("release", _RELEASE), ("upload", _UPLOAD),
-                ("download", _DOWNLOAD), ("run_round", _RUN_ROUND), ("synchronize", _SYNC), ("mailbox", _MAILBOX)]
+                ("download", _DOWNLOAD), ("run_round", _RUN_ROUND), ("synchronize", _SYNC), ("mailbox", _MAILBOX),
+                ("synchronize_slot", _SYNC_SLOT), ("mailbox_slot", _MAILBOX_SLOT)]
 
 
 def pose_stride(d):

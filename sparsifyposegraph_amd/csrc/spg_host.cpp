@@ -87,6 +87,26 @@ struct RoundBlanket {
 
 struct BlanketLog { int32_t root_id, round, status, info; double kld, min_gap; };
 
+// One batch of mutually independent blankets: what used to be "the round". Two of them can be in
+// flight on the two launch slots of the backend (the host prepares / commits one while the device
+// computes the other).
+struct Batch {
+    std::vector<RoundBlanket> rb;
+    std::vector<int32_t> rb_verts, rb_edges;
+    std::vector<spg_blanket_desc> h_blk;
+    std::vector<int64_t> h_vpo;
+    std::vector<spg_edge_ref> h_er;
+    std::vector<int32_t> h_ev;
+    std::vector<int64_t> chunk_hdr;   // per rank: doubles of out records at the start of its chunk
+    spg_round_info rinfo{};
+    bool round_open = false;
+    bool used_mailbox = false;
+    int eff_ranks = 1, eff_rank = 0;   // ranks the batch is split over (1 = computed whole by every rank)
+    int slot = 0;
+    int seq = 0;                       // launch order
+    int round_no = 0;
+};
+
 struct spg_graph {
     spg_ctx *ctx = nullptr;
     int d = 0, ps = 0, rec = 0;
@@ -108,23 +128,16 @@ struct spg_graph {
     bool active = false;
     spg_options opts{};
     int rank = 0, nranks = 1;
-    std::vector<int32_t> pending;
+    std::vector<int32_t> pending;   // removal list (vertex indices) in the caller's order; [pend_head, end) is still to do
+    size_t pend_head = 0;
     std::vector<uint8_t> in_set;   // vertex index is in the removal list
-    std::vector<RoundBlanket> rb;
-    std::vector<int32_t> rb_verts, rb_edges;
+    Batch bt[2];
+    Batch *B = &bt[0];                                // batch the round functions currently work on
     std::vector<int32_t> Dpool;                       // owner sets, flat
     std::vector<std::pair<int32_t, int32_t>> Dspan;   // (offset, length) per owner
-    std::vector<spg_blanket_desc> h_blk;
-    std::vector<int64_t> h_vpo;
-    std::vector<spg_edge_ref> h_er;
-    std::vector<int32_t> h_ev;
-    std::vector<int64_t> chunk_hdr;   // per rank: doubles of out records at the start of its chunk
-    spg_round_info rinfo{};
-    bool round_open = false;
-    bool used_mailbox = false;
     int shard_threshold = 2048;
-    int eff_ranks = 1, eff_rank = 0;   // ranks the current round is split over (1 = replicated round)
-    int round_no = 0;
+    int round_no = 0, launch_seq = 0;
+    bool pipelined = false;                           // two batches in flight (single rank, backend with slots)
     spg_marg_stats stats{};
     std::vector<BlanketLog> log;
     std::vector<double> hdr_buf;
@@ -624,14 +637,15 @@ static void new_edge_budget(const spg_options &o, int d, int k, int32_t &n_new_m
     }
 }
 
-// Select this round's mutually commuting blankets, in list order. Fills g->rb; rewrites g->pending.
+// Select this round's mutually commuting blankets, in list order. Fills bt.rb; rewrites g->pending.
 static void schedule_round(spg_graph *g) {
+    Batch &bt = *g->B;
     const spg_options &o = g->opts;
     const bool dense = dense_mode(o);
     const size_t DCAP = 512;
-    g->rb.clear();
-    g->rb_verts.clear();
-    g->rb_edges.clear();
+    bt.rb.clear();
+    bt.rb_verts.clear();
+    bt.rb_edges.clear();
     if (g->vowners.size() < g->vid.size()) g->vowners.resize(g->vid.size());
     for (int32_t v : g->touched) g->vowners[v].clear();
     g->touched.clear();
@@ -652,10 +666,24 @@ static void schedule_round(spg_graph *g) {
             g->vowners[x].push_back(oid);
         }
     };
-    for (size_t pos = 0; pos < g->pending.size(); pos++) {
+    // blankets of the batch that is still in flight: their removals are not in the host graph yet, so
+    // nothing that fails to commute with them may be selected now
+    bool inflight = false;
+    {
+        Batch &other = g->bt[&bt == &g->bt[0] ? 1 : 0];
+        inflight = other.round_open;
+        if (other.round_open)
+            for (const RoundBlanket &ob : other.rb) {
+                B.assign(other.rb_verts.begin() + ob.vbeg, other.rb_verts.begin() + ob.vbeg + ob.nv);
+                reg(B);
+            }
+    }
+    // The scan touches only a prefix of the pending list: entries that have to wait are written back
+    // right in front of the untouched tail, so a call costs O(scanned), not O(pending).
+    size_t pos = g->pend_head;
+    for (; pos < g->pending.size() && !stop; pos++) {
         int32_t v = g->pending[pos];
         if (!g->valive[v]) continue;  // absorbed by an earlier cluster (`deleted`, src/vertex_remover.cpp:91)
-        if (stop) { newpending.push_back(v); continue; }
         if (dense) extended_blanket(g, v, B, centres);
         else { closed_neighbourhood(g, v, B); centres.assign(1, v); }
         bool inD = false, conflict = false;
@@ -683,16 +711,16 @@ static void schedule_round(spg_graph *g) {
                 if (!is_c) tmp.push_back(x);
             }
             std::sort(tmp.begin(), tmp.end(), byid);
-            rbk.vbeg = (int32_t)g->rb_verts.size();
-            g->rb_verts.insert(g->rb_verts.end(), centres.begin(), centres.end());
-            g->rb_verts.insert(g->rb_verts.end(), tmp.begin(), tmp.end());
+            rbk.vbeg = (int32_t)bt.rb_verts.size();
+            bt.rb_verts.insert(bt.rb_verts.end(), centres.begin(), centres.end());
+            bt.rb_verts.insert(bt.rb_verts.end(), tmp.begin(), tmp.end());
             rbk.nv = (int32_t)(centres.size() + tmp.size());
-            collect_edges(g, g->rb_verts.data() + rbk.vbeg, rbk.nv, centres, o.include_intra_clique != 0, work);
-            rbk.ebeg = (int32_t)g->rb_edges.size();
+            collect_edges(g, bt.rb_verts.data() + rbk.vbeg, rbk.nv, centres, o.include_intra_clique != 0, work);
+            rbk.ebeg = (int32_t)bt.rb_edges.size();
             rbk.ne = (int32_t)work.size();
-            g->rb_edges.insert(g->rb_edges.end(), work.begin(), work.end());
+            bt.rb_edges.insert(bt.rb_edges.end(), work.begin(), work.end());
             reg(B);
-            g->rb.push_back(std::move(rbk));
+            bt.rb.push_back(std::move(rbk));
             consec = 0;
         } else {
             newpending.push_back(v);
@@ -734,14 +762,22 @@ static void schedule_round(spg_graph *g) {
                     }
                 }
             }
-            if (Dv.size() > DCAP) { stop = true; continue; }
+            if (Dv.size() > DCAP) { stop = true; continue; }  // (v is already in newpending; the loop ends here)
             reg(Dv);
             // stop scanning once a long run of list entries had to wait: whatever follows is
             // (almost always) waiting on them too, and not scanning only defers more
-            if (++consec > 48 + g->rb.size() / 8 || n_deferred > 256 + 2 * g->rb.size()) stop = true;
+            // (with another batch in flight the blocked stretch is usually exactly the part of the list
+            //  that waits for it: give up sooner, the next call comes right after that batch commits)
+            size_t patience = inflight ? 12 + bt.rb.size() / 16 : 48 + bt.rb.size() / 8;
+            if (++consec > patience || n_deferred > 256 + 2 * bt.rb.size()) stop = true;
         }
     }
-    g->pending.swap(newpending);
+    {
+        size_t nd = newpending.size();
+        size_t nh = pos - nd;
+        for (size_t i = 0; i < nd; i++) g->pending[nh + i] = newpending[i];
+        g->pend_head = nh;
+    }
 }
 
 // ================================================================================= rounds
@@ -752,6 +788,7 @@ extern "C" int spg_graph_marginalize_begin(spg_graph *g, const int32_t *which, i
     g->opts = *opts;
     g->rank = rank; g->nranks = nranks;
     g->pending.clear();
+    g->pend_head = 0;
     g->in_set.assign(g->vid.size(), 0);
     for (int i = 0; i < n; i++) {
         auto it = g->vidx.find(which[i]);
@@ -761,14 +798,23 @@ extern "C" int spg_graph_marginalize_begin(spg_graph *g, const int32_t *which, i
         g->in_set[it->second] = 1;
         g->pending.push_back(it->second);
     }
+    // room for the regions of the rounds to come (grown later if this estimate is short)
+    if (int rc = arena_ensure(g, g->used * 3 + (1 << 20))) return rc;
     if (int rc = sync_device(g)) return rc;
     g->active = true;
-    g->round_open = false;
+    g->bt[0].round_open = false;
+    g->bt[1].round_open = false;
+    g->bt[0].slot = 0; g->bt[1].slot = 1;
+    g->B = &g->bt[0];
     g->round_no = 0;
+    g->launch_seq = 0;
+    g->pipelined = false;
     g->stats = spg_marg_stats{};
     g->log.clear();
     return 0;
 }
+
+static int prepare_scheduled(spg_graph *g, spg_round_info *info, double t0);
 
 extern "C" int spg_graph_set_shard_threshold(spg_graph *g, int min_blankets) {
     if (!g || min_blankets < 0) return SPG_EINVAL;
@@ -777,23 +823,31 @@ extern "C" int spg_graph_set_shard_threshold(spg_graph *g, int min_blankets) {
 }
 
 extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
-    if (!g || !g->active || g->round_open) return SPG_ESTATE;
+    if (!g || !g->active) return SPG_ESTATE;
+    Batch &bt = *g->B;
+    if (bt.round_open) return SPG_ESTATE;
     double t0 = now_s();
     schedule_round(g);
     g->stats.schedule_seconds += now_s() - t0;
-    int B = (int)g->rb.size();
+    return prepare_scheduled(g, info, t0);
+}
+
+// descriptors + arena region for the blankets already selected into *g->B
+static int prepare_scheduled(spg_graph *g, spg_round_info *info, double t0) {
+    Batch &bt = *g->B;
+    int B = (int)bt.rb.size();
     if (B == 0) { g->stats.host_seconds += now_s() - t0; return 0; }
     const spg_options &o = g->opts;
     // small rounds are latency-bound: every rank computes them whole, nothing is exchanged
     const bool sharded = g->nranks > 1 && B >= g->shard_threshold;
-    g->eff_ranks = sharded ? g->nranks : 1;
-    g->eff_rank = sharded ? g->rank : 0;
-    const int d = g->d, nr = g->eff_ranks;
+    bt.eff_ranks = sharded ? g->nranks : 1;
+    bt.eff_rank = sharded ? g->rank : 0;
+    const int d = g->d, nr = bt.eff_ranks;
     // ---- contiguous, cost-balanced slices (cost ~ n^3 + E d^3)
     std::vector<double> cost(B);
     double total = 0;
     for (int b = 0; b < B; b++) {
-        RoundBlanket &r = g->rb[b];
+        RoundBlanket &r = bt.rb[b];
         double nn = (double)d * (r.nv - r.n_remove);
         cost[b] = nn * nn * nn + (double)r.ne * d * d * d + 1.0;
         total += cost[b];
@@ -811,27 +865,27 @@ extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
         first[nr] = B;
     }
     // ---- descriptors
-    g->h_blk.resize(B);
-    g->h_vpo.clear(); g->h_er.clear(); g->h_ev.clear();
-    g->chunk_hdr.assign(nr, 0);
+    bt.h_blk.resize(B);
+    bt.h_vpo.clear(); bt.h_er.clear(); bt.h_ev.clear();
+    bt.chunk_hdr.assign(nr, 0);
     std::vector<int64_t> chunk_len(nr, 0);
     if (g->lidx.size() < g->vid.size()) g->lidx.resize(g->vid.size(), -1);
     std::vector<int32_t> &lidx = g->lidx;
     for (int q = 0; q < nr; q++) {
         int64_t hdr = 0, body = 0;
         for (int b = first[q]; b < first[q + 1]; b++) {
-            RoundBlanket &r = g->rb[b];
+            RoundBlanket &r = bt.rb[b];
             r.rank = q;
             int k = r.nv - r.n_remove;
-            const int32_t *rverts = g->rb_verts.data() + r.vbeg;
-            const int32_t *redges = g->rb_edges.data() + r.ebeg;
-            spg_blanket_desc &bd = g->h_blk[b];
+            const int32_t *rverts = bt.rb_verts.data() + r.vbeg;
+            const int32_t *redges = bt.rb_edges.data() + r.ebeg;
+            spg_blanket_desc &bd = bt.h_blk[b];
             memset(&bd, 0, sizeof bd);
-            bd.vert_begin = (int32_t)g->h_vpo.size();
+            bd.vert_begin = (int32_t)bt.h_vpo.size();
             bd.n_vert = r.nv;
             bd.n_remove = r.n_remove;
-            for (int i = 0; i < r.nv; i++) { g->h_vpo.push_back(g->vpose[rverts[i]]); lidx[rverts[i]] = (int32_t)i; }
-            bd.edge_begin = (int32_t)g->h_er.size();
+            for (int i = 0; i < r.nv; i++) { bt.h_vpo.push_back(g->vpose[rverts[i]]); lidx[rverts[i]] = (int32_t)i; }
+            bd.edge_begin = (int32_t)bt.h_er.size();
             bd.n_edge = r.ne;
             int32_t scratch = 0;
             for (int ei_ = 0; ei_ < r.ne; ei_++) {
@@ -839,9 +893,9 @@ extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
                 const GEdge &e = g->edges[eid];
                 if (e.kind == SPG_EDGE_GLC) scratch = std::max(scratch, e.len - d * e.nv + e.nv * 2 * d * d);
                 spg_edge_ref er;
-                er.off = e.off; er.len = e.len; er.kind = e.kind; er.vbegin = (int32_t)g->h_ev.size(); er.nv = e.nv;
-                for (int i = 0; i < e.nv; i++) g->h_ev.push_back(lidx[g->everts[e.vbeg + i]]);
-                g->h_er.push_back(er);
+                er.off = e.off; er.len = e.len; er.kind = e.kind; er.vbegin = (int32_t)bt.h_ev.size(); er.nv = e.nv;
+                for (int i = 0; i < e.nv; i++) bt.h_ev.push_back(lidx[g->everts[e.vbeg + i]]);
+                bt.h_er.push_back(er);
             }
             new_edge_budget(o, d, k, bd.n_new_max, bd.n_new_vert_max, bd.new_len);
             bd.pad_ = scratch;  // doubles of assembly scratch the blanket's n-ary edges need (r*dq + q*2*d*d)
@@ -851,7 +905,7 @@ extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
             body += bd.new_len;
             bd.tinfo_off = -1;
         }
-        g->chunk_hdr[q] = hdr;
+        bt.chunk_hdr[q] = hdr;
         chunk_len[q] = hdr + body;
     }
     int64_t clen = 0;
@@ -860,55 +914,63 @@ extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
     int64_t region = align_up(g->used, 32);
     int64_t need = region + clen * nr;
     if (need > g->cap) {
-        // grow: pull device-only ranges into the mirror, re-allocate, push the whole mirror back
+        // grow: pull device-only ranges into the mirror, re-allocate, push the whole mirror back.
+        // Not while another batch is running (it writes into the arena): tell the driver to commit it first.
+        Batch &other = g->bt[&bt == &g->bt[0] ? 1 : 0];
+        if (other.round_open) return 2;
         if (int rc = arena_ensure(g, need + need / 2)) return rc;
         if (int rc = sync_device(g)) return rc;
     }
     for (int q = 0; q < nr; q++) {
         int64_t base = region + clen * q;
         for (int b = first[q]; b < first[q + 1]; b++) {
-            spg_blanket_desc &bd = g->h_blk[b];
+            spg_blanket_desc &bd = bt.h_blk[b];
             bd.out_off += base;
-            bd.new_off += base + g->chunk_hdr[q];
-            g->rb[b].desc = bd;
+            bd.new_off += base + bt.chunk_hdr[q];
+            bt.rb[b].desc = bd;
         }
     }
     if ((int64_t)g->host.size() < need) g->host.resize((size_t)need);
     g->used = need;
     g->dev_synced = need;  // the region is produced on the device
-    g->rinfo.n_blankets = B;
-    g->rinfo.my_first = first[g->eff_rank];
-    g->rinfo.my_count = first[g->eff_rank + 1] - first[g->eff_rank];
-    g->rinfo.region_off = region;
-    g->rinfo.chunk_len = clen;
-    g->rinfo.exchange = sharded ? 1 : 0;
-    g->rinfo.pad_ = 0;
-    if (info) *info = g->rinfo;
-    g->round_open = true;
+    bt.rinfo.n_blankets = B;
+    bt.rinfo.my_first = first[bt.eff_rank];
+    bt.rinfo.my_count = first[bt.eff_rank + 1] - first[bt.eff_rank];
+    bt.rinfo.region_off = region;
+    bt.rinfo.chunk_len = clen;
+    bt.rinfo.exchange = sharded ? 1 : 0;
+    bt.rinfo.pad_ = 0;
+    if (info) *info = bt.rinfo;
+    bt.round_open = true;
     g->round_no++;
+    bt.round_no = g->round_no;
+    bt.seq = g->launch_seq++;
     g->stats.host_seconds += now_s() - t0;
     return 1;
 }
 
 extern "C" int spg_graph_round_compute(spg_graph *g) {
-    if (!g || !g->active || !g->round_open) return SPG_ESTATE;
+    if (!g || !g->active) return SPG_ESTATE;
+    Batch &bt = *g->B;
+    if (!bt.round_open) return SPG_ESTATE;
     double t0 = now_s();
     spg_round_desc rd{};
     rd.opts = &g->opts;
-    rd.n_blankets = g->rinfo.n_blankets;
-    rd.first = g->rinfo.my_first;
-    rd.count = g->rinfo.my_count;
-    rd.blankets = g->h_blk.data();
-    rd.vert_pose_off = g->h_vpo.data();
-    rd.edges = g->h_er.data();
-    rd.edge_vert = g->h_ev.data();
-    rd.n_vert_total = (int64_t)g->h_vpo.size();
-    rd.n_edge_total = (int64_t)g->h_er.size();
-    rd.n_edge_vert_total = (int64_t)g->h_ev.size();
+    rd.n_blankets = bt.rinfo.n_blankets;
+    rd.first = bt.rinfo.my_first;
+    rd.count = bt.rinfo.my_count;
+    rd.blankets = bt.h_blk.data();
+    rd.vert_pose_off = bt.h_vpo.data();
+    rd.edges = bt.h_er.data();
+    rd.edge_vert = bt.h_ev.data();
+    rd.n_vert_total = (int64_t)bt.h_vpo.size();
+    rd.n_edge_total = (int64_t)bt.h_er.size();
+    rd.n_edge_vert_total = (int64_t)bt.h_ev.size();
     // single rank: let the kernel deliver the out records straight into the backend's host mailbox
-    rd.mail_base = g->rinfo.region_off + g->rinfo.chunk_len * g->eff_rank;
-    rd.mail_len = (g->eff_ranks == 1 && g->ctx->be.mailbox) ? g->chunk_hdr[g->eff_rank] : 0;
-    g->used_mailbox = rd.mail_len > 0;
+    rd.mail_base = bt.rinfo.region_off + bt.rinfo.chunk_len * bt.eff_rank;
+    rd.mail_len = (bt.eff_ranks == 1 && g->ctx->be.mailbox) ? bt.chunk_hdr[bt.eff_rank] : 0;
+    rd.slot = g->pipelined ? bt.slot : 0;
+    bt.used_mailbox = rd.mail_len > 0;
     int rc = g->ctx->be.run_round(g->ctx->be.user, g->dev, &rd);
     g->stats.device_seconds += now_s() - t0;
     if (rc && g->ctx->is_hip) snprintf(g->ctx->err, sizeof g->ctx->err, "%s", spg::hip_backend_error(&g->ctx->be));
@@ -916,39 +978,44 @@ extern "C" int spg_graph_round_compute(spg_graph *g) {
 }
 
 extern "C" int spg_graph_round_commit(spg_graph *g) {
-    if (!g || !g->active || !g->round_open) return SPG_ESTATE;
+    if (!g || !g->active) return SPG_ESTATE;
+    Batch &bt = *g->B;
+    if (!bt.round_open) return SPG_ESTATE;
     double t0 = now_s();
-    const int nr = g->eff_ranks;
-    int rc = g->ctx->be.synchronize(g->ctx->be.user);
+    const int nr = bt.eff_ranks;
+    const bool slotted = g->pipelined && g->ctx->be.synchronize_slot && g->ctx->be.mailbox_slot;
+    int rc = slotted ? g->ctx->be.synchronize_slot(g->ctx->be.user, bt.slot) : g->ctx->be.synchronize(g->ctx->be.user);
     if (rc) return rc;
     // read back the out-record part of every rank chunk (mailbox: already in host memory)
-    const double *mail = (g->used_mailbox && g->ctx->be.mailbox) ? g->ctx->be.mailbox(g->ctx->be.user) : nullptr;
+    const double *mail = nullptr;
+    if (bt.used_mailbox && g->ctx->be.mailbox)
+        mail = slotted ? g->ctx->be.mailbox_slot(g->ctx->be.user, bt.slot) : g->ctx->be.mailbox(g->ctx->be.user);
     for (int q = 0; q < nr; q++) {
-        if (g->chunk_hdr[q] == 0) continue;
-        int64_t base = g->rinfo.region_off + g->rinfo.chunk_len * q;
-        if (mail && q == g->eff_rank) { memcpy(g->host.data() + base, mail, (size_t)g->chunk_hdr[q] * 8); continue; }
-        rc = g->ctx->be.download(g->ctx->be.user, g->host.data() + base, (char *)g->dev + base * 8, g->chunk_hdr[q]);
+        if (bt.chunk_hdr[q] == 0) continue;
+        int64_t base = bt.rinfo.region_off + bt.rinfo.chunk_len * q;
+        if (mail && q == bt.eff_rank) { memcpy(g->host.data() + base, mail, (size_t)bt.chunk_hdr[q] * 8); continue; }
+        rc = g->ctx->be.download(g->ctx->be.user, g->host.data() + base, (char *)g->dev + base * 8, bt.chunk_hdr[q]);
         if (rc) return rc;
     }
     double t1 = now_s();
     g->stats.device_seconds += t1 - t0;
     // the payload part of the region stays device-only until someone asks for it
     {
-        int64_t lo = g->rinfo.region_off, hi = g->rinfo.region_off + g->rinfo.chunk_len * nr;
+        int64_t lo = bt.rinfo.region_off, hi = bt.rinfo.region_off + bt.rinfo.chunk_len * nr;
         if (g->stale_hi <= g->stale_lo) { g->stale_lo = lo; g->stale_hi = hi; }
         else { g->stale_lo = std::min(g->stale_lo, lo); g->stale_hi = std::max(g->stale_hi, hi); }
     }
     // updateInputGraph (src/vertex_remover.cpp:500-546), in list order
     std::vector<int32_t> vix;
-    for (size_t b = 0; b < g->rb.size(); b++) {
-        RoundBlanket &r = g->rb[b];
+    for (size_t b = 0; b < bt.rb.size(); b++) {
+        RoundBlanket &r = bt.rb[b];
         const spg_blanket_desc &bd = r.desc;
         const double *rec = g->host.data() + bd.out_off;
         int status = (int)rec[0], inf = (int)rec[1], n_new = (int)rec[4];
-        g->log.push_back({g->vid[r.root], g->round_no, status, inf, rec[2], rec[3]});
+        g->log.push_back({g->vid[r.root], bt.round_no, status, inf, rec[2], rec[3]});
         g->stats.max_blanket = std::max(g->stats.max_blanket, r.nv);
-        const int32_t *rverts = g->rb_verts.data() + r.vbeg;
-        const int32_t *redges = g->rb_edges.data() + r.ebeg;
+        const int32_t *rverts = bt.rb_verts.data() + r.vbeg;
+        const int32_t *redges = bt.rb_edges.data() + r.ebeg;
         bool fine = (status == SPG_OK || status == SPG_ST_KLD_NOT_PD);
         if (!fine) { g->stats.n_bad_status++; continue; }
         if (std::isfinite(rec[2])) g->stats.kld_sum += rec[2];
@@ -982,7 +1049,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
             g->stats.n_new_edges++;
         }
     }
-    g->round_open = false;
+    bt.round_open = false;
     g->stats.n_rounds = g->round_no;
     g->stats.host_seconds += now_s() - t1;
     g->stats.commit_seconds += now_s() - t1;
@@ -992,22 +1059,98 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
 extern "C" int spg_graph_marginalize_end(spg_graph *g, spg_marg_stats *stats) {
     if (!g || !g->active) return SPG_ESTATE;
     g->active = false;
-    g->round_open = false;
+    g->bt[0].round_open = false;
+    g->bt[1].round_open = false;
+    g->B = &g->bt[0];
     if (g->ctx->is_hip) g->stats.n_launches = spg::hip_backend_launches(&g->ctx->be);
     if (stats) *stats = g->stats;
     return g->stats.n_bad_status ? SPG_EBLANKET : 0;
+}
+
+// Move the second half of a freshly scheduled batch into the other (idle) batch: both halves are
+// mutually independent, so they can be launched back to back on the two slots.
+static void split_batch(spg_graph *g, Batch &a, Batch &b) {
+    size_t keep = a.rb.size() / 2;
+    b.rb.clear(); b.rb_verts.clear(); b.rb_edges.clear();
+    for (size_t i = keep; i < a.rb.size(); i++) {
+        RoundBlanket r = a.rb[i];
+        int32_t vb = (int32_t)b.rb_verts.size(), eb = (int32_t)b.rb_edges.size();
+        b.rb_verts.insert(b.rb_verts.end(), a.rb_verts.begin() + r.vbeg, a.rb_verts.begin() + r.vbeg + r.nv);
+        b.rb_edges.insert(b.rb_edges.end(), a.rb_edges.begin() + r.ebeg, a.rb_edges.begin() + r.ebeg + r.ne);
+        r.vbeg = vb; r.ebeg = eb;
+        b.rb.push_back(r);
+    }
+    a.rb.resize(keep);
 }
 
 extern "C" int spg_graph_marginalize(spg_graph *g, const int32_t *which, int n, const spg_options *opts, spg_marg_stats *stats) {
     int launches0 = (g && g->ctx->is_hip) ? spg::hip_backend_launches(&g->ctx->be) : 0;
     int rc = spg_graph_marginalize_begin(g, which, n, opts, 0, 1);
     if (rc) return rc;
-    for (;;) {
-        rc = spg_graph_round_prepare(g, nullptr);
-        if (rc < 0) break;
-        if (rc == 0) break;
-        if ((rc = spg_graph_round_compute(g)) != 0) break;
-        if ((rc = spg_graph_round_commit(g)) != 0) break;
+    const char *env = getenv("SPG_NO_PIPELINE");
+    g->pipelined = g->ctx->be.synchronize_slot && g->ctx->be.mailbox_slot && !(env && env[0] == '1');
+    if (!g->pipelined) {
+        for (;;) {
+            rc = spg_graph_round_prepare(g, nullptr);
+            if (rc <= 0) break;
+            if ((rc = spg_graph_round_compute(g)) != 0) break;
+            if ((rc = spg_graph_round_commit(g)) != 0) break;
+        }
+    } else {
+        // Two batches in flight. Whenever a slot is idle, schedule whatever commutes with the batch
+        // still running (and with everything earlier in the list) and launch it; otherwise wait for
+        // the older batch, apply its graph update, and try again. A batch scheduled while nothing is
+        // running is cut in two so that both slots start working at once.
+        rc = 0;
+        for (;;) {
+            bool launched = false;
+            for (int s_ = 0; s_ < 2 && rc == 0; s_++) {
+                Batch &bt = g->bt[s_], &other = g->bt[1 - s_];
+                if (bt.round_open || g->pend_head >= g->pending.size()) continue;
+                g->B = &bt;
+                double t0 = now_s();
+                schedule_round(g);
+                g->stats.schedule_seconds += now_s() - t0;
+                if (bt.rb.empty()) { g->stats.host_seconds += now_s() - t0; continue; }
+                bool do_split = !other.round_open && bt.rb.size() >= 64;
+                if (do_split) split_batch(g, bt, other);
+                int prc = prepare_scheduled(g, nullptr, t0);
+                if (prc == 2) {  // the arena has to grow: finish the running batch, then prepare again
+                    g->B = &other;
+                    if ((rc = spg_graph_round_commit(g)) != 0) break;
+                    g->B = &bt;
+                    prc = prepare_scheduled(g, nullptr, now_s());
+                }
+                if (prc < 0) { rc = prc; break; }
+                if ((rc = spg_graph_round_compute(g)) != 0) break;
+                launched = true;
+                if (do_split) {
+                    g->B = &other;
+                    prc = prepare_scheduled(g, nullptr, now_s());
+                    if (prc == 2) {
+                        g->B = &bt;
+                        if ((rc = spg_graph_round_commit(g)) != 0) break;
+                        g->B = &other;
+                        prc = prepare_scheduled(g, nullptr, now_s());
+                    }
+                    if (prc < 0) { rc = prc; break; }
+                    if ((rc = spg_graph_round_compute(g)) != 0) break;
+                }
+            }
+            if (rc != 0) break;
+            Batch *oldest = nullptr;
+            for (int s_ = 0; s_ < 2; s_++)
+                if (g->bt[s_].round_open && (!oldest || g->bt[s_].seq < oldest->seq)) oldest = &g->bt[s_];
+            if (!oldest) {
+                if (!launched) break;  // nothing in flight, nothing schedulable: done
+                continue;
+            }
+            g->B = oldest;
+            if ((rc = spg_graph_round_commit(g)) != 0) break;
+        }
+        // drain on error
+        for (int s_ = 0; s_ < 2; s_++) if (g->bt[s_].round_open) { g->ctx->be.synchronize(g->ctx->be.user); g->bt[s_].round_open = false; }
+        g->B = &g->bt[0];
     }
     int rc2 = spg_graph_marginalize_end(g, stats);
     if (stats && g->ctx->is_hip) stats->n_launches -= launches0;

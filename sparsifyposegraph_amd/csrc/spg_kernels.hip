@@ -1109,48 +1109,52 @@ namespace spg {
 
 struct HipBackend {
     int device = 0;
-    hipStream_t stream = nullptr;
     char err[512] = {0};
-    // device-side descriptor buffers (grown on demand)
-    void *d_desc = nullptr, *d_gws = nullptr;
-    size_t c_desc = 0, c_gws = 0;
-    // pinned host mailbox the kernel writes out records into (device-visible)
-    void *h_mail = nullptr, *d_mail = nullptr;
-    size_t c_mail = 0;
-    // pinned host staging
-    void *h_stage = nullptr;
-    size_t c_stage = 0;
+    struct Timed { hipEvent_t a, b; double bytes; int blankets; };
+    // Two independent launch slots (stream + descriptor buffers + pinned staging + pinned mailbox +
+    // large-blanket workspace) so that the host can prepare and launch one batch of blankets while the
+    // previous one is still running.
+    struct Slot {
+        hipStream_t stream = nullptr;
+        void *d_desc = nullptr, *d_gws = nullptr;
+        size_t c_desc = 0, c_gws = 0;
+        void *h_mail = nullptr, *d_mail = nullptr;   // pinned host mailbox the kernel writes out records into
+        size_t c_mail = 0;
+        void *h_stage = nullptr;                      // pinned host staging for the descriptor upload
+        size_t c_stage = 0;
+        std::vector<Timed> pending;
+    };
+    static constexpr int NSLOT = 2;
+    Slot slots[NSLOT];
     int lds_limit = 160 * 1024;
     int n_launches = 0;
     bool force_one_wave = false;  // SPG_ONE_WAVE=1: never use the two-wavefront latency variant (A/B timing)
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
     bool profiling = false;
-    struct Timed { hipEvent_t a, b; double bytes; int blankets; };
-    std::vector<Timed> pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     double prof_ms = 0, prof_bytes = 0;
     long long prof_launches = 0, prof_blankets = 0;
 
-    int ensure(void **p, size_t *cap, size_t need) {
+    int ensure(Slot &S, void **p, size_t *cap, size_t need) {
         if (need <= *cap) return 0;
         size_t nc = std::max(need, *cap * 2);
-        if (*p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(*p)); *p = nullptr; }
+        if (*p) { HIPCHK(hipStreamSynchronize(S.stream)); HIPCHK(hipFree(*p)); *p = nullptr; }
         HIPCHK(hipMalloc(p, nc));
         *cap = nc;
         return 0;
     }
-    int ensure_stage(size_t need) {
-        if (need <= c_stage) return 0;
-        size_t nc = std::max(need, c_stage * 2);
-        if (h_stage) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipHostFree(h_stage)); h_stage = nullptr; }
-        HIPCHK(hipHostMalloc(&h_stage, nc, hipHostMallocDefault));
-        c_stage = nc;
+    int ensure_stage(Slot &S, size_t need) {
+        if (need <= S.c_stage) return 0;
+        size_t nc = std::max(need, S.c_stage * 2);
+        if (S.h_stage) { HIPCHK(hipStreamSynchronize(S.stream)); HIPCHK(hipHostFree(S.h_stage)); S.h_stage = nullptr; }
+        HIPCHK(hipHostMalloc(&S.h_stage, nc, hipHostMallocDefault));
+        S.c_stage = nc;
         return 0;
     }
 };
 
 template <int D, int NT, bool GWS, int ALG>
-static int launch_bin(HipBackend *hb, const KArgs &ka, int nblocks, size_t lds_bytes, double alg_bytes) {
+static int launch_bin(HipBackend *hb, HipBackend::Slot &S, const KArgs &ka, int nblocks, size_t lds_bytes, double alg_bytes) {
     char *err = hb->err;
     auto kern = blanket_kernel<D, NT, GWS, ALG>;
     if (lds_bytes > 64 * 1024)
@@ -1162,33 +1166,34 @@ static int launch_bin(HipBackend *hb, const KArgs &ka, int nblocks, size_t lds_b
             HIPCHK(hipEventCreate(&t.b));
         } else { t.a = hb->pool.back().first; t.b = hb->pool.back().second; hb->pool.pop_back(); }
         t.bytes = alg_bytes; t.blankets = nblocks;
-        HIPCHK(hipEventRecord(t.a, hb->stream));
+        HIPCHK(hipEventRecord(t.a, S.stream));
     }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), lds_bytes, hb->stream, ka);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), lds_bytes, S.stream, ka);
     HIPCHK(hipGetLastError());
     if (hb->profiling) {
-        HIPCHK(hipEventRecord(t.b, hb->stream));
-        hb->pending.push_back(t);
+        HIPCHK(hipEventRecord(t.b, S.stream));
+        S.pending.push_back(t);
     }
     hb->n_launches++;
     return 0;
 }
 
-static void drain_profile(HipBackend *hb) {
-    for (auto &t : hb->pending) {
+static void drain_profile(HipBackend *hb, HipBackend::Slot &S) {
+    for (auto &t : S.pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
             hb->prof_ms += ms; hb->prof_bytes += t.bytes; hb->prof_launches++; hb->prof_blankets += t.blankets;
         }
         hb->pool.push_back({t.a, t.b});
     }
-    hb->pending.clear();
+    S.pending.clear();
 }
 
 static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     HipBackend *hb = (HipBackend *)user;
     char *err = hb->err;
     if (rd->count <= 0) return 0;
+    HipBackend::Slot &S = hb->slots[rd->slot & (HipBackend::NSLOT - 1)];
     const spg_options &o = *rd->opts;
     const int D = o.pose_dim;
     if (D != 3 && D != 6) return SPG_EINVAL;
@@ -1229,11 +1234,11 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     size_t tot = o_list + al(s_list);
     HIPCHK(hipSetDevice(hb->device));
     // the previous round's copy must have drained before the staging buffer is rewritten
-    HIPCHK(hipStreamSynchronize(hb->stream));
-    drain_profile(hb);
-    if (int rc = hb->ensure_stage(tot)) return rc;
-    if (int rc = hb->ensure(&hb->d_desc, &hb->c_desc, tot)) return rc;
-    char *st = (char *)hb->h_stage;
+    HIPCHK(hipStreamSynchronize(S.stream));
+    drain_profile(hb, S);
+    if (int rc = hb->ensure_stage(S, tot)) return rc;
+    if (int rc = hb->ensure(S, &S.d_desc, &S.c_desc, tot)) return rc;
+    char *st = (char *)S.h_stage;
     memcpy(st + o_blk, rd->blankets, s_blk);
     memcpy(st + o_vpo, rd->vert_pose_off, s_vpo);
     memcpy(st + o_er, rd->edges, s_er);
@@ -1244,26 +1249,26 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         for (int i = 0; i < NB; i++) for (int32_t b : bins[i].list) lst[p++] = b;
     }
     // one host->device copy for all descriptors of the round
-    HIPCHK(hipMemcpyAsync(hb->d_desc, st, tot, hipMemcpyHostToDevice, hb->stream));
+    HIPCHK(hipMemcpyAsync(S.d_desc, st, tot, hipMemcpyHostToDevice, S.stream));
     double *mail_dev = nullptr;
     if (rd->mail_len > 0) {
         size_t need = (size_t)rd->mail_len * 8;
-        if (need > hb->c_mail) {
-            if (hb->h_mail) HIPCHK(hipHostFree(hb->h_mail));
-            size_t nc = std::max(need, hb->c_mail * 2);
-            HIPCHK(hipHostMalloc(&hb->h_mail, nc, hipHostMallocMapped));
-            HIPCHK(hipHostGetDevicePointer(&hb->d_mail, hb->h_mail, 0));
-            hb->c_mail = nc;
+        if (need > S.c_mail) {
+            if (S.h_mail) HIPCHK(hipHostFree(S.h_mail));
+            size_t nc = std::max(need, S.c_mail * 2);
+            HIPCHK(hipHostMalloc(&S.h_mail, nc, hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer(&S.d_mail, S.h_mail, 0));
+            S.c_mail = nc;
         }
-        mail_dev = (double *)hb->d_mail;
+        mail_dev = (double *)S.d_mail;
     }
     // ---- launch each non-empty bin
     KArgs ka;
     ka.arena = (double *)arena;
-    ka.blk = (const spg_blanket_desc *)((char *)hb->d_desc + o_blk);
-    ka.vpo = (const int64_t *)((char *)hb->d_desc + o_vpo);
-    ka.er = (const spg_edge_ref *)((char *)hb->d_desc + o_er);
-    ka.ev = (const int32_t *)((char *)hb->d_desc + o_ev);
+    ka.blk = (const spg_blanket_desc *)((char *)S.d_desc + o_blk);
+    ka.vpo = (const int64_t *)((char *)S.d_desc + o_vpo);
+    ka.er = (const spg_edge_ref *)((char *)S.d_desc + o_er);
+    ka.ev = (const int32_t *)((char *)S.d_desc + o_ev);
     ka.mail = mail_dev;
     ka.mail_base = rd->mail_base;
     ka.gws = nullptr; ka.gws_stride = 0;
@@ -1272,7 +1277,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     for (int i = 0; i < NB; i++) {
         int nb = (int)bins[i].list.size();
         if (nb == 0) continue;
-        ka.list = (const int32_t *)((char *)hb->d_desc + o_list) + list_off;
+        ka.list = (const int32_t *)((char *)S.d_desc + o_list) + list_off;
         list_off += nb;
         int rc;
         if (i < NB - 1) {
@@ -1287,23 +1292,23 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
             if (two_waves) {
                 Layout L2 = make_layout(D, 128, bins[i].kmax, bins[i].mmax, o.algorithm, o.topology, bins[i].smax);
                 size_t lds2 = std::min((size_t)(L2.small_doubles + L2.mat_doubles) * 8, (size_t)hb->lds_limit);
-                rc = (D == 6) ? launch_bin<6, 128, false, SPG_ALG_NFR>(hb, ka, nb, lds2, bins[i].bytes) : launch_bin<3, 128, false, SPG_ALG_NFR>(hb, ka, nb, lds2, bins[i].bytes);
+                rc = (D == 6) ? launch_bin<6, 128, false, SPG_ALG_NFR>(hb, S, ka, nb, lds2, bins[i].bytes) : launch_bin<3, 128, false, SPG_ALG_NFR>(hb, S, ka, nb, lds2, bins[i].bytes);
             } else if (o.algorithm == SPG_ALG_GLC)
-                rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_GLC>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_GLC>(hb, ka, nb, lds, bins[i].bytes);
+                rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_GLC>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_GLC>(hb, S, ka, nb, lds, bins[i].bytes);
             else
-                rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_NFR>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_NFR>(hb, ka, nb, lds, bins[i].bytes);
+                rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes);
         } else {
             Layout L = make_layout(D, 256, bins[i].kmax, bins[i].mmax, o.algorithm, o.topology, bins[i].smax);
             size_t lds = (size_t)L.small_doubles * 8;
             if (lds > (size_t)hb->lds_limit) { snprintf(err, sizeof hb->err, "blanket too large for LDS side buffers: k=%d m=%d", bins[i].kmax, bins[i].mmax); return SPG_ECAPACITY; }
             size_t stride = ((size_t)L.mat_doubles + 31) & ~(size_t)31;
-            if (int rc2 = hb->ensure(&hb->d_gws, &hb->c_gws, stride * 8 * (size_t)nb)) return rc2;
-            ka.gws = (double *)hb->d_gws;
+            if (int rc2 = hb->ensure(S, &S.d_gws, &S.c_gws, stride * 8 * (size_t)nb)) return rc2;
+            ka.gws = (double *)S.d_gws;
             ka.gws_stride = (int64_t)stride;
             if (o.algorithm == SPG_ALG_GLC)
-                rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_GLC>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_GLC>(hb, ka, nb, lds, bins[i].bytes);
+                rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_GLC>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_GLC>(hb, S, ka, nb, lds, bins[i].bytes);
             else
-                rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_NFR>(hb, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_NFR>(hb, ka, nb, lds, bins[i].bytes);
+                rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes);
         }
         if (rc) return rc;
     }
@@ -1319,32 +1324,43 @@ static void *hip_alloc(void *user, int64_t doubles) {
 }
 static void hip_release(void *user, void *p) {
     HipBackend *hb = (HipBackend *)user;
-    (void)hipStreamSynchronize(hb->stream);
+    (void)hipStreamSynchronize(hb->slots[0].stream);
     (void)hipFree(p);
 }
 static int hip_upload(void *user, void *dst, const double *src, int64_t doubles) {
     HipBackend *hb = (HipBackend *)user;
     char *err = hb->err;
-    HIPCHK(hipMemcpyAsync(dst, src, (size_t)doubles * 8, hipMemcpyHostToDevice, hb->stream));
-    HIPCHK(hipStreamSynchronize(hb->stream));
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)doubles * 8, hipMemcpyHostToDevice, hb->slots[0].stream));
+    HIPCHK(hipStreamSynchronize(hb->slots[0].stream));
     return 0;
 }
 static int hip_download(void *user, double *dst, const void *src, int64_t doubles) {
     HipBackend *hb = (HipBackend *)user;
     char *err = hb->err;
-    HIPCHK(hipMemcpyAsync(dst, src, (size_t)doubles * 8, hipMemcpyDeviceToHost, hb->stream));
-    HIPCHK(hipStreamSynchronize(hb->stream));
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)doubles * 8, hipMemcpyDeviceToHost, hb->slots[0].stream));
+    HIPCHK(hipStreamSynchronize(hb->slots[0].stream));
     return 0;
 }
 static int hip_sync(void *user) {
     HipBackend *hb = (HipBackend *)user;
     char *err = hb->err;
-    HIPCHK(hipStreamSynchronize(hb->stream));
-    drain_profile(hb);
+    for (auto &S : hb->slots) {
+        HIPCHK(hipStreamSynchronize(S.stream));
+        drain_profile(hb, S);
+    }
+    return 0;
+}
+static int hip_sync_slot(void *user, int slot) {
+    HipBackend *hb = (HipBackend *)user;
+    char *err = hb->err;
+    HipBackend::Slot &S = hb->slots[slot & (HipBackend::NSLOT - 1)];
+    HIPCHK(hipStreamSynchronize(S.stream));
+    drain_profile(hb, S);
     return 0;
 }
 
-static const double *hip_mailbox(void *user) { return (const double *)((HipBackend *)user)->h_mail; }
+static const double *hip_mailbox(void *user) { return (const double *)((HipBackend *)user)->slots[0].h_mail; }
+static const double *hip_mailbox_slot(void *user, int slot) { return (const double *)((HipBackend *)user)->slots[slot & (HipBackend::NSLOT - 1)].h_mail; }
 
 int hip_backend_create(int device, spg_backend *out, char *errbuf, size_t errlen) {
     int ndev = 0;
@@ -1362,7 +1378,9 @@ int hip_backend_create(int device, spg_backend *out, char *errbuf, size_t errlen
     }
     HipBackend *hb = new HipBackend;
     hb->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&hb->stream, hipStreamNonBlocking) != hipSuccess) {
+    bool okc = hipSetDevice(device) == hipSuccess;
+    for (auto &S : hb->slots) okc = okc && hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) == hipSuccess;
+    if (!okc) {
         snprintf(errbuf, errlen, "cannot create HIP stream on device %d", device);
         delete hb;
         return SPG_EHIP;
@@ -1377,6 +1395,8 @@ int hip_backend_create(int device, spg_backend *out, char *errbuf, size_t errlen
     out->run_round = hip_run_round;
     out->synchronize = hip_sync;
     out->mailbox = hip_mailbox;
+    out->synchronize_slot = hip_sync_slot;
+    out->mailbox_slot = hip_mailbox_slot;
     return 0;
 }
 
@@ -1384,17 +1404,19 @@ void hip_backend_destroy(spg_backend *b) {
     HipBackend *hb = (HipBackend *)b->user;
     if (!hb) return;
     (void)hipSetDevice(hb->device);
-    (void)hipStreamSynchronize(hb->stream);
-    if (hb->d_desc) (void)hipFree(hb->d_desc);
-    if (hb->d_gws) (void)hipFree(hb->d_gws);
-    if (hb->h_mail) (void)hipHostFree(hb->h_mail);
-    if (hb->h_stage) (void)hipHostFree(hb->h_stage);
-    (void)hipStreamDestroy(hb->stream);
+    for (auto &S : hb->slots) {
+        (void)hipStreamSynchronize(S.stream);
+        if (S.d_desc) (void)hipFree(S.d_desc);
+        if (S.d_gws) (void)hipFree(S.d_gws);
+        if (S.h_mail) (void)hipHostFree(S.h_mail);
+        if (S.h_stage) (void)hipHostFree(S.h_stage);
+        (void)hipStreamDestroy(S.stream);
+    }
     delete hb;
     b->user = nullptr;
 }
 
-void *hip_backend_stream(spg_backend *b) { return b->user ? (void *)((HipBackend *)b->user)->stream : nullptr; }
+void *hip_backend_stream(spg_backend *b) { return b->user ? (void *)((HipBackend *)b->user)->slots[0].stream : nullptr; }
 const char *hip_backend_error(spg_backend *b) { return b->user ? ((HipBackend *)b->user)->err : ""; }
 int hip_backend_launches(spg_backend *b) { return b->user ? ((HipBackend *)b->user)->n_launches : 0; }
 void hip_backend_profile(spg_backend *b, int enable) {

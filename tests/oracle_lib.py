@@ -163,7 +163,7 @@ class OracleBackend:
 
         self.cb = (abi._ALLOC(_alloc), abi._RELEASE(_release), abi._UPLOAD(_upload), abi._DOWNLOAD(_download),
                    abi._RUN_ROUND(_run_round), abi._SYNC(_sync))
-        self.struct = abi.Backend(None, *self.cb, abi._MAILBOX())
+        self.struct = abi.Backend(None, *self.cb, abi._MAILBOX(), abi._SYNC_SLOT(), abi._MAILBOX_SLOT())
 
 
 def injected_context():
