@@ -130,13 +130,17 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
             if world == 1 and args.poses == 100000 and args.ring == 400:
-                traffic = pm["traffic_bytes_per_launch_uncorrected"]
+                # the PMC passes see the same launches; scale to this run's launch count
+                traffic = pm["traffic_bytes_total_uncorrected_per_step"] * args.steps / prof["launches"]
                 traffic_note = "profiles/r01_pmc_summary.json: (FETCH_SIZE + WRITE_SIZE) * 1024 per launch, separate --pmc passes, uncorrected (8 B/lane gathers are outside the guide's calibration; includes instruction fetch)"
         except Exception:
             pass
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic, "traffic_note": traffic_note, "kernel": "blanket_kernel<6,64,false,NFR>", "launches": prof["launches"],
+            "traffic": traffic, "traffic_note": traffic_note,
+            # launches of <= 512 blankets give every blanket two wavefronts (NT = 128), larger ones one (NT = 64)
+            "kernel": "blanket_kernel<6,128,false,NFR>" if prof["blankets"] / prof["launches"] <= 512 else "blanket_kernel<6,64,false,NFR>",
+            "launches": prof["launches"],
             "avg_launch_us": 1e6 * per_launch_s, "alg_bytes_per_launch": per_launch_bytes,
             "blankets_per_launch": prof["blankets"] / prof["launches"],
             "note": "path is fp64-ALU/latency-bound on paper (SURVEY.md 8d: ~110 flop/B); fp64 vector fraction alongside",

@@ -194,6 +194,14 @@ typedef struct {
  * (src/graph_wrapper_g2o.cpp:462) — LM is outside the accelerated path. */
 int spg_graph_marginalize(spg_graph *g, const int32_t *which, int n, const spg_options *opts,
                           spg_marg_stats *stats);
+/* The same call for nranks cooperating processes (one per GPU), each holding an identical replica:
+ * batches below the shard threshold are computed redundantly by every rank (no communication);
+ * a batch at or above it is sharded, and `exchange` is called once for it — it must all-gather the
+ * nranks equal chunks of arena[region_off, region_off + nranks*chunk_len) in place (rank r owns
+ * chunk r), e.g. ncclAllGather / torch.distributed.all_gather_into_tensor, and return 0. */
+typedef int (*spg_exchange_fn)(void *user, void *arena, int64_t region_off, int64_t chunk_len, int nranks, int rank);
+int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, int n, const spg_options *opts, int rank, int nranks,
+                                spg_exchange_fn exchange, void *exchange_user, spg_marg_stats *stats);
 /* per-removed-vertex diagnostics of the last marginalize call, in processing order */
 int spg_graph_last_blanket_count(const spg_graph *g);
 int spg_graph_last_blankets(const spg_graph *g, int32_t *root_id, int32_t *round, int32_t *status,

@@ -93,6 +93,7 @@ _DOWNLOAD = C.CFUNCTYPE(C.c_int, C.c_void_p, _f64p, C.c_void_p, C.c_int64)
 _RUN_ROUND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(RoundDesc))
 _SYNC = C.CFUNCTYPE(C.c_int, C.c_void_p)
 _MAILBOX = C.CFUNCTYPE(C.c_void_p, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int)
 _SYNC_SLOT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 _MAILBOX_SLOT = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int)
 

@@ -1084,16 +1084,29 @@ static void split_batch(spg_graph *g, Batch &a, Batch &b) {
 }
 
 extern "C" int spg_graph_marginalize(spg_graph *g, const int32_t *which, int n, const spg_options *opts, spg_marg_stats *stats) {
+    return spg_graph_marginalize_ranks(g, which, n, opts, 0, 1, nullptr, nullptr, stats);
+}
+
+extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, int n, const spg_options *opts, int rank, int nranks,
+                                           spg_exchange_fn exchange, void *exchange_user, spg_marg_stats *stats) {
+    if (nranks > 1 && !exchange) return SPG_EINVAL;
     int launches0 = (g && g->ctx->is_hip) ? spg::hip_backend_launches(&g->ctx->be) : 0;
-    int rc = spg_graph_marginalize_begin(g, which, n, opts, 0, 1);
+    int rc = spg_graph_marginalize_begin(g, which, n, opts, rank, nranks);
     if (rc) return rc;
     const char *env = getenv("SPG_NO_PIPELINE");
     g->pipelined = g->ctx->be.synchronize_slot && g->ctx->be.mailbox_slot && !(env && env[0] == '1');
+    auto do_exchange = [&](Batch &b) -> int {
+        if (!b.rinfo.exchange) return 0;
+        int erc = g->ctx->be.synchronize(g->ctx->be.user);  // this rank's chunk is complete in memory
+        if (erc) return erc;
+        return exchange(exchange_user, g->dev, b.rinfo.region_off, b.rinfo.chunk_len, g->nranks, g->rank);
+    };
     if (!g->pipelined) {
         for (;;) {
             rc = spg_graph_round_prepare(g, nullptr);
             if (rc <= 0) break;
             if ((rc = spg_graph_round_compute(g)) != 0) break;
+            if ((rc = do_exchange(*g->B)) != 0) break;
             if ((rc = spg_graph_round_commit(g)) != 0) break;
         }
     } else {
@@ -1112,6 +1125,18 @@ extern "C" int spg_graph_marginalize(spg_graph *g, const int32_t *which, int n, 
                 schedule_round(g);
                 g->stats.schedule_seconds += now_s() - t0;
                 if (bt.rb.empty()) { g->stats.host_seconds += now_s() - t0; continue; }
+                if (g->nranks > 1 && (int)bt.rb.size() >= g->shard_threshold) {
+                    // a wide batch: worth sharding over the ranks. Finish what is in flight, then run it
+                    // as one exchanged round (compute own slice, all-gather, commit).
+                    if (other.round_open) { g->B = &other; if ((rc = spg_graph_round_commit(g)) != 0) break; g->B = &bt; }
+                    int prc = prepare_scheduled(g, nullptr, t0);
+                    if (prc < 0) { rc = prc; break; }
+                    if ((rc = spg_graph_round_compute(g)) != 0) break;
+                    if ((rc = do_exchange(bt)) != 0) break;
+                    if ((rc = spg_graph_round_commit(g)) != 0) break;
+                    launched = true;
+                    continue;
+                }
                 bool do_split = !other.round_open && bt.rb.size() >= 64;
                 if (do_split) split_batch(g, bt, other);
                 int prc = prepare_scheduled(g, nullptr, t0);

@@ -47,6 +47,7 @@ SYMBOLS = {
     "spg_graph_get_edges": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i64p, _f64p]),
     "spg_graph_set_estimate": (C.c_int, [C.c_void_p, C.c_int, _f64p]),
     "spg_graph_marginalize": (C.c_int, [C.c_void_p, _i32p, C.c_int, C.POINTER(abi.Options), C.POINTER(abi.MargStats)]),
+    "spg_graph_marginalize_ranks": (C.c_int, [C.c_void_p, _i32p, C.c_int, C.POINTER(abi.Options), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(abi.MargStats)]),
     "spg_graph_last_blanket_count": (C.c_int, [C.c_void_p]),
     "spg_graph_last_blankets": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _f64p, _f64p]),
     "spg_graph_substitute_edge": (C.c_int, [C.c_void_p, _i32p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _f64p, _f64p]),

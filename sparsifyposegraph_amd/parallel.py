@@ -36,19 +36,52 @@ def arena_tensor(graph, device=None):
     return torch.from_numpy(np.ctypeslib.as_array(buf))
 
 
-def marginalize_sharded(graph, which, opts, device=None, group=None):
+def marginalize_sharded(graph, which, opts, device=None, group=None, stepwise=False):
     """Run graph.marginalizeNoOptimize(which) cooperatively on every rank of `group`.
 
     Every rank must call this with identical arguments on an identical replica. Returns the
     per-rank stats dict (identical on all ranks except timing fields).
+
+    Default: the library's own (pipelined) driver, `spg_graph_marginalize_ranks`, which calls back
+    into `exchange` only for batches wide enough to be sharded. `stepwise=True` drives the
+    round-stepping ABI from Python instead (one batch at a time; used by tests).
     """
     import torch
     import torch.distributed as dist
+    from . import abi
+    from .lib import check
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     on_gpu = device is not None and str(device).startswith("cuda")
+    state = {"view": None, "ptr": None}
+
+    def all_gather_region(arena_ptr, region_off, chunk_len):
+        if arena_ptr != state["ptr"]:  # the arena may be re-allocated while a batch is prepared
+            state["view"], state["ptr"] = arena_tensor(graph, device), arena_ptr
+        region = state["view"][region_off:region_off + ws * chunk_len]
+        mine = region[rank * chunk_len:(rank + 1) * chunk_len]
+        dist.all_gather_into_tensor(region, mine, group=group)
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    if not stepwise:
+        def _cb(user, arena, region_off, chunk_len, nranks, r):
+            try:
+                all_gather_region(arena, region_off, chunk_len)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print(f"exchange failed: {e!r}")
+                return abi.EHIP
+        cb = abi.EXCHANGE_FN(_cb)
+        which = np.ascontiguousarray(which, np.int32)
+        st = abi.MargStats()
+        rc = graph.L.spg_graph_marginalize_ranks(graph.h, which.ctypes.data_as(C.POINTER(C.c_int32)), len(which), C.byref(opts),
+                                                 rank, ws, C.cast(cb, C.c_void_p) if ws > 1 else None, None, C.byref(st))
+        graph.last_stats = st.asdict()
+        check(rc, graph.ctx.h, "spg_graph_marginalize_ranks")
+        return graph.last_stats
+
     graph.begin(which, opts, rank, ws)
-    view, view_ptr = None, None
     try:
         while True:
             info = graph.round_prepare()
@@ -56,15 +89,9 @@ def marginalize_sharded(graph, which, opts, device=None, group=None):
                 break
             graph.round_compute()
             if ws > 1 and info.exchange:
-                ptr, _ = graph.arena()
-                if ptr != view_ptr:  # the arena may be re-allocated while a round is prepared
-                    view, view_ptr = arena_tensor(graph, device), ptr
                 graph.ctx.synchronize()  # this rank's chunk is complete in memory
-                region = view[info.region_off:info.region_off + ws * info.chunk_len]
-                mine = region[rank * info.chunk_len:(rank + 1) * info.chunk_len]
-                dist.all_gather_into_tensor(region, mine, group=group)
-                if on_gpu:
-                    torch.cuda.synchronize()
+                ptr, _ = graph.arena()
+                all_gather_region(ptr, info.region_off, info.chunk_len)
             graph.round_commit()
     finally:
         stats = graph.end()

@@ -29,7 +29,7 @@ for ci, case in enumerate(sys.argv[2:]):
     # (rounds below 2048 blankets are computed redundantly, nothing exchanged)
     if ci < len(sys.argv[2:]) - 1:
         hg.set_shard_threshold(0)
-    st = marginalize_sharded(hg, which, opts)
+    st = marginalize_sharded(hg, which, opts, stepwise=(ci % 2 == 0))
     ids, _ = hg.vertices()
     assert np.array_equal(ids, gold_vids), (rank, case)
     util.compare_edge_sets(g["pose_dim"], gold_edges, hg.edges(), rtol=1e-11)
