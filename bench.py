@@ -117,6 +117,7 @@ def main():
             "rounds": stats["n_rounds"], "removed": removed, "max_blanket": stats["max_blanket"],
             "kld_sum": stats["kld_sum"], "host_seconds_per_step": stats["host_seconds"], "device_wait_seconds_per_step": stats["device_seconds"],
             "schedule_seconds_per_step": stats["schedule_seconds"], "commit_seconds_per_step": stats["commit_seconds"],
+            "launch_seconds_per_step": stats["launch_seconds"],
         },
     }
     if prof["launches"] > 0 and prof["kernel_ms"] > 0:

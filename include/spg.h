@@ -186,6 +186,7 @@ typedef struct {
     double device_seconds; /* time blocked on the device (launch -> results visible) */
     double schedule_seconds; /* part of host_seconds: conflict-free round selection */
     double commit_seconds;   /* part of host_seconds: graph update */
+    double launch_seconds;   /* part of device_seconds: descriptor upload + kernel launch calls */
 } spg_marg_stats;
 
 /* GraphWrapperG2O::marginalizeNoOptimize (src/graph_wrapper_g2o.cpp:398-453): removes `which` with

@@ -131,7 +131,8 @@ struct spg_graph {
     std::vector<int32_t> pending;   // removal list (vertex indices) in the caller's order; [pend_head, end) is still to do
     size_t pend_head = 0;
     std::vector<uint8_t> in_set;   // vertex index is in the removal list
-    Batch bt[2];
+    static constexpr int NB = 4;                      // batches that can be in flight (= backend launch slots)
+    Batch bt[NB];
     Batch *B = &bt[0];                                // batch the round functions currently work on
     std::vector<int32_t> Dpool;                       // owner sets, flat
     std::vector<std::pair<int32_t, int32_t>> Dspan;   // (offset, length) per owner
@@ -669,14 +670,14 @@ static void schedule_round(spg_graph *g) {
     // blankets of the batch that is still in flight: their removals are not in the host graph yet, so
     // nothing that fails to commute with them may be selected now
     bool inflight = false;
-    {
-        Batch &other = g->bt[&bt == &g->bt[0] ? 1 : 0];
-        inflight = other.round_open;
-        if (other.round_open)
-            for (const RoundBlanket &ob : other.rb) {
-                B.assign(other.rb_verts.begin() + ob.vbeg, other.rb_verts.begin() + ob.vbeg + ob.nv);
-                reg(B);
-            }
+    for (int bi = 0; bi < spg_graph::NB; bi++) {
+        Batch &other = g->bt[bi];
+        if (&other == &bt || !other.round_open) continue;
+        inflight = true;
+        for (const RoundBlanket &ob : other.rb) {
+            B.assign(other.rb_verts.begin() + ob.vbeg, other.rb_verts.begin() + ob.vbeg + ob.nv);
+            reg(B);
+        }
     }
     // The scan touches only a prefix of the pending list: entries that have to wait are written back
     // right in front of the untouched tail, so a call costs O(scanned), not O(pending).
@@ -802,9 +803,7 @@ extern "C" int spg_graph_marginalize_begin(spg_graph *g, const int32_t *which, i
     if (int rc = arena_ensure(g, g->used * 3 + (1 << 20))) return rc;
     if (int rc = sync_device(g)) return rc;
     g->active = true;
-    g->bt[0].round_open = false;
-    g->bt[1].round_open = false;
-    g->bt[0].slot = 0; g->bt[1].slot = 1;
+    for (int i = 0; i < spg_graph::NB; i++) { g->bt[i].round_open = false; g->bt[i].slot = i; }
     g->B = &g->bt[0];
     g->round_no = 0;
     g->launch_seq = 0;
@@ -916,8 +915,7 @@ static int prepare_scheduled(spg_graph *g, spg_round_info *info, double t0) {
     if (need > g->cap) {
         // grow: pull device-only ranges into the mirror, re-allocate, push the whole mirror back.
         // Not while another batch is running (it writes into the arena): tell the driver to commit it first.
-        Batch &other = g->bt[&bt == &g->bt[0] ? 1 : 0];
-        if (other.round_open) return 2;
+        for (int bi = 0; bi < spg_graph::NB; bi++) if (&g->bt[bi] != &bt && g->bt[bi].round_open) return 2;
         if (int rc = arena_ensure(g, need + need / 2)) return rc;
         if (int rc = sync_device(g)) return rc;
     }
@@ -973,6 +971,7 @@ extern "C" int spg_graph_round_compute(spg_graph *g) {
     bt.used_mailbox = rd.mail_len > 0;
     int rc = g->ctx->be.run_round(g->ctx->be.user, g->dev, &rd);
     g->stats.device_seconds += now_s() - t0;
+    g->stats.launch_seconds += now_s() - t0;
     if (rc && g->ctx->is_hip) snprintf(g->ctx->err, sizeof g->ctx->err, "%s", spg::hip_backend_error(&g->ctx->be));
     return rc;
 }
@@ -1059,20 +1058,18 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
 extern "C" int spg_graph_marginalize_end(spg_graph *g, spg_marg_stats *stats) {
     if (!g || !g->active) return SPG_ESTATE;
     g->active = false;
-    g->bt[0].round_open = false;
-    g->bt[1].round_open = false;
+    for (int i = 0; i < spg_graph::NB; i++) g->bt[i].round_open = false;
     g->B = &g->bt[0];
     if (g->ctx->is_hip) g->stats.n_launches = spg::hip_backend_launches(&g->ctx->be);
     if (stats) *stats = g->stats;
     return g->stats.n_bad_status ? SPG_EBLANKET : 0;
 }
 
-// Move the second half of a freshly scheduled batch into the other (idle) batch: both halves are
-// mutually independent, so they can be launched back to back on the two slots.
-static void split_batch(spg_graph *g, Batch &a, Batch &b) {
-    size_t keep = a.rb.size() / 2;
+// Move blankets [from, to) of a freshly scheduled batch into another (idle) batch: all of them are
+// mutually independent, so the parts can be launched back to back on different slots.
+static void move_blankets(Batch &a, size_t from, size_t to, Batch &b) {
     b.rb.clear(); b.rb_verts.clear(); b.rb_edges.clear();
-    for (size_t i = keep; i < a.rb.size(); i++) {
+    for (size_t i = from; i < to; i++) {
         RoundBlanket r = a.rb[i];
         int32_t vb = (int32_t)b.rb_verts.size(), eb = (int32_t)b.rb_edges.size();
         b.rb_verts.insert(b.rb_verts.end(), a.rb_verts.begin() + r.vbeg, a.rb_verts.begin() + r.vbeg + r.nv);
@@ -1080,7 +1077,6 @@ static void split_batch(spg_graph *g, Batch &a, Batch &b) {
         r.vbeg = vb; r.ebeg = eb;
         b.rb.push_back(r);
     }
-    a.rb.resize(keep);
 }
 
 extern "C" int spg_graph_marginalize(spg_graph *g, const int32_t *which, int n, const spg_options *opts, spg_marg_stats *stats) {
@@ -1110,71 +1106,88 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
             if ((rc = spg_graph_round_commit(g)) != 0) break;
         }
     } else {
-        // Two batches in flight. Whenever a slot is idle, schedule whatever commutes with the batch
-        // still running (and with everything earlier in the list) and launch it; otherwise wait for
-        // the older batch, apply its graph update, and try again. A batch scheduled while nothing is
-        // running is cut in two so that both slots start working at once.
+        // Up to NB batches in flight. After every commit one scheduling pass picks whatever commutes
+        // with the batches still running (and with everything earlier in the list); a large pick is
+        // cut into as many parts as there are idle slots so that the host work of one part overlaps the
+        // device work of the others. With nothing schedulable, wait for the oldest batch and apply it.
+        constexpr int NB = spg_graph::NB;
         rc = 0;
+        auto commit_all = [&]() -> int {
+            for (;;) {
+                Batch *o = nullptr;
+                for (int i = 0; i < NB; i++) if (g->bt[i].round_open && (!o || g->bt[i].seq < o->seq)) o = &g->bt[i];
+                if (!o) return 0;
+                g->B = o;
+                if (int c = spg_graph_round_commit(g)) return c;
+            }
+        };
+        auto launch_batch = [&](Batch &b, double t0) -> int {
+            g->B = &b;
+            int prc = prepare_scheduled(g, nullptr, t0);
+            if (prc == 2) {  // the arena has to grow: nothing may be running while it is re-allocated
+                bool was_open = b.round_open;
+                (void)was_open;
+                if (int c = commit_all()) return c;
+                g->B = &b;
+                prc = prepare_scheduled(g, nullptr, now_s());
+            }
+            if (prc < 0) return prc;
+            return spg_graph_round_compute(g);
+        };
         for (;;) {
             bool launched = false;
-            for (int s_ = 0; s_ < 2 && rc == 0; s_++) {
-                Batch &bt = g->bt[s_], &other = g->bt[1 - s_];
-                if (bt.round_open || g->pend_head >= g->pending.size()) continue;
+            int f = -1, nfree = 0;
+            for (int i = 0; i < NB; i++) if (!g->bt[i].round_open) { if (f < 0) f = i; nfree++; }
+            if (f >= 0 && g->pend_head < g->pending.size()) {
+                Batch &bt = g->bt[f];
                 g->B = &bt;
                 double t0 = now_s();
                 schedule_round(g);
                 g->stats.schedule_seconds += now_s() - t0;
-                if (bt.rb.empty()) { g->stats.host_seconds += now_s() - t0; continue; }
-                if (g->nranks > 1 && (int)bt.rb.size() >= g->shard_threshold) {
+                if (bt.rb.empty()) {
+                    g->stats.host_seconds += now_s() - t0;
+                } else if (g->nranks > 1 && (int)bt.rb.size() >= g->shard_threshold) {
                     // a wide batch: worth sharding over the ranks. Finish what is in flight, then run it
                     // as one exchanged round (compute own slice, all-gather, commit).
-                    if (other.round_open) { g->B = &other; if ((rc = spg_graph_round_commit(g)) != 0) break; g->B = &bt; }
-                    int prc = prepare_scheduled(g, nullptr, t0);
-                    if (prc < 0) { rc = prc; break; }
-                    if ((rc = spg_graph_round_compute(g)) != 0) break;
+                    if ((rc = commit_all()) != 0) break;
+                    if ((rc = launch_batch(bt, t0)) != 0) break;
                     if ((rc = do_exchange(bt)) != 0) break;
-                    if ((rc = spg_graph_round_commit(g)) != 0) break;
-                    launched = true;
-                    continue;
-                }
-                bool do_split = !other.round_open && bt.rb.size() >= 64;
-                if (do_split) split_batch(g, bt, other);
-                int prc = prepare_scheduled(g, nullptr, t0);
-                if (prc == 2) {  // the arena has to grow: finish the running batch, then prepare again
-                    g->B = &other;
-                    if ((rc = spg_graph_round_commit(g)) != 0) break;
                     g->B = &bt;
-                    prc = prepare_scheduled(g, nullptr, now_s());
-                }
-                if (prc < 0) { rc = prc; break; }
-                if ((rc = spg_graph_round_compute(g)) != 0) break;
-                launched = true;
-                if (do_split) {
-                    g->B = &other;
-                    prc = prepare_scheduled(g, nullptr, now_s());
-                    if (prc == 2) {
-                        g->B = &bt;
-                        if ((rc = spg_graph_round_commit(g)) != 0) break;
-                        g->B = &other;
-                        prc = prepare_scheduled(g, nullptr, now_s());
-                    }
-                    if (prc < 0) { rc = prc; break; }
-                    if ((rc = spg_graph_round_compute(g)) != 0) break;
+                    if ((rc = spg_graph_round_commit(g)) != 0) break;
+                    continue;
+                } else {
+                    size_t S = bt.rb.size();
+                    int parts = (int)std::min<size_t>((size_t)nfree, std::max<size_t>(1, S / 24));
+                    // hand parts 1..parts-1 to other idle batches, keep part 0 here
+                    std::vector<Batch *> tgt;
+                    for (int i = 0; i < NB && (int)tgt.size() < parts - 1; i++) if (i != f && !g->bt[i].round_open) tgt.push_back(&g->bt[i]);
+                    parts = (int)tgt.size() + 1;
+                    size_t per = (S + parts - 1) / parts;
+                    for (int pi = 1; pi < parts; pi++) move_blankets(bt, std::min(S, per * pi), std::min(S, per * (pi + 1)), *tgt[pi - 1]);
+                    bt.rb.resize(std::min(S, per));
+                    if ((rc = launch_batch(bt, t0)) != 0) break;
+                    for (int pi = 1; pi < parts && rc == 0; pi++) if (!tgt[pi - 1]->rb.empty()) rc = launch_batch(*tgt[pi - 1], now_s());
+                    if (rc != 0) break;
+                    launched = true;
                 }
             }
-            if (rc != 0) break;
             Batch *oldest = nullptr;
-            for (int s_ = 0; s_ < 2; s_++)
-                if (g->bt[s_].round_open && (!oldest || g->bt[s_].seq < oldest->seq)) oldest = &g->bt[s_];
+            for (int i = 0; i < NB; i++) if (g->bt[i].round_open && (!oldest || g->bt[i].seq < oldest->seq)) oldest = &g->bt[i];
             if (!oldest) {
                 if (!launched) break;  // nothing in flight, nothing schedulable: done
                 continue;
+            }
+            // keep scheduling while slots are idle and the last pass found work; otherwise apply the oldest batch
+            if (launched) {
+                int nf2 = 0;
+                for (int i = 0; i < NB; i++) nf2 += !g->bt[i].round_open;
+                (void)nf2;
             }
             g->B = oldest;
             if ((rc = spg_graph_round_commit(g)) != 0) break;
         }
         // drain on error
-        for (int s_ = 0; s_ < 2; s_++) if (g->bt[s_].round_open) { g->ctx->be.synchronize(g->ctx->be.user); g->bt[s_].round_open = false; }
+        for (int s_ = 0; s_ < spg_graph::NB; s_++) if (g->bt[s_].round_open) { g->ctx->be.synchronize(g->ctx->be.user); g->bt[s_].round_open = false; }
         g->B = &g->bt[0];
     }
     int rc2 = spg_graph_marginalize_end(g, stats);

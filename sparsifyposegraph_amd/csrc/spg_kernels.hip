@@ -1111,7 +1111,7 @@ struct HipBackend {
     int device = 0;
     char err[512] = {0};
     struct Timed { hipEvent_t a, b; double bytes; int blankets; };
-    // Two independent launch slots (stream + descriptor buffers + pinned staging + pinned mailbox +
+    // Independent launch slots (stream + descriptor buffers + pinned staging + pinned mailbox +
     // large-blanket workspace) so that the host can prepare and launch one batch of blankets while the
     // previous one is still running.
     struct Slot {
@@ -1124,7 +1124,7 @@ struct HipBackend {
         size_t c_stage = 0;
         std::vector<Timed> pending;
     };
-    static constexpr int NSLOT = 2;
+    static constexpr int NSLOT = 4;
     Slot slots[NSLOT];
     int lds_limit = 160 * 1024;
     int n_launches = 0;
