@@ -269,12 +269,19 @@ typedef struct {
     int32_t nv;
 } spg_edge_ref;
 /* per-blanket output record layout (doubles) at out_off:
- *   [0] status  [1] info bits  [2] kld  [3] min_gap  [4] n_new
- *   then per new edge e < n_new: [5+4e] kind  [6+4e] record offset relative to new_off
- *                                [7+4e] record length  [8+4e] nv
- *   then, starting at 5 + 4*n_new_max: the local vertex indices of the new edges, concatenated
- * record length = SPG_OUT_LEN(n_new_max, n_new_vert_max) */
-#define SPG_OUT_HDR 5
+ *   [0] status  [1] info bits  [2] kld  [3] min_gap  [4] n_new  [5] ready tag
+ *   then per new edge e < n_new: [6+4e] kind  [7+4e] record offset relative to new_off
+ *                                [8+4e] record length  [9+4e] nv
+ *   then, starting at 6 + 4*n_new_max: the local vertex indices of the new edges, concatenated
+ * record length = SPG_OUT_LEN(n_new_max, n_new_vert_max).
+ * [5] is written LAST (after a system-scope release) with SPG_READY_WORD(spg_round_desc.tag) — 2^52 + tag,
+ * a value no other word of a record can hold, so stale mailbox contents never look ready — once everything the graph
+ * update needs (status, n_new, the new-edge table and the new records in the arena) is in place; the
+ * per-blanket KLD [2] — and a status change to SPG_ST_KLD_NOT_PD — may land later, at the latest when
+ * the launch has completed. A host that polls the mailbox can therefore commit a batch while its
+ * KLD tails are still running. */
+#define SPG_OUT_HDR 6
+#define SPG_READY_WORD(tag) (4503599627370496.0 + (double)(tag))
 #define SPG_OUT_LEN(n_new_max, n_new_vert_max) (SPG_OUT_HDR + 4 * (n_new_max) + (n_new_vert_max))
 typedef struct {
     const spg_options *opts;
@@ -288,8 +295,8 @@ typedef struct {
      * computed blankets are ALSO delivered to backend->mailbox()[out_off - mail_base] (pinned host
      * memory written by the kernel), so the host needs no device->host copy to read them */
     int64_t mail_base, mail_len;
-    int32_t slot;   /* launch slot (0 | 1): batches in different slots may be in flight at the same time */
-    int32_t pad2_;
+    int32_t slot;   /* launch slot: batches in different slots may be in flight at the same time */
+    int32_t tag;    /* launch tag: SPG_READY_WORD(tag) lands in word [5] of every out record of this launch */
 } spg_round_desc;
 typedef struct {
     void *user;

@@ -109,6 +109,7 @@ extern "C" int spg_run_round(double *arena, const spg_round_desc *rd) {
             nn++;
         }
         rec[4] = nn;
+        rec[5] = SPG_READY_WORD(rd->tag);
         if (bd.tinfo_off >= 0 && out.target.r > 0)
             std::memcpy(arena + bd.tinfo_off, out.target.a.data(), out.target.a.size() * sizeof(double));
     }

@@ -20,7 +20,7 @@ INFO_RANK_DEFICIENT, INFO_GLC_ROOT_EDGE = 1, 2
 FLAG_GLC_KLD = 1
 FLAG_FORCE_EIG = 2
 EINVAL, ENODEV, ENOMEM, ECAPACITY, EHIP, EIO, ESTATE, EBLANKET = -1, -2, -3, -4, -5, -6, -7, -8
-OUT_HDR = 5
+OUT_HDR = 6
 
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
@@ -83,7 +83,7 @@ class RoundDesc(C.Structure):
     _fields_ = [("opts", C.POINTER(Options)), ("n_blankets", C.c_int32), ("first", C.c_int32),
                 ("count", C.c_int32), ("blankets", C.POINTER(BlanketDesc)), ("vert_pose_off", _i64p),
                 ("edges", C.POINTER(EdgeRef)), ("edge_vert", _i32p), ("n_vert_total", C.c_int64),
-                ("n_edge_total", C.c_int64), ("n_edge_vert_total", C.c_int64), ("mail_base", C.c_int64), ("mail_len", C.c_int64), ("slot", C.c_int32), ("pad2_", C.c_int32)]
+                ("n_edge_total", C.c_int64), ("n_edge_vert_total", C.c_int64), ("mail_base", C.c_int64), ("mail_len", C.c_int64), ("slot", C.c_int32), ("tag", C.c_int32)]
 
 
 _ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int64)

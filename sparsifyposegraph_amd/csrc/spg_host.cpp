@@ -17,6 +17,7 @@
 // commutes with every earlier vertex that is selected in this round or still deferred — a deferred
 // vertex is represented by a superset D(u) of every vertex its blanket can reach before its turn.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -66,6 +67,7 @@ struct HostMirror {
 struct spg_ctx {
     spg_backend be{};
     bool is_hip = false;
+    int tag_counter = 0;          // ready tags are unique per context (its mailboxes are shared by all graphs)
     char err[768] = {0};
 };
 
@@ -105,6 +107,9 @@ struct Batch {
     int slot = 0;
     int seq = 0;                       // launch order
     int round_no = 0;
+    int tag = 0;                       // ready tag of the launch (out record word [5])
+    // blankets committed from the mailbox before their KLD tail finished: (log index, mailbox offset)
+    std::vector<std::pair<int32_t, int64_t>> kld_pending;
 };
 
 struct spg_graph {
@@ -947,6 +952,25 @@ static int prepare_scheduled(spg_graph *g, spg_round_info *info, double t0) {
     return 1;
 }
 
+// Late results of a batch that was committed by polling: once its launch has completed, pick up the
+// per-blanket KLD (and a possible SPG_ST_KLD_NOT_PD) from the mailbox.
+static int harvest_kld(spg_graph *g, Batch &bt) {
+    if (bt.kld_pending.empty()) return 0;
+    const bool slotted = g->ctx->be.synchronize_slot && g->ctx->be.mailbox_slot;
+    int rc = slotted ? g->ctx->be.synchronize_slot(g->ctx->be.user, bt.slot) : g->ctx->be.synchronize(g->ctx->be.user);
+    if (rc) return rc;
+    const double *mail = slotted ? g->ctx->be.mailbox_slot(g->ctx->be.user, bt.slot) : g->ctx->be.mailbox(g->ctx->be.user);
+    for (auto &pr : bt.kld_pending) {
+        const double *rec = mail + pr.second;
+        BlanketLog &lg = g->log[pr.first];
+        lg.kld = rec[2];
+        lg.status = (int32_t)rec[0];
+        if (std::isfinite(rec[2])) g->stats.kld_sum += rec[2];
+    }
+    bt.kld_pending.clear();
+    return 0;
+}
+
 extern "C" int spg_graph_round_compute(spg_graph *g) {
     if (!g || !g->active) return SPG_ESTATE;
     Batch &bt = *g->B;
@@ -968,6 +992,10 @@ extern "C" int spg_graph_round_compute(spg_graph *g) {
     rd.mail_base = bt.rinfo.region_off + bt.rinfo.chunk_len * bt.eff_rank;
     rd.mail_len = (bt.eff_ranks == 1 && g->ctx->be.mailbox) ? bt.chunk_hdr[bt.eff_rank] : 0;
     rd.slot = g->pipelined ? bt.slot : 0;
+    bt.tag = ++g->ctx->tag_counter;
+    rd.tag = bt.tag;
+    // the mailbox of this slot is about to be rewritten: collect what the previous launch left in it
+    if (int hrc = harvest_kld(g, bt)) return hrc;
     bt.used_mailbox = rd.mail_len > 0;
     int rc = g->ctx->be.run_round(g->ctx->be.user, g->dev, &rd);
     g->stats.device_seconds += now_s() - t0;
@@ -983,12 +1011,37 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
     double t0 = now_s();
     const int nr = bt.eff_ranks;
     const bool slotted = g->pipelined && g->ctx->be.synchronize_slot && g->ctx->be.mailbox_slot;
-    int rc = slotted ? g->ctx->be.synchronize_slot(g->ctx->be.user, bt.slot) : g->ctx->be.synchronize(g->ctx->be.user);
-    if (rc) return rc;
-    // read back the out-record part of every rank chunk (mailbox: already in host memory)
     const double *mail = nullptr;
     if (bt.used_mailbox && g->ctx->be.mailbox)
         mail = slotted ? g->ctx->be.mailbox_slot(g->ctx->be.user, bt.slot) : g->ctx->be.mailbox(g->ctx->be.user);
+    int rc = 0;
+    bool polled = false;
+    if (mail && nr == 1) {
+        // Poll the ready tags the kernel writes (system-scope release) after each blanket's graph-update
+        // data is complete; the launch itself may still be finishing KLD tails. Bounded spin: after
+        // ~5 s fall back to a stream synchronisation, which also surfaces a faulted kernel.
+        const int64_t base = bt.rinfo.region_off + bt.rinfo.chunk_len * bt.eff_rank;
+        const double want = SPG_READY_WORD(bt.tag);
+        const double t_spin = now_s();
+        polled = true;
+        for (const RoundBlanket &r : bt.rb) {
+            const volatile double *flag = mail + (r.desc.out_off - base) + 5;
+            uint32_t spins = 0;
+            while (*flag != want) {
+                if ((++spins & 0x3fff) == 0 && now_s() - t_spin > 5.0) { polled = false; break; }
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            if (!polled) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!polled) {
+        rc = slotted ? g->ctx->be.synchronize_slot(g->ctx->be.user, bt.slot) : g->ctx->be.synchronize(g->ctx->be.user);
+        if (rc) return rc;
+    }
+    // read back the out-record part of every rank chunk (mailbox: already in host memory)
     for (int q = 0; q < nr; q++) {
         if (bt.chunk_hdr[q] == 0) continue;
         int64_t base = bt.rinfo.region_off + bt.rinfo.chunk_len * q;
@@ -1012,12 +1065,13 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
         const double *rec = g->host.data() + bd.out_off;
         int status = (int)rec[0], inf = (int)rec[1], n_new = (int)rec[4];
         g->log.push_back({g->vid[r.root], bt.round_no, status, inf, rec[2], rec[3]});
+        if (polled && (status == SPG_OK)) bt.kld_pending.push_back({(int32_t)g->log.size() - 1, bd.out_off - (bt.rinfo.region_off + bt.rinfo.chunk_len * bt.eff_rank)});
         g->stats.max_blanket = std::max(g->stats.max_blanket, r.nv);
         const int32_t *rverts = bt.rb_verts.data() + r.vbeg;
         const int32_t *redges = bt.rb_edges.data() + r.ebeg;
         bool fine = (status == SPG_OK || status == SPG_ST_KLD_NOT_PD);
         if (!fine) { g->stats.n_bad_status++; continue; }
-        if (std::isfinite(rec[2])) g->stats.kld_sum += rec[2];
+        if (!polled && std::isfinite(rec[2])) g->stats.kld_sum += rec[2];
         for (int ei_ = 0; ei_ < r.ne; ei_++) {
             int32_t eid = redges[ei_];
             GEdge &e = g->edges[eid];
@@ -1058,6 +1112,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
 extern "C" int spg_graph_marginalize_end(spg_graph *g, spg_marg_stats *stats) {
     if (!g || !g->active) return SPG_ESTATE;
     g->active = false;
+    for (int i = 0; i < spg_graph::NB; i++) (void)harvest_kld(g, g->bt[i]);
     for (int i = 0; i < spg_graph::NB; i++) g->bt[i].round_open = false;
     g->B = &g->bt[0];
     if (g->ctx->is_hip) g->stats.n_launches = spg::hip_backend_launches(&g->ctx->be);

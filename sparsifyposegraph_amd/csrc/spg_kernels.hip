@@ -127,7 +127,7 @@ struct KArgs {
     const int32_t *list;
     double *gws;
     int64_t gws_stride;
-    int topology, algorithm, flags, lin_point;
+    int topology, algorithm, flags, lin_point, tag;
     double chord_ratio;
     double *mail;        // pinned host mailbox for out records (or nullptr)
     int64_t mail_base;   // arena offset that maps to mail[0]
@@ -170,7 +170,11 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     int status = SPG_OK, info = 0, n_new = 0;
     double kld = __builtin_nan(""), min_gap = __builtin_inf();
 
-    auto finish = [&]() {
+    // publish(): everything the host's graph update needs — status so far, n_new, the new-edge table —
+    // followed by a system-scope release and the ready tag. finish() = publish (unless done) + KLD.
+    bool published = false;
+    auto publish = [&]() {
+        T.sync();  // every lane's new-record stores precede the release below
         if (tid == 0) {
             orec[0] = (double)status; orec[1] = (double)info; orec[2] = kld; orec[3] = min_gap; orec[4] = (double)n_new;
             for (int e = 0; e < n_new; e++) {
@@ -182,8 +186,17 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                 orec[SPG_OUT_HDR + 4 * bd.n_new_max + 2 * e + 1] = (double)(m + pairs[2 * e + 1]);
             }
         }
+        __threadfence_system();
+        T.sync();
+        if (tid == 0) {
+            __hip_atomic_store(&orec[5], SPG_READY_WORD(a.tag), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        published = true;
     };
-
+    auto finish = [&]() {
+        if (!published) { publish(); return; }
+        if (tid == 0) { orec[2] = kld; orec[0] = (double)status; }
+    };
     // diagnostic cycle stamps (flags bit 16, needs tinfo_off >= 0): written only to the debug region
     const bool stamping = ((a.flags >> 16) & 1) && bd.tinfo_off >= 0;
     auto STAMP = [&](int idx) {
@@ -978,6 +991,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         if (misc[0]) { status = SPG_ST_CLOSED_FORM_NOT_PD; finish(); return; }
     }
     n_new = ne;
+    publish();  // the graph update can proceed; the KLD below is reported later
     STAMP(18);  // closed form
     if (stop_after == 7) { finish(); return; }
 
@@ -1258,6 +1272,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
             size_t nc = std::max(need, S.c_mail * 2);
             HIPCHK(hipHostMalloc(&S.h_mail, nc, hipHostMallocMapped));
             HIPCHK(hipHostGetDevicePointer(&S.d_mail, S.h_mail, 0));
+            memset(S.h_mail, 0, nc);   // a fresh mailbox never looks ready
             S.c_mail = nc;
         }
         mail_dev = (double *)S.d_mail;
@@ -1272,7 +1287,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     ka.mail = mail_dev;
     ka.mail_base = rd->mail_base;
     ka.gws = nullptr; ka.gws_stride = 0;
-    ka.topology = o.topology; ka.algorithm = o.algorithm; ka.flags = o.flags; ka.chord_ratio = o.chord_ratio; ka.lin_point = o.lin_point;
+    ka.topology = o.topology; ka.algorithm = o.algorithm; ka.flags = o.flags; ka.chord_ratio = o.chord_ratio; ka.lin_point = o.lin_point; ka.tag = rd->tag;
     size_t list_off = 0;
     for (int i = 0; i < NB; i++) {
         int nb = (int)bins[i].list.size();
