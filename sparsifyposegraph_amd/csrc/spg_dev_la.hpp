@@ -90,7 +90,7 @@ __device__ __forceinline__ int ceil_log2(int n) {
 // *T.flag = 1 (checked by the caller after the call). Two barriers per column: every lane derives
 // 1/sqrt(pivot) itself, lane 0 alone stores the pivot. If rdiag != nullptr it receives 1/L_jj.
 template <int NT>
-__device__ void chol_lower(const Team<NT> &T, double *A, int n, int ld, double *rdiag = nullptr) {
+__device__ void chol_lower(const Team<NT> T, double *A, int n, int ld, double *rdiag = nullptr) {
     for (int j = 0; j < n; j++) {
         // every lane reads the pivot (ordered after the previous column's trailing update by barrier #2)
         double d = A[j * ld + j];
@@ -121,7 +121,7 @@ __device__ void chol_lower(const Team<NT> &T, double *A, int n, int ld, double *
 
 // 2 * sum(log L_ii) of a Cholesky factor
 template <int NT>
-__device__ double chol_logdet(const Team<NT> &T, const double *L, int n, int ld) {
+__device__ double chol_logdet(const Team<NT> T, const double *L, int n, int ld) {
     // one lane walks the diagonal (n <= a few hundred): a single log of the running product
     double v = 0;
     if (T.tid == 0) {
@@ -134,7 +134,7 @@ __device__ double chol_logdet(const Team<NT> &T, const double *L, int n, int ld)
 
 // Linv = L^-1 (lower), one lane per column; Linv may not alias L. Strict upper of Linv is zeroed.
 template <int NT>
-__device__ void tri_inverse_lower(const Team<NT> &T, const double *L, double *Li, int n, int ld, const double *rdiag = nullptr) {
+__device__ void tri_inverse_lower(const Team<NT> T, const double *L, double *Li, int n, int ld, const double *rdiag = nullptr) {
     for (int c = T.tid; c < n; c += NT) {
         for (int i = 0; i < c; i++) Li[i * ld + c] = 0.0;
         Li[c * ld + c] = rdiag ? rdiag[c] : fast_rcp(L[c * ld + c]);
@@ -149,7 +149,7 @@ __device__ void tri_inverse_lower(const Team<NT> &T, const double *L, double *Li
 
 // Out = Li^T Li (full symmetric), i.e. (L L^T)^-1 from Li = L^-1. Out may not alias Li.
 template <int NT>
-__device__ void gram_lower_inverse(const Team<NT> &T, const double *Li, double *Out, int n, int ld) {
+__device__ void gram_lower_inverse(const Team<NT> T, const double *Li, double *Out, int n, int ld) {
     int sh = ceil_log2(n);
     int tot = n << sh;
     for (int it = T.tid; it < tot; it += NT) {
@@ -166,7 +166,7 @@ __device__ void gram_lower_inverse(const Team<NT> &T, const double *Li, double *
 
 // Y <- L^-1 Y for a (n x m) right-hand side stored row-major with leading dimension ldy; lane per column.
 template <int NT>
-__device__ void tri_solve_lower(const Team<NT> &T, const double *L, int n, int ld, double *Y, int m, int ldy) {
+__device__ void tri_solve_lower(const Team<NT> T, const double *L, int n, int ld, double *Y, int m, int ldy) {
     for (int c = T.tid; c < m; c += NT) {
         for (int i = 0; i < n; i++) {
             double s = Y[i * ldy + c];
@@ -179,7 +179,7 @@ __device__ void tri_solve_lower(const Team<NT> &T, const double *L, int n, int l
 
 // strict upper -> strict lower
 template <int NT>
-__device__ void mirror_upper(const Team<NT> &T, double *A, int n, int ld) {
+__device__ void mirror_upper(const Team<NT> T, double *A, int n, int ld) {
     int sh = ceil_log2(n);
     int tot = n << sh;
     for (int it = T.tid; it < tot; it += NT) {
@@ -204,7 +204,7 @@ __device__ __forceinline__ void rr_pair(int s, int pi, int n2, int &p, int &q) {
 // exit its diagonal holds the eigenvalues), V receives the eigenvectors in columns. cs: 2*(n/2+1)
 // doubles of scratch. Returns false (uniformly) if not converged in max_sweeps.
 template <int NT>
-__device__ bool jacobi_eigh(const Team<NT> &T, double *A, double *V, int n, int ld, double *cs, int max_sweeps = 60) {
+__device__ bool jacobi_eigh(const Team<NT> T, double *A, double *V, int n, int ld, double *cs, int max_sweeps = 60) {
     int sh = ceil_log2(n);
     int tot = n << sh;
     double f = 0;
@@ -288,7 +288,7 @@ __device__ bool jacobi_eigh(const Team<NT> &T, double *A, double *V, int n, int 
 
 // rank-by-counting sort of n keys (ascending, ties by index): perm[rank] = index
 template <int NT>
-__device__ void sort_ascending(const Team<NT> &T, const double *key, int stride, int n, int *perm) {
+__device__ void sort_ascending(const Team<NT> T, const double *key, int stride, int n, int *perm) {
     for (int i = T.tid; i < n; i += NT) {
         double ki = key[i * stride];
         int r = 0;
@@ -366,7 +366,7 @@ namespace spgdev {
 // Eigen::PartialPivLU(J).solve(I), src/topology_provider_glc.cpp:63-64). scratch: cnt*(2*s+2) doubles.
 // Sets *T.flag on a zero / non-finite pivot.
 template <int NT>
-__device__ void gj_inverse_batch(const Team<NT> &T, double *A, int cnt, int s, int ld, int stride, double *scratch) {
+__device__ void gj_inverse_batch(const Team<NT> T, double *A, int cnt, int s, int ld, int stride, double *scratch) {
     double *fcol = scratch;                       // cnt * s
     int *ipiv = reinterpret_cast<int *>(scratch + (size_t)cnt * s);  // cnt * s ints (fits in cnt*s doubles)
     int sh = ceil_log2(s);
@@ -436,7 +436,7 @@ __device__ void gj_inverse_batch(const Team<NT> &T, double *A, int cnt, int s, i
 // On exit the diagonals hold the eigenvalues, V the eigenvectors. Sets *T.flag if any matrix fails
 // to converge.
 template <int NT>
-__device__ void jacobi_batch(const Team<NT> &T, double *A, double *V, int cnt, int s, int ld, int stride, double *cs,
+__device__ void jacobi_batch(const Team<NT> T, double *A, double *V, int cnt, int s, int ld, int stride, double *cs,
                              int *done, int max_sweeps = 60) {
     int sh = ceil_log2(s);
     int np = (s + 1) >> 1, n2 = np * 2;

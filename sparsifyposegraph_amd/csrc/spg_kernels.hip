@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     // publish(): everything the host's graph update needs — status so far, n_new, the new-edge table —
     // followed by a system-scope release and the ready tag. finish() = publish (unless done) + KLD.
     bool published = false;
-    auto publish = [&]() {
+    auto publish = [&, T]() {
         T.sync();  // every lane's new-record stores precede the release below
         if (tid == 0) {
             orec[0] = (double)status; orec[1] = (double)info; orec[2] = kld; orec[3] = min_gap; orec[4] = (double)n_new;
@@ -193,13 +193,13 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         }
         published = true;
     };
-    auto finish = [&]() {
+    auto finish = [&, T]() {
         if (!published) { publish(); return; }
         if (tid == 0) { orec[2] = kld; orec[0] = (double)status; }
     };
     // diagnostic cycle stamps (flags bit 16, needs tinfo_off >= 0): written only to the debug region
     const bool stamping = ((a.flags >> 16) & 1) && bd.tinfo_off >= 0;
-    auto STAMP = [&](int idx) {
+    auto STAMP = [&, T](int idx) {
         if (stamping) {
             T.sync();
             if (tid == 0) arena[bd.tinfo_off + idx] = (double)__builtin_amdgcn_s_memtime();
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         for (int it = tid; it < n * n; it += NT) { int i = it / n, j = it - i * n; dst[it] = M1[i * ld + j]; }
     }
     // pseudo-Chow-Liu tree of the kept vertices (a8): fills pairs[0..2(k-1)) in pop order, sets min_gap
-    auto chow_liu_tree = [&](auto &TT) -> int {
+    auto chow_liu_tree = [&](const auto TT) -> int {
         if (k == 2) {
             if (TT.tid == 0) { pairs[0] = 0; pairs[1] = 1; }
             TT.sync();
@@ -658,7 +658,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     bool gauge_ok = false;
     double logdetS = 0.0;
     double *Sg = M1, *Scr = M3;      // Sigma and scratch for the closed form (swapped on the gauge route)
-    auto gauge_chain = [&](auto &TT) {
+    auto gauge_chain = [&](const auto TT) {
         // ---- gauge basis
         for (int v = TT.tid; v < k; v += TT.size) {
             const double *X = pose + (m + v) * PSZ;

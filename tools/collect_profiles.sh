@@ -1,0 +1,16 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun) from the repo root: kernel-trace stats and two separate PMC passes
+# of the default bench command, raw output under gpurun_out/prof_*; tools/summarize_profiles.py then
+# condenses them into profiles/.  Usage: bash tools/collect_profiles.sh [steps]
+set -e
+STEPS=${1:-3}
+ROOT=$(pwd)
+export TMPDIR=/tmp
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd $ROOT
+python bench.py --steps $STEPS --warmup 1 > $OUT/prof_bench.json 2> $OUT/prof_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o run -- python3 bench.py --steps $STEPS --warmup 1 --no-cpu-baseline > $OUT/prof_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch -o run -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write -o run -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_write.log 2>&1
+find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -name '*.csv' | head -20
