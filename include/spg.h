@@ -56,7 +56,8 @@ enum {
 
 enum {
     SPG_EINVAL = -1, SPG_ENODEV = -2, SPG_ENOMEM = -3, SPG_ECAPACITY = -4, SPG_EHIP = -5, SPG_EIO = -6,
-    SPG_ESTATE = -7, SPG_EBLANKET = -8 /* at least one blanket has status != OK that prevents graph update */
+    SPG_ESTATE = -7, SPG_EBLANKET = -8, /* at least one blanket has status != OK that prevents graph update */
+    SPG_ENOTPD = -9 /* a graph's information matrix is not positive definite (global KLD) */
 };
 
 /* SparsityOptions (src/sparsity_options.h:11-30) + algorithm selector + pose dimension */
@@ -214,6 +215,26 @@ int spg_graph_last_blankets(const spg_graph *g, int32_t *root_id, int32_t *round
  * endpoint is replaced by the nearest surviving vertex, meas (3|7) and info_upper (6|21) are filled. */
 int spg_graph_substitute_edge(spg_graph *g, const int32_t *marginalized, int n_marg, int maxid,
                               int *from, int *to, double *meas, double *info_upper);
+
+/* ---- global Kullback-Leibler divergence ------------------------------------
+ * other->information() / sparseInformation() (src/graph_wrapper_g2o.cpp:351-396): the dense
+ * Gauss-Newton information of the graph at its stored estimates over all vertices except the fixed one
+ * (fixed_id < 0: the smallest id, which is the vertex the reference fixes and skips), id order,
+ * n = pose_dim * (V - 1). Returns n; the n x n row-major matrix is written if cap >= n*n. */
+int64_t spg_graph_information(spg_graph *g, int32_t fixed_id, double *out, int64_t cap);
+/* kullbackLeiblerDivergence(diff, infox, maty, InformationInformation) (src/utils.cpp:70-97):
+ * kld = 0.5 * (innerprod + mahalanobis - logdetx - logdety - n), logdety = -sum log D(maty). */
+typedef struct {
+    double kld, innerprod, mahalanobis, logdetx, logdety;
+    int64_t n;               /* variables compared: pose_dim * (kept vertices - fixed) */
+    int64_t n_marginalized;  /* baseline variables marginalised out */
+    double device_seconds;   /* HIP-event time of assembly + factorisations + solve */
+} spg_kld_terms;
+/* baseline->kullbackLeibler(other) (src/graph_wrapper_g2o.cpp:531-548): marginal of the baseline's
+ * information onto other's vertices (computeIndices :472-499), estimateDifference (:550-575), then the
+ * formula above, all dense on the device. other's vertices must be a subset of the baseline's; both
+ * graphs must live on the same device. SPG_ENOTPD if either information matrix is not PD. */
+int spg_graph_kullback_leibler(spg_graph *baseline, spg_graph *other, int32_t fixed_id, spg_kld_terms *out);
 
 /* ---- round-stepping form of the same call, for multi-GPU sharding ---------------------------
  * All ranks hold a replica and run the same deterministic scheduler; rank r computes its slice of

@@ -23,6 +23,7 @@
 // message. Thread model: one GraphWrapperHIP per host thread (as the reference's one VertexRemover
 // per call, src/vertex_remover.h:92-98).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <stdexcept>
@@ -211,6 +212,21 @@ public:
             out[e].data.assign(data.begin() + doff[e], data.begin() + doff[e + 1]);
         }
         return out;
+    }
+    // GraphWrapperG2O::information (src/graph_wrapper_g2o.cpp:351-358): n x n row-major, first vertex fixed
+    std::vector<double> information() {
+        int64_t n = spg_graph_information(_g, -1, nullptr, 0);
+        check((int)std::min<int64_t>(n, 0), "information");
+        std::vector<double> H((size_t)n * n);
+        check((int)std::min<int64_t>(spg_graph_information(_g, -1, H.data(), (int64_t)H.size()), 0), "information");
+        return H;
+    }
+    // GraphWrapperG2O::kullbackLeibler(other), called on the baseline (src/graph_wrapper_g2o.cpp:531-548)
+    double kullbackLeibler(GraphWrapperHIP *other, spg_kld_terms *terms = nullptr) {
+        spg_kld_terms t;
+        check(spg_graph_kullback_leibler(_g, other->_g, -1, &t), "kullbackLeibler");
+        if (terms) *terms = t;
+        return t.kld;
     }
     // "nodes = ..; edges = .." of src/graph_wrapper_g2o.cpp:606-612 (fill-in needs the LM Hessian: omitted)
     void printStats(std::ostream &s) const override;

@@ -87,18 +87,30 @@ inline bool chol_lower(Mat &A) {
 
 // Solve L L^T X = B in place (B is n x m).
 inline void chol_solve(const Mat &L, Mat &B) {
+    // row-sweeping form (contiguous inner loops); per entry the same operations in the same order as
+    // the textbook column-by-column substitution
     int n = L.r, m = B.c;
-    for (int c = 0; c < m; c++) {
-        for (int i = 0; i < n; i++) {
-            double s = B(i, c);
-            for (int k = 0; k < i; k++) s -= L(i, k) * B(k, c);
-            B(i, c) = s / L(i, i);
+    for (int i = 0; i < n; i++) {
+        double *bi = &B.a[(size_t)i * m];
+        for (int k = 0; k < i; k++) {
+            double l = L(i, k);
+            if (l == 0.0) continue;
+            const double *bk = &B.a[(size_t)k * m];
+            for (int c = 0; c < m; c++) bi[c] -= l * bk[c];
         }
-        for (int i = n - 1; i >= 0; i--) {
-            double s = B(i, c);
-            for (int k = i + 1; k < n; k++) s -= L(k, i) * B(k, c);
-            B(i, c) = s / L(i, i);
+        double d = L(i, i);
+        for (int c = 0; c < m; c++) bi[c] /= d;
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double *bi = &B.a[(size_t)i * m];
+        for (int k = i + 1; k < n; k++) {
+            double l = L(k, i);
+            if (l == 0.0) continue;
+            const double *bk = &B.a[(size_t)k * m];
+            for (int c = 0; c < m; c++) bi[c] -= l * bk[c];
         }
+        double d = L(i, i);
+        for (int c = 0; c < m; c++) bi[c] /= d;
     }
 }
 

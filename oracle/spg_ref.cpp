@@ -322,6 +322,108 @@ int spgref_graph_last_blankets(void *h, int32_t *root, int32_t *status, int32_t 
     return (int)g->log.size();
 }
 
+// ------------------------------------------------------------------------------ global KLD (a18)
+// other->information() == sparseInformation(): Hpp of the optimiser over the non-fixed vertices in id
+// order (src/graph_wrapper_g2o.cpp:351-396). No LM in scope: the Gauss-Newton Hessian at the stored
+// estimates (g2o's LM restores the undamped diagonal after each solve). ids_out: the variables' vertices.
+static Mat graph_information(RGraph *g, int fixed_id, std::vector<int> &ids_out) {
+    int d = g->d, ps = pose_stride(d);
+    std::vector<int> ids;
+    std::map<int, int> loc;
+    for (auto &kv : g->pose) { loc[kv.first] = (int)ids.size(); ids.push_back(kv.first); }
+    std::vector<double> poses(ids.size() * (size_t)ps);
+    for (size_t i = 0; i < ids.size(); i++) std::memcpy(&poses[i * ps], g->pose[ids[i]].data(), ps * sizeof(double));
+    BlanketIn in;
+    in.d = d; in.nv = (int)ids.size(); in.m = 0; in.pose = poses.data();
+    for (auto &e : g->edges) {
+        if (!e.alive) continue;
+        EdgeIn ei;
+        ei.kind = e.kind;
+        for (int id : e.ids) ei.v.push_back(loc[id]);
+        ei.data = e.data.data();
+        ei.len = (int64_t)e.data.size();
+        in.edges.push_back(ei);
+    }
+    Mat H = assemble_hessian(in);
+    std::vector<int> keep;
+    ids_out.clear();
+    for (size_t i = 0; i < ids.size(); i++) {
+        if (ids[i] == fixed_id) continue;
+        ids_out.push_back(ids[i]);
+        for (int a = 0; a < d; a++) keep.push_back((int)i * d + a);
+    }
+    return select(H, keep, keep);
+}
+
+int64_t spgref_graph_information(void *h, int32_t fixed_id, double *out, int64_t cap) {
+    RGraph *g = (RGraph *)h;
+    std::vector<int> ids;
+    Mat H = graph_information(g, fixed_id, ids);
+    if (out && (int64_t)H.a.size() <= cap) std::memcpy(out, H.a.data(), H.a.size() * sizeof(double));
+    return H.r;
+}
+
+// GraphWrapperG2O::kullbackLeibler(other) called on the baseline (src/graph_wrapper_g2o.cpp:531-548):
+// marginal of the baseline information onto other's vertices (computeIndices :472-499, first vertex
+// skipped), estimateDifference (:550-575), kullbackLeiblerDivergence(..., InformationInformation)
+// (src/utils.cpp:70-97). terms: kld, innerprod, mahalanobis, logdetx, logdety, n.
+int spgref_graph_kullback_leibler(void *hb, void *ho, int32_t fixed_id, double *terms) {
+    RGraph *gb = (RGraph *)hb, *go = (RGraph *)ho;
+    if (gb->d != go->d) return SPG_EINVAL;
+    int d = gb->d;
+    std::vector<int> ids_b, ids_o;
+    Mat Hb = graph_information(gb, fixed_id, ids_b);
+    Mat infox = graph_information(go, fixed_id, ids_o);
+    std::vector<int> keep, marg;
+    size_t j = 0;
+    for (size_t i = 0; i < ids_b.size(); i++) {
+        bool kept = j < ids_o.size() && ids_o[j] == ids_b[i];
+        if (kept) j++;
+        for (int a = 0; a < d; a++) (kept ? keep : marg).push_back((int)i * d + a);
+    }
+    if (j != ids_o.size()) return SPG_EINVAL;  // other holds a vertex the baseline lacks
+    Mat maty = select(Hb, keep, keep);
+    if (!marg.empty()) {
+        Mat Hmm = select(Hb, marg, marg), Hmk = select(Hb, marg, keep);
+        if (!chol_lower(Hmm)) return SPG_EBLANKET;
+        Mat Y = Hmk;
+        chol_solve(Hmm, Y);
+        Mat C = matmul(transpose(Hmk), Y);
+        for (size_t i = 0; i < maty.a.size(); i++) maty.a[i] -= C.a[i];
+    }
+    int n = infox.r;
+    // estimateDifference: baseline estimate vs other's, per kept vertex
+    std::vector<double> diff((size_t)n, 0.0);
+    for (size_t i = 0; i < ids_o.size(); i++) {
+        const double *xb = gb->pose[ids_o[i]].data(), *xo = go->pose[ids_o[i]].data();
+        if (d == 3) {
+            diff[i * 3] = xb[0] - xo[0]; diff[i * 3 + 1] = xb[1] - xo[1]; diff[i * 3 + 2] = normalize_theta(xb[2] - xo[2]);
+        } else {
+            iso_to_mqt(iso_mul(iso_inv(iso_from_tq(xb)), iso_from_tq(xo)), &diff[i * 6]);
+        }
+    }
+    bool okx = true, oky = true;
+    double logdetx = spd_logdet(infox, okx);
+    Mat Ly = maty;
+    oky = chol_lower(Ly);
+    if (!okx || !oky) return SPG_EBLANKET;
+    double logdety = 0;
+    for (int i = 0; i < n; i++) logdety -= 2.0 * std::log(Ly(i, i));   // mode InformationInformation: -sum log D
+    Mat Z = infox;
+    chol_solve(Ly, Z);
+    double innerprod = 0;
+    for (int i = 0; i < n; i++) innerprod += Z(i, i);
+    double mahal = 0;
+    for (int i = 0; i < n; i++) {
+        double s = 0;
+        for (int k = 0; k < n; k++) s += infox(i, k) * diff[k];
+        mahal += diff[i] * s;
+    }
+    terms[0] = 0.5 * (innerprod + mahal - logdetx - logdety - n);
+    terms[1] = innerprod; terms[2] = mahal; terms[3] = logdetx; terms[4] = logdety; terms[5] = n;
+    return 0;
+}
+
 // Batch entry spread over host threads (cpu_baseline "B": same rounds, all cores). Blankets are
 // independent; outputs are produced per thread and stitched in order.
 int spgref_marginalize_batch_mt(const spg_options *o, const spg_batch *b, spg_result *r, int nthreads) {

@@ -19,7 +19,7 @@ ST_OK, ST_HMM_NOT_PD, ST_EIG_FAIL, ST_NONFINITE, ST_TIKHONOV_NOT_PD, ST_CLOSED_F
 INFO_RANK_DEFICIENT, INFO_GLC_ROOT_EDGE = 1, 2
 FLAG_GLC_KLD = 1
 FLAG_FORCE_EIG = 2
-EINVAL, ENODEV, ENOMEM, ECAPACITY, EHIP, EIO, ESTATE, EBLANKET = -1, -2, -3, -4, -5, -6, -7, -8
+EINVAL, ENODEV, ENOMEM, ECAPACITY, EHIP, EIO, ESTATE, EBLANKET, ENOTPD = -1, -2, -3, -4, -5, -6, -7, -8, -9
 OUT_HDR = 6
 
 _i32p = C.POINTER(C.c_int32)
@@ -57,6 +57,15 @@ class MargStats(C.Structure):
                 ("n_bad_status", C.c_int32), ("max_blanket", C.c_int32), ("n_launches", C.c_int32),
                 ("kld_sum", C.c_double), ("host_seconds", C.c_double), ("device_seconds", C.c_double),
                 ("schedule_seconds", C.c_double), ("commit_seconds", C.c_double), ("launch_seconds", C.c_double)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class KldTerms(C.Structure):
+    """spg_kld_terms (include/spg.h)"""
+    _fields_ = [("kld", C.c_double), ("innerprod", C.c_double), ("mahalanobis", C.c_double), ("logdetx", C.c_double),
+                ("logdety", C.c_double), ("n", C.c_int64), ("n_marginalized", C.c_int64), ("device_seconds", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

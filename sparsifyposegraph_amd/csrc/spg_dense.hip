@@ -1,0 +1,595 @@
+// csrc/spg_dense.hip — dense fp64 kernels for the global Kullback-Leibler divergence.
+//
+// Reference: GraphWrapperG2O::kullbackLeibler (src/graph_wrapper_g2o.cpp:531-548), computeIndices
+// (:472-499), estimateDifference (:550-575), sparseInformation (:382-396) and
+// kullbackLeiblerDivergence(..., InformationInformation) (src/utils.cpp:70-97).
+//
+// The reference marginalises the baseline with a sparse Cholesky on the host and then runs dense
+// n_g x n_g LDLT / solve. Here everything is dense and stays in HBM (the shipped datasets need at most
+// 15k x 15k fp64 = 1.8 GB of the 288 GB): the baseline information is assembled with the variables
+// ordered [marginalised | kept], ONE blocked Cholesky of that matrix leaves chol(selectedInfo) in
+// its trailing block (the Schur complement is what a right-looking factorisation has produced when
+// it reaches the kept block), and
+//     trace(maty^-1 infox) = || L_y^-1 L_x ||_F^2,   logdet = 2 sum log diag(L),   mahalanobis = || L_x^T diff ||^2.
+// The O(n^3) work (trailing updates, panel solves, the triangular solve for L_y^-1 L_x) is one
+// 64x64x64 tile kernel on the fp64 matrix cores (v_mfma_f64_16x16x4_f64); diagonal blocks are
+// factorised and inverted by one workgroup in LDS, so panel solves are products with L_jj^-T.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "spg_dev_geom.hpp"
+#include "spg_dev_la.hpp"
+#include "spg_internal.h"
+
+using namespace spgdev;
+
+namespace {
+
+constexpr int TB = 64;    // tile edge
+constexpr int LDR = 66;   // LDS row stride of a staged tile: (row*66 + k) mod 32 is distinct over a half wave's 16 rows x 2 k
+using d4 = __attribute__((ext_vector_type(4))) double;
+
+#define HIPCHK(x)                                                                                              \
+    do {                                                                                                       \
+        hipError_t e_ = (x);                                                                                   \
+        if (e_ != hipSuccess) {                                                                                \
+            snprintf(err, errlen, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__);     \
+            rc = SPG_EHIP;                                                                                     \
+            goto done;                                                                                         \
+        }                                                                                                      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ tiles
+// C(p,q) (op)= A(p,q) * B(p,q)^T over one 64x64x64 tile triple; (p,q) from the grid. Tiles are
+// addressed as base + p*stride_p + q*stride_q (elements), each with its own leading dimension.
+struct TileOp {
+    double *C;
+    const double *A, *B;
+    long long c_p, c_q, a_p, a_q, b_p, b_q;
+    int ldc, lda, ldb;
+    int tri;       // 1: blockIdx.x enumerates the pairs q <= p of a triangle
+    int subtract;  // 1: C -= A B^T; 0: C = A B^T (C may alias A: the tile is staged before it is written)
+};
+
+__global__ __launch_bounds__(256) void tile_abt_kernel(TileOp op) {
+    __shared__ double As[TB * LDR], Bs[TB * LDR];
+    int p = blockIdx.x, q = blockIdx.y;
+    if (op.tri) {
+        // blockIdx.x = p(p+1)/2 + q
+        int t = blockIdx.x;
+        p = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((p + 1) * (p + 2) / 2 <= t) p++;
+        while (p * (p + 1) / 2 > t) p--;
+        q = t - p * (p + 1) / 2;
+    }
+    const double *A = op.A + p * op.a_p + q * op.a_q;
+    const double *B = op.B + p * op.b_p + q * op.b_q;
+    double *C = op.C + p * op.c_p + q * op.c_q;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // stage: a wave reads one 512-byte row segment per instruction (coalesced), LDS rows are contiguous
+    for (int i = 0; i < TB / 4; i++) {
+        int row = i * 4 + w;
+        As[row * LDR + lane] = A[(long long)row * op.lda + lane];
+        Bs[row * LDR + lane] = B[(long long)row * op.ldb + lane];
+    }
+    __syncthreads();
+    const int r0 = (w >> 1) * 32, c0 = (w & 1) * 32;   // this wave's 32x32 quadrant
+    const int li = lane & 15, lk = lane >> 4;
+    d4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 2; y++) acc[x][y] = d4{0, 0, 0, 0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < TB; k0 += 4) {
+        // A fragment: A[row = li][k = lk]; B fragment: B[k = lk][col = li] = Bt[col][k]
+        double a0 = As[(r0 + li) * LDR + k0 + lk], a1 = As[(r0 + 16 + li) * LDR + k0 + lk];
+        double b0 = Bs[(c0 + li) * LDR + k0 + lk], b1 = Bs[(c0 + 16 + li) * LDR + k0 + lk];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 2; y++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int row = r0 + 16 * x + lk + 4 * r, col = c0 + 16 * y + li;
+                double *dst = C + (long long)row * op.ldc + col;
+                *dst = op.subtract ? (*dst - acc[x][y][r]) : acc[x][y][r];
+            }
+}
+
+// Factor the 64x64 diagonal block at Ajj (lower Cholesky, in place, strict upper zeroed) and write
+// its inverse (dense 64x64, row-major, strict upper zero) to Linv. *bad is set if a pivot is not positive.
+__global__ __launch_bounds__(256) void diag_potrf_kernel(double *Ajj, int ld, double *Linv, int *bad, int factor) {
+    __shared__ double L[TB * 65], Li[TB * 65], red[256], rdiag[TB];
+    __shared__ int flag;
+    Ajj += (long long)blockIdx.x * TB * ((long long)ld + 1);
+    Linv += (long long)blockIdx.x * TB * TB;
+    const int tid = threadIdx.x;
+    if (tid == 0) flag = 0;
+    for (int it = tid; it < TB * TB; it += 256) {
+        int r = it >> 6, c = it & 63;
+        L[r * 65 + c] = (c <= r) ? Ajj[(long long)r * ld + c] : 0.0;
+    }
+    __syncthreads();
+    Team<256> T{tid, red, &flag};
+    if (factor) {
+        chol_lower<256>(T, L, TB, 65, rdiag);
+        if (tid == 0 && flag) *bad = 1;
+        for (int it = tid; it < TB * TB; it += 256) {
+            int r = it >> 6, c = it & 63;
+            Ajj[(long long)r * ld + c] = L[r * 65 + c];
+        }
+    } else {
+        if (tid < TB) rdiag[tid] = 1.0 / L[tid * 65 + tid];
+        __syncthreads();
+    }
+    tri_inverse_lower<256>(T, L, Li, TB, 65, rdiag);
+    for (int it = tid; it < TB * TB; it += 256) {
+        int r = it >> 6, c = it & 63;
+        Linv[it] = Li[r * 65 + c];
+    }
+}
+
+// pad rows [n, N) of an N x N matrix get a unit diagonal
+__global__ void pad_identity_kernel(double *M, int ld, int n0, int n1) {
+    int i = n0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n1) M[(long long)i * ld + i] = 1.0;
+}
+
+// Y = L^T (upper triangular copy; the strict lower triangle of Y becomes 0)
+__global__ void transpose_lower_kernel(const double *L, int ldl, double *Y, int ldy, int n) {
+    __shared__ double t[32][33];
+    int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // Y tile at rows by.., cols bx..
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 256 threads: 8 rows per pass
+    for (int i = ty; i < 32; i += 8) {
+        int r = bx + i, c = by + tx;                  // L[r][c] -> Y[c][r]
+        t[i][tx] = (r < n && c < n && c <= r) ? L[(long long)r * ldl + c] : 0.0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int r = by + i, c = bx + tx;
+        if (r < n && c < n) Y[(long long)r * ldy + c] = t[tx][i];
+    }
+}
+
+// out[0] += sum of squares of M (n x n); out[1] += 2 * sum log diag(La); out[2] += 2 * sum log diag(Lb)
+__global__ __launch_bounds__(256) void sumsq_kernel(const double *M, int ld, int n, double *partial) {
+    __shared__ double red[256];
+    double s = 0;
+    long long tot = (long long)n * n;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < tot; it += (long long)gridDim.x * 256) {
+        long long r = it / n, c = it - r * n;
+        double v = M[r * ld + c];
+        s += v * v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// one workgroup: out[0] = sum partial[0..np), out[1] = 2 sum_{i<n} log La[i][i], out[2] = 2 sum log Lb[i][i],
+// out[3] = || Y^T... the Mahalanobis term: sum_r (sum_c Y[r][c] diff[c])^2 with Y = L_x^T (upper)
+__global__ __launch_bounds__(256) void finish_kernel(const double *partial, int np, const double *La, int lda, const double *Lb, int ldb,
+                                                     int n, const double *Y, int ldy, const double *diff, double *out) {
+    __shared__ double red[256];
+    auto reduce = [&](double v) {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    double s = 0;
+    for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+    double t0 = reduce(s);
+    s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s += log(La[(long long)i * lda + i]);
+    double t1 = 2.0 * reduce(s);
+    s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s += log(Lb[(long long)i * ldb + i]);
+    double t2 = 2.0 * reduce(s);
+    s = 0;
+    if (diff) {
+        for (int r = threadIdx.x; r < n; r += 256) {
+            double v = 0;
+            for (int c = r; c < n; c++) v += Y[(long long)r * ldy + c] * diff[c];
+            s += v * v;
+        }
+    }
+    double t3 = reduce(s);
+    if (threadIdx.x == 0) { out[0] = t0; out[1] = t1; out[2] = t2; out[3] = t3; }
+}
+
+// ------------------------------------------------------------------------------------------ assembly
+struct GraphDev {
+    const double *arena;
+    const int32_t *pos;       // per vertex: scalar offset of its block in the matrix, -1 = not a variable
+    const int64_t *vpo;       // per vertex: pose offset in the arena
+    const int32_t *rowptr;    // CSR: incident live edges per vertex (ascending edge index)
+    const int32_t *inc;
+    const spg_edge_ref *er;
+    const int32_t *ev;        // edge -> global vertex indices
+    const int64_t *aw_off;    // per edge: offset of its weighted Jacobian in aw (GLC edges), -1 otherwise
+    double *aw;
+    int nv, ne;
+};
+
+template <int D>
+__device__ __forceinline__ void load_pose(const double *arena, int64_t off, double *X) {
+    if (D == 6) iso_from_tq(arena + off, X);
+    else { X[0] = arena[off]; X[1] = arena[off + 1]; X[2] = arena[off + 2]; }
+}
+
+// A_e = W_e * J_reparam (r x dq) of every GLC edge (src/glc_edge.cpp:40-49,
+// src/glc_reparam_binary.hpp:78-127): one workgroup per edge, result in g.aw.
+template <int D>
+__global__ __launch_bounds__(64) void glc_weighted_jacobian_kernel(GraphDev g) {
+    constexpr int DD = D * D, PSZ = (D == 6) ? kIso : 3;
+    extern __shared__ double Jb[];   // q x (Ji0 | Jii)
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const spg_edge_ref er = g.er[e];
+    if (er.kind != SPG_EDGE_GLC) return;
+    const int q = er.nv, dq = D * q, rr = (er.len - dq) / dq;
+    const double *rec = g.arena + er.off;
+    double *Aw = g.aw + g.aw_off[e];
+    for (int i = tid; i < q; i += 64) {
+        double X0[PSZ], Xi[PSZ];
+        load_pose<D>(g.arena, g.vpo[g.ev[er.vbegin]], X0);
+        load_pose<D>(g.arena, g.vpo[g.ev[er.vbegin + i]], Xi);
+        if (D == 6) {
+            double Z[kIso], Xz[kIso] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+            iso_from_mqt(rec + 6 * i, Z);
+            if (i == 0) se3_edge_jac(Xz, X0, Z, Jb, Jb + DD, nullptr);
+            else se3_edge_jac(X0, Xi, Z, Jb + i * 2 * DD, Jb + i * 2 * DD + DD, nullptr);
+        } else {
+            double xz[3] = {0, 0, 0};
+            if (i == 0) se2_edge_jac(xz, X0, rec, Jb, Jb + DD, nullptr);
+            else se2_edge_jac(X0, Xi, rec + 3 * i, Jb + i * 2 * DD, Jb + i * 2 * DD + DD, nullptr);
+        }
+    }
+    __syncthreads();
+    for (int it = tid; it < rr * dq; it += 64) {
+        int row = it / dq, col = it - row * dq, blk = col / D, c = col - blk * D;
+        const double *Wr = rec + dq + (int64_t)row * dq;
+        double s = 0;
+        if (blk == 0) {
+            for (int p = 0; p < D; p++) s += Wr[p] * Jb[DD + p * D + c];
+            for (int i = 1; i < q; i++)
+                for (int p = 0; p < D; p++) s += Wr[i * D + p] * Jb[i * 2 * DD + p * D + c];
+        } else {
+            for (int p = 0; p < D; p++) s += Wr[blk * D + p] * Jb[blk * 2 * DD + DD + p * D + c];
+        }
+        Aw[it] = s;
+    }
+}
+
+// H = sum_e J_e^T Omega_e J_e over the live edges, rows of vertex v by workgroup v (one wavefront):
+// deterministic (edges in ascending index), no atomics. Only the lower block triangle (pos(u) <=
+// pos(v)) is written; diagonal blocks are written in full.
+template <int D>
+__global__ __launch_bounds__(64) void dense_assemble_kernel(GraphDev g, double *M, int ld) {
+    constexpr int DD = D * D, PS = (D == 6) ? 7 : 3, PSZ = (D == 6) ? kIso : 3;
+    __shared__ double Jv[DD], Ju[DD], Om[DD], Tv[DD], Tu[DD];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const int pv = g.pos[v];
+    if (pv < 0) return;
+    const int r = tid / D, c = tid - r * D;      // lanes < DD own one entry of a d x d block
+    const bool act = tid < DD;
+    double diag = 0;
+    for (int ii = g.rowptr[v]; ii < g.rowptr[v + 1]; ii++) {
+        const int e = g.inc[ii];
+        const spg_edge_ref er = g.er[e];
+        if (er.kind == SPG_EDGE_BINARY) {
+            const int vi = g.ev[er.vbegin], vj = g.ev[er.vbegin + 1];
+            if (vi == vj) continue;
+            const double *rec = g.arena + er.off;
+            if (tid == 0) {
+                double Xi[PSZ], Xj[PSZ];
+                load_pose<D>(g.arena, g.vpo[vi], Xi);
+                load_pose<D>(g.arena, g.vpo[vj], Xj);
+                double *Ji = (v == vi) ? Jv : Ju, *Jj = (v == vi) ? Ju : Jv;
+                if (D == 6) {
+                    double Z[kIso];
+                    iso_from_tq(rec, Z);
+                    se3_edge_jac(Xi, Xj, Z, Ji, Jj, nullptr);
+                } else {
+                    se2_edge_jac(Xi, Xj, rec, Ji, Jj, nullptr);
+                }
+            }
+            if (act) {
+                int lo = r < c ? r : c, hi = r < c ? c : r;
+                Om[tid] = rec[PS + lo * D - lo * (lo - 1) / 2 + (hi - lo)];
+            }
+            __syncthreads();
+            if (act) {
+                double sv = 0, su = 0;
+#pragma unroll
+                for (int p = 0; p < D; p++) { sv += Om[r * D + p] * Jv[p * D + c]; su += Om[r * D + p] * Ju[p * D + c]; }
+                Tv[tid] = sv; Tu[tid] = su;
+            }
+            __syncthreads();
+            const int u = (v == vi) ? vj : vi, pu = g.pos[u];
+            if (act) {
+                double sd = 0, so = 0;
+#pragma unroll
+                for (int p = 0; p < D; p++) { sd += Jv[p * D + r] * Tv[p * D + c]; so += Jv[p * D + r] * Tu[p * D + c]; }
+                diag += sd;
+                if (pu >= 0 && pu < pv) M[(long long)(pv + r) * ld + pu + c] += so;
+            }
+            __syncthreads();
+        } else {
+            const int q = er.nv, dq = D * q, rr = (er.len - dq) / dq;
+            const double *Aw = g.aw + g.aw_off[e];
+            int iv = 0;
+            for (int i = 0; i < q; i++) if (g.ev[er.vbegin + i] == v) iv = i;
+            if (act) {
+                for (int iu = 0; iu < q; iu++) {
+                    const int u = g.ev[er.vbegin + iu], pu = g.pos[u];
+                    if (!(u == v || (pu >= 0 && pu < pv))) continue;
+                    double s = 0;
+                    for (int p = 0; p < rr; p++) s += Aw[(int64_t)p * dq + iv * D + r] * Aw[(int64_t)p * dq + iu * D + c];
+                    if (u == v) diag += s;
+                    else M[(long long)(pv + r) * ld + pu + c] += s;
+                }
+            }
+        }
+    }
+    if (act) M[(long long)(pv + r) * ld + pv + c] = diag;
+}
+
+// estimateDifference (src/graph_wrapper_g2o.cpp:550-575): one lane per kept vertex
+template <int D>
+__global__ void pose_diff_kernel(const double *arena_b, const int64_t *vpo_b, const double *arena_o, const int64_t *vpo_o, int nk, double *diff) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nk) return;
+    const double *xb = arena_b + vpo_b[i], *xo = arena_o + vpo_o[i];
+    if (D == 3) {
+        diff[3 * i] = xb[0] - xo[0];
+        diff[3 * i + 1] = xb[1] - xo[1];
+        diff[3 * i + 2] = normalize_theta(xb[2] - xo[2]);
+    } else {
+        double Xb[kIso], Xo[kIso], E[kIso], qd[4];
+        iso_from_tq(xb, Xb);
+        iso_from_tq(xo, Xo);
+        iso_inv_mul(Xb, Xo, E);
+        R_to_quat(E, qd);
+        diff[6 * i] = E[9]; diff[6 * i + 1] = E[10]; diff[6 * i + 2] = E[11];
+        diff[6 * i + 3] = qd[0]; diff[6 * i + 4] = qd[1]; diff[6 * i + 5] = qd[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+template <class T>
+int upload(DevBuf &b, const T *src, size_t n, hipStream_t s) {
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    if (hipMalloc(&b.p, bytes) != hipSuccess) return SPG_ENOMEM;
+    (void)s;   // synchronous: the sources are short-lived pageable host vectors
+    if (n && hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return SPG_EHIP;
+    return 0;
+}
+
+struct GraphBufs {
+    DevBuf pos, vpo, rowptr, inc, er, ev, awoff, aw;
+    GraphDev dev{};
+    int max_q = 0;
+    bool has_glc = false;
+};
+
+int stage_graph(const spg::DenseGraphIn &in, GraphBufs &gb, hipStream_t s) {
+    std::vector<int64_t> awoff((size_t)in.ne, -1);
+    int64_t aw_total = 0;
+    for (int e = 0; e < in.ne; e++) {
+        if (in.er[e].kind != SPG_EDGE_GLC) continue;
+        int q = in.er[e].nv, dq = in.D * q;
+        if (q <= 0 || in.er[e].len < dq || (in.er[e].len - dq) % dq) return SPG_EINVAL;
+        awoff[e] = aw_total;
+        aw_total += (int64_t)(in.er[e].len - dq);
+        gb.max_q = std::max(gb.max_q, q);
+        gb.has_glc = true;
+    }
+    if ((size_t)gb.max_q * 2 * in.D * in.D * sizeof(double) > 60000) return SPG_ECAPACITY;   // LDS staging of one GLC edge's Jacobians
+    int rc;
+    if ((rc = upload(gb.pos, in.pos, (size_t)in.nv, s))) return rc;
+    if ((rc = upload(gb.vpo, in.vpo, (size_t)in.nv, s))) return rc;
+    if ((rc = upload(gb.rowptr, in.rowptr, (size_t)in.nv + 1, s))) return rc;
+    if ((rc = upload(gb.inc, in.inc, (size_t)in.rowptr[in.nv], s))) return rc;
+    if ((rc = upload(gb.er, in.er, (size_t)in.ne, s))) return rc;
+    if ((rc = upload(gb.ev, in.ev, (size_t)in.n_ev, s))) return rc;
+    if ((rc = upload(gb.awoff, awoff.data(), awoff.size(), s))) return rc;
+    if (hipMalloc(&gb.aw.p, std::max<int64_t>(aw_total, 1) * 8) != hipSuccess) return SPG_ENOMEM;
+    gb.dev = GraphDev{(const double *)in.dev_arena, (const int32_t *)gb.pos.p, (const int64_t *)gb.vpo.p,
+                      (const int32_t *)gb.rowptr.p, (const int32_t *)gb.inc.p, (const spg_edge_ref *)gb.er.p,
+                      (const int32_t *)gb.ev.p, (const int64_t *)gb.awoff.p, (double *)gb.aw.p, in.nv, in.ne};
+    return 0;
+}
+
+template <int D>
+void launch_assemble(const GraphBufs &gb, double *M, int ld, hipStream_t s) {
+    if (gb.has_glc) {
+        size_t sh = (size_t)gb.max_q * 2 * D * D * sizeof(double);
+        hipLaunchKernelGGL((glc_weighted_jacobian_kernel<D>), dim3(gb.dev.ne), dim3(64), sh, s, gb.dev);
+    }
+    hipLaunchKernelGGL((dense_assemble_kernel<D>), dim3(gb.dev.nv), dim3(64), 0, s, gb.dev, M, ld);
+}
+
+void launch_tiles(const TileOp &op, int gx, int gy, hipStream_t s) {
+    if (gx <= 0 || gy <= 0) return;
+    hipLaunchKernelGGL(tile_abt_kernel, dim3(gx, gy), dim3(256), 0, s, op);
+}
+
+// Blocked right-looking lower Cholesky of the N x N matrix M (N a multiple of 64), in place.
+void potrf_lower(double *M, int N, double *linv /*64*64*/, int *bad, hipStream_t s) {
+    const int nt = N / TB;
+    const long long ld = N;
+    for (int j = 0; j < nt; j++) {
+        hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(256), 0, s, M + (long long)j * TB * (ld + 1), N, linv, bad, 1);
+        const int rem = nt - j - 1;
+        if (rem == 0) break;
+        double *panel = M + ((long long)(j + 1) * TB * ld + (long long)j * TB);
+        TileOp trsm{panel, panel, linv, TB * ld, 0, TB * ld, 0, 0, 0, N, N, TB, 0, 0};
+        launch_tiles(trsm, rem, 1, s);
+        double *trail = M + (long long)(j + 1) * TB * (ld + 1);
+        TileOp syrk{trail, panel, panel, TB * ld, TB, TB * ld, 0, 0, TB * ld, N, N, N, 1, 1};
+        launch_tiles(syrk, rem * (rem + 1) / 2, 1, s);
+    }
+}
+
+// Y <- Y * Ls^-T for upper-triangular Y (Ng x Ng, ldy) and lower-triangular Ls (ld), tile-aligned.
+void rsolve_lower_transposed(double *Y, int ldy, const double *Ls, int ld, int Ng, double *linv_all, int *bad, hipStream_t s) {
+    const int nt = Ng / TB;
+    hipLaunchKernelGGL(diag_potrf_kernel, dim3(nt), dim3(256), 0, s, const_cast<double *>(Ls), ld, linv_all, bad, 0);
+    for (int c = 0; c < nt; c++) {
+        double *col = Y + (long long)c * TB;
+        TileOp scale{col, col, linv_all + (long long)c * TB * TB, (long long)TB * ldy, 0, (long long)TB * ldy, 0, 0, 0, ldy, ldy, TB, 0, 0};
+        launch_tiles(scale, c + 1, 1, s);
+        const int rem = nt - c - 1;
+        if (rem == 0) break;
+        const double *lpanel = Ls + ((long long)(c + 1) * TB * ld + (long long)c * TB);
+        TileOp upd{Y + (long long)(c + 1) * TB, col, lpanel, (long long)TB * ldy, TB, (long long)TB * ldy, 0, 0, (long long)TB * ld, ldy, ldy, ld, 0, 1};
+        launch_tiles(upd, c + 1, rem, s);
+    }
+}
+
+inline int round_up(int n) { return (n + TB - 1) / TB * TB; }
+
+}  // namespace
+
+namespace spg {
+
+// Dense information matrix of one graph (variables = vertices with pos >= 0, n = D * count), host
+// output n x n row-major, full symmetric.
+int hip_dense_information(void *stream, const DenseGraphIn &in, int n, double *out, char *err, size_t errlen) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = 0;
+    const int N = round_up(std::max(n, 1));
+    GraphBufs gb;
+    DevBuf M;
+    std::vector<double> h;
+    if (hipMalloc(&M.p, (size_t)N * N * 8) != hipSuccess) { snprintf(err, errlen, "hipMalloc of a %d x %d matrix failed", N, N); return SPG_ENOMEM; }
+    HIPCHK(hipMemsetAsync(M.p, 0, (size_t)N * N * 8, s));
+    if ((rc = stage_graph(in, gb, s))) { snprintf(err, errlen, "staging the graph for dense assembly failed (%d)", rc); goto done; }
+    if (in.D == 6) launch_assemble<6>(gb, (double *)M.p, N, s);
+    else launch_assemble<3>(gb, (double *)M.p, N, s);
+    HIPCHK(hipGetLastError());
+    h.resize((size_t)N * N);
+    HIPCHK(hipMemcpyAsync(h.data(), M.p, (size_t)N * N * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) out[(size_t)i * n + j] = (j <= i) ? h[(size_t)i * N + j] : h[(size_t)j * N + i];
+done:
+    return rc;
+}
+
+// Global KLD. base.pos orders the baseline's variables [marginalised | pad | kept | pad] with the
+// kept block starting at Nm (multiple of 64); other.pos orders other's variables [kept | pad].
+// kept_vpo_*: pose offsets of the kept vertices in both arenas, in kept order.
+int hip_dense_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &other, int n_marg, int n_keep,
+                  const int64_t *kept_vpo_base, const int64_t *kept_vpo_other, double *terms, double *seconds,
+                  char *err, size_t errlen) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = 0;
+    const int D = base.D, nk = n_keep / D;
+    const int Nm = round_up(n_marg), Ng = round_up(std::max(n_keep, 1)), N = Nm + Ng, ntg = Ng / TB;
+    GraphBufs gb, go;
+    DevBuf Mb, X, Y, linv, linv_all, bad, partial, outb, diff, vb, vo;
+    int h_bad[2] = {0, 0};
+    double h_out[4] = {0, 0, 0, 0};
+    const int np = 1024;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0;
+    if (hipMalloc(&Mb.p, (size_t)N * N * 8) != hipSuccess || hipMalloc(&X.p, (size_t)Ng * Ng * 8) != hipSuccess ||
+        hipMalloc(&Y.p, (size_t)Ng * Ng * 8) != hipSuccess) {
+        snprintf(err, errlen, "hipMalloc of the dense KLD matrices failed (N = %d, Ng = %d)", N, Ng);
+        return SPG_ENOMEM;
+    }
+    HIPCHK(hipMalloc(&linv.p, TB * TB * 8));
+    HIPCHK(hipMalloc(&linv_all.p, (size_t)ntg * TB * TB * 8));
+    HIPCHK(hipMalloc(&bad.p, 2 * sizeof(int)));
+    HIPCHK(hipMalloc(&partial.p, np * 8));
+    HIPCHK(hipMalloc(&outb.p, 4 * 8));
+    HIPCHK(hipMalloc(&diff.p, (size_t)Ng * 8));
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    if ((rc = upload(vb, kept_vpo_base, (size_t)nk, s)) || (rc = upload(vo, kept_vpo_other, (size_t)nk, s)) ||
+        (rc = stage_graph(base, gb, s)) || (rc = stage_graph(other, go, s))) {
+        snprintf(err, errlen, "staging the graphs for the dense KLD failed (%d)", rc);
+        goto done;
+    }
+    HIPCHK(hipEventRecord(e0, s));
+    HIPCHK(hipMemsetAsync(Mb.p, 0, (size_t)N * N * 8, s));
+    HIPCHK(hipMemsetAsync(X.p, 0, (size_t)Ng * Ng * 8, s));
+    HIPCHK(hipMemsetAsync(bad.p, 0, 2 * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(diff.p, 0, (size_t)Ng * 8, s));
+    if (D == 6) { launch_assemble<6>(gb, (double *)Mb.p, N, s); launch_assemble<6>(go, (double *)X.p, Ng, s); }
+    else { launch_assemble<3>(gb, (double *)Mb.p, N, s); launch_assemble<3>(go, (double *)X.p, Ng, s); }
+    if (Nm > n_marg) hipLaunchKernelGGL(pad_identity_kernel, dim3((Nm - n_marg + 255) / 256), dim3(256), 0, s, (double *)Mb.p, N, n_marg, Nm);
+    if (Ng > n_keep) {
+        hipLaunchKernelGGL(pad_identity_kernel, dim3((Ng - n_keep + 255) / 256), dim3(256), 0, s, (double *)Mb.p, N, Nm + n_keep, N);
+        hipLaunchKernelGGL(pad_identity_kernel, dim3((Ng - n_keep + 255) / 256), dim3(256), 0, s, (double *)X.p, Ng, n_keep, Ng);
+    }
+    if (D == 6) hipLaunchKernelGGL((pose_diff_kernel<6>), dim3((nk + 63) / 64), dim3(64), 0, s, (const double *)base.dev_arena, (const int64_t *)vb.p, (const double *)other.dev_arena, (const int64_t *)vo.p, nk, (double *)diff.p);
+    else hipLaunchKernelGGL((pose_diff_kernel<3>), dim3((nk + 63) / 64), dim3(64), 0, s, (const double *)base.dev_arena, (const int64_t *)vb.p, (const double *)other.dev_arena, (const int64_t *)vo.p, nk, (double *)diff.p);
+    potrf_lower((double *)Mb.p, N, (double *)linv.p, (int *)bad.p, s);
+    potrf_lower((double *)X.p, Ng, (double *)linv.p, (int *)bad.p + 1, s);
+    {
+        const double *Ls = (const double *)Mb.p + ((long long)Nm * N + Nm);
+        hipLaunchKernelGGL(transpose_lower_kernel, dim3(Ng / 32, Ng / 32), dim3(256), 0, s, (const double *)X.p, Ng, (double *)Y.p, Ng, Ng);
+        // Mahalanobis and log-dets need Y = L_x^T before the solve overwrites it
+        hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, s, (const double *)partial.p, 0, (const double *)X.p, Ng, Ls, N, Ng,
+                           (const double *)Y.p, Ng, (const double *)diff.p, (double *)outb.p);
+        HIPCHK(hipMemcpyAsync(h_out, outb.p, 4 * 8, hipMemcpyDeviceToHost, s));
+        rsolve_lower_transposed((double *)Y.p, Ng, Ls, N, Ng, (double *)linv_all.p, (int *)bad.p, s);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(np), dim3(256), 0, s, (const double *)Y.p, Ng, Ng, (double *)partial.p);
+        hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, s, (const double *)partial.p, np, (const double *)X.p, Ng, Ls, N, 0,
+                           (const double *)Y.p, Ng, (const double *)nullptr, (double *)outb.p);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, s));
+    {
+        double h_sum[4];
+        HIPCHK(hipStreamSynchronize(s));   // h_out (first finish) is in place
+        double logdetx = h_out[1], logdet_s = h_out[2], mahal = h_out[3];
+        HIPCHK(hipMemcpy(h_sum, outb.p, 4 * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h_bad, bad.p, 2 * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (h_bad[0] || h_bad[1]) {
+            snprintf(err, errlen, "global KLD: %s information matrix is not positive definite", h_bad[0] ? "the baseline" : "the sparsified");
+            rc = SPG_ENOTPD;
+            goto done;
+        }
+        const double innerprod = h_sum[0] - (double)(Ng - n_keep);   // the unit pad rows contribute 1 each
+        const double logdety = -logdet_s;                            // reference sign (mode InformationInformation)
+        terms[0] = 0.5 * (innerprod + mahal - logdetx - logdety - n_keep);
+        terms[1] = innerprod; terms[2] = mahal; terms[3] = logdetx; terms[4] = logdety; terms[5] = n_keep;
+        if (seconds) *seconds = 1e-3 * ms;
+    }
+done:
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+}
+
+}  // namespace spg

@@ -1527,3 +1527,141 @@ extern "C" int spg_graph_substitute_edge(spg_graph *g, const int32_t *marginaliz
     if (*from == toConnect) *to = minid; else *from = minid;
     return 0;
 }
+
+// ================================================================================= global KLD (a18)
+namespace {
+struct DenseStage {
+    std::vector<int32_t> pos, rowptr, inc, ev;
+    std::vector<spg_edge_ref> er;
+    spg::DenseGraphIn in;
+};
+
+// Live vertex indices in ascending id order.
+std::vector<int32_t> live_vertices_by_id(const spg_graph *g) {
+    std::vector<int32_t> v;
+    for (size_t i = 0; i < g->vid.size(); i++) if (g->valive[i]) v.push_back((int32_t)i);
+    std::sort(v.begin(), v.end(), [&](int32_t a, int32_t b) { return g->vid[a] < g->vid[b]; });
+    return v;
+}
+
+// st.pos must be filled (size = number of vertex slots, -1 = not a variable).
+void build_dense_stage(spg_graph *g, DenseStage &st) {
+    const int nv = (int)g->vid.size();
+    std::vector<int32_t> remap(g->edges.size(), -1);
+    for (size_t e = 0; e < g->edges.size(); e++) {
+        const GEdge &ge = g->edges[e];
+        if (!ge.alive) continue;
+        remap[e] = (int32_t)st.er.size();
+        st.er.push_back({ge.off, ge.len, ge.kind, (int32_t)st.ev.size(), ge.nv});
+        for (int i = 0; i < ge.nv; i++) st.ev.push_back(g->everts[ge.vbeg + i]);
+    }
+    st.rowptr.assign((size_t)nv + 1, 0);
+    for (int v = 0; v < nv; v++) {
+        if (g->valive[v]) {
+            std::vector<int32_t> es;
+            for (int32_t e : g->adj[v]) if (remap[e] >= 0) es.push_back(remap[e]);
+            std::sort(es.begin(), es.end());
+            es.erase(std::unique(es.begin(), es.end()), es.end());
+            st.inc.insert(st.inc.end(), es.begin(), es.end());
+        }
+        st.rowptr[v + 1] = (int32_t)st.inc.size();
+    }
+    st.in.D = g->d; st.in.nv = nv; st.in.ne = (int)st.er.size();
+    st.in.pos = st.pos.data(); st.in.vpo = g->vpose.data(); st.in.rowptr = st.rowptr.data(); st.in.inc = st.inc.data();
+    st.in.er = st.er.data(); st.in.ev = st.ev.data(); st.in.n_ev = (int64_t)st.ev.size(); st.in.dev_arena = g->dev;
+}
+
+int resolve_fixed(const spg_graph *g, const std::vector<int32_t> &order, int32_t fixed_id) {
+    if (order.empty()) return -1;
+    if (fixed_id < 0) return order[0];   // the reference skips its first (smallest-id) vertex
+    auto it = g->vidx.find(fixed_id);
+    if (it == g->vidx.end() || !g->valive[it->second]) return -1;
+    return it->second;
+}
+}  // namespace
+
+extern "C" int64_t spg_graph_information(spg_graph *g, int32_t fixed_id, double *out, int64_t cap) {
+    if (!g || g->active) return SPG_EINVAL;
+    std::vector<int32_t> order = live_vertices_by_id(g);
+    int fixed = resolve_fixed(g, order, fixed_id);
+    if (fixed < 0) return set_err(g->ctx, SPG_EINVAL, "spg_graph_information: the fixed vertex is not in the graph");
+    const int64_t n = (int64_t)g->d * ((int64_t)order.size() - 1);
+    if (!out || cap < n * n) return n;
+    if (!g->ctx->is_hip) return set_err(g->ctx, SPG_ESTATE, "spg_graph_information needs the HIP backend");
+    if (int rc = sync_device(g)) return rc;
+    if (int rc = g->ctx->be.synchronize(g->ctx->be.user)) return rc;
+    DenseStage st;
+    st.pos.assign(g->vid.size(), -1);
+    int p = 0;
+    for (int32_t v : order) if (v != fixed) { st.pos[v] = p; p += g->d; }
+    build_dense_stage(g, st);
+    g->ctx->err[0] = 0;
+    int rc = spg::hip_dense_information(spg::hip_backend_stream(&g->ctx->be), st.in, (int)n, out, g->ctx->err, sizeof g->ctx->err);
+    return rc ? rc : n;
+}
+
+extern "C" int spg_graph_kullback_leibler(spg_graph *base, spg_graph *other, int32_t fixed_id, spg_kld_terms *out) {
+    if (!base || !other || !out || base->active || other->active) return SPG_EINVAL;
+    spg_ctx *ctx = base->ctx;
+    if (base->d != other->d) return set_err(ctx, SPG_EINVAL, "spg_graph_kullback_leibler: pose dimensions differ");
+    if (!ctx->is_hip || !other->ctx->is_hip) return set_err(ctx, SPG_ESTATE, "spg_graph_kullback_leibler needs the HIP backend");
+    if (spg::hip_backend_device(&ctx->be) != spg::hip_backend_device(&other->ctx->be))
+        return set_err(ctx, SPG_EINVAL, "spg_graph_kullback_leibler: both graphs must live on the same device");
+    const int d = base->d;
+    std::vector<int32_t> ob = live_vertices_by_id(base), oo = live_vertices_by_id(other);
+    int fb = resolve_fixed(base, ob, fixed_id);
+    if (fb < 0) return set_err(ctx, SPG_EINVAL, "spg_graph_kullback_leibler: the fixed vertex is not in the baseline");
+    const int32_t fid = base->vid[fb];
+    int fo = resolve_fixed(other, oo, fid);
+    if (fo < 0) return set_err(ctx, SPG_EINVAL, "spg_graph_kullback_leibler: the fixed vertex is not in the sparsified graph");
+    // computeIndices (src/graph_wrapper_g2o.cpp:472-499): merge of the two id-sorted vertex lists
+    std::vector<int32_t> kept_b, kept_o, marg_b;
+    {
+        size_t j = 0;
+        for (int32_t v : ob) {
+            if (v == fb) continue;
+            while (j < oo.size() && (oo[j] == fo || other->vid[oo[j]] < base->vid[v])) {
+                if (oo[j] != fo) return set_err(ctx, SPG_EINVAL, "spg_graph_kullback_leibler: the sparsified graph holds a vertex the baseline lacks");
+                j++;
+            }
+            if (j < oo.size() && other->vid[oo[j]] == base->vid[v]) { kept_b.push_back(v); kept_o.push_back(oo[j]); j++; }
+            else marg_b.push_back(v);
+        }
+        for (; j < oo.size(); j++)
+            if (oo[j] != fo) return set_err(ctx, SPG_EINVAL, "spg_graph_kullback_leibler: the sparsified graph holds a vertex the baseline lacks");
+    }
+    if (kept_b.empty()) return set_err(ctx, SPG_EINVAL, "spg_graph_kullback_leibler: no common free vertex");
+    const int64_t n_marg = (int64_t)d * marg_b.size(), n_keep = (int64_t)d * kept_b.size();
+    const int64_t Nm = (n_marg + 63) / 64 * 64, Ng = (n_keep + 63) / 64 * 64;
+    if (Nm + Ng > 46000) return set_err(ctx, SPG_ECAPACITY, "spg_graph_kullback_leibler: dense formulation limited to 46k variables (16 GB)");
+    if (int rc = sync_device(base)) return rc;
+    if (int rc = sync_device(other)) return rc;
+    if (int rc = ctx->be.synchronize(ctx->be.user)) return rc;
+    if (other->ctx != ctx) if (int rc = other->ctx->be.synchronize(other->ctx->be.user)) return rc;
+    DenseStage sb, so;
+    sb.pos.assign(base->vid.size(), -1);
+    so.pos.assign(other->vid.size(), -1);
+    std::vector<int64_t> kvb, kvo;
+    {
+        int p = 0;
+        for (int32_t v : marg_b) { sb.pos[v] = p; p += d; }
+        p = (int)Nm;
+        int q = 0;
+        for (size_t i = 0; i < kept_b.size(); i++) {
+            sb.pos[kept_b[i]] = p; p += d;
+            so.pos[kept_o[i]] = q; q += d;
+            kvb.push_back(base->vpose[kept_b[i]]);
+            kvo.push_back(other->vpose[kept_o[i]]);
+        }
+    }
+    build_dense_stage(base, sb);
+    build_dense_stage(other, so);
+    double terms[6] = {0, 0, 0, 0, 0, 0}, secs = 0;
+    ctx->err[0] = 0;
+    int rc = spg::hip_dense_kld(spg::hip_backend_stream(&ctx->be), sb.in, so.in, (int)n_marg, (int)n_keep, kvb.data(), kvo.data(),
+                                terms, &secs, ctx->err, sizeof ctx->err);
+    if (rc) return rc;
+    out->kld = terms[0]; out->innerprod = terms[1]; out->mahalanobis = terms[2]; out->logdetx = terms[3];
+    out->logdety = terms[4]; out->n = (int64_t)terms[5]; out->n_marginalized = n_marg; out->device_seconds = secs;
+    return 0;
+}

@@ -1,6 +1,7 @@
 // csrc/spg_internal.h — declarations shared between the HIP translation unit and the host code.
 #pragma once
 #include <cstddef>
+#include <cstdint>
 #include "../../include/spg.h"
 
 namespace spg {
@@ -11,7 +12,25 @@ void hip_backend_destroy(spg_backend *b);
 void *hip_backend_stream(spg_backend *b);
 const char *hip_backend_error(spg_backend *b);
 int hip_backend_launches(spg_backend *b);
+int hip_backend_device(spg_backend *b);
 void hip_backend_profile(spg_backend *b, int enable);
 void hip_backend_profile_read(spg_backend *b, double *ms, double *bytes, long long *launches, long long *blankets);
+
+// Dense global KLD (spg_dense.hip). Host-staged description of one graph for the dense assembly.
+struct DenseGraphIn {
+    int D = 0, nv = 0, ne = 0;
+    const int32_t *pos = nullptr;       // [nv] scalar offset of the vertex block in the dense matrix, -1 = not a variable
+    const int64_t *vpo = nullptr;       // [nv] pose offset in the arena
+    const int32_t *rowptr = nullptr;    // [nv+1] CSR of incident live edges (indices into er, ascending)
+    const int32_t *inc = nullptr;
+    const spg_edge_ref *er = nullptr;   // [ne] live edges; vbegin indexes ev
+    const int32_t *ev = nullptr;        // vertex indices of the edges
+    int64_t n_ev = 0;
+    const void *dev_arena = nullptr;    // device arena of the graph
+};
+int hip_dense_information(void *stream, const DenseGraphIn &in, int n, double *out, char *err, size_t errlen);
+int hip_dense_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &other, int n_marg, int n_keep,
+                  const int64_t *kept_vpo_base, const int64_t *kept_vpo_other, double *terms, double *seconds,
+                  char *err, size_t errlen);
 
 }  // namespace spg

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     // publish(): everything the host's graph update needs — status so far, n_new, the new-edge table —
     // followed by a system-scope release and the ready tag. finish() = publish (unless done) + KLD.
     bool published = false;
-    auto publish = [&, T]() {
+    auto publish = [&]() {
         T.sync();  // every lane's new-record stores precede the release below
         if (tid == 0) {
             orec[0] = (double)status; orec[1] = (double)info; orec[2] = kld; orec[3] = min_gap; orec[4] = (double)n_new;
@@ -193,13 +193,13 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         }
         published = true;
     };
-    auto finish = [&, T]() {
+    auto finish = [&]() {
         if (!published) { publish(); return; }
         if (tid == 0) { orec[2] = kld; orec[0] = (double)status; }
     };
     // diagnostic cycle stamps (flags bit 16, needs tinfo_off >= 0): written only to the debug region
     const bool stamping = ((a.flags >> 16) & 1) && bd.tinfo_off >= 0;
-    auto STAMP = [&, T](int idx) {
+    auto STAMP = [&](int idx) {
         if (stamping) {
             T.sync();
             if (tid == 0) arena[bd.tinfo_off + idx] = (double)__builtin_amdgcn_s_memtime();
@@ -1433,6 +1433,7 @@ void hip_backend_destroy(spg_backend *b) {
 
 void *hip_backend_stream(spg_backend *b) { return b->user ? (void *)((HipBackend *)b->user)->slots[0].stream : nullptr; }
 const char *hip_backend_error(spg_backend *b) { return b->user ? ((HipBackend *)b->user)->err : ""; }
+int hip_backend_device(spg_backend *b) { return b->user ? ((HipBackend *)b->user)->device : -1; }
 int hip_backend_launches(spg_backend *b) { return b->user ? ((HipBackend *)b->user)->n_launches : 0; }
 void hip_backend_profile(spg_backend *b, int enable) {
     HipBackend *hb = (HipBackend *)b->user;

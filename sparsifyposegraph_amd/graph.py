@@ -148,6 +148,24 @@ class GraphWrapperHIP:
                                                _p(meas, C.c_double), _p(info, C.c_double)), self.ctx.h, "computeSubstituteEdge")
         return f.value, t.value, meas, info
 
+    def information(self, fixed_id=-1):
+        """GraphWrapperG2O::information (src/graph_wrapper_g2o.cpp:351-358): dense Gauss-Newton
+        information at the stored estimates, all vertices but the fixed one (default: smallest id)."""
+        n = self.L.spg_graph_information(self.h, int(fixed_id), None, 0)
+        check(min(int(n), 0), self.ctx.h, "information")
+        out = np.zeros((int(n), int(n)))
+        rc = self.L.spg_graph_information(self.h, int(fixed_id), _p(out, C.c_double), out.size)
+        check(min(int(rc), 0), self.ctx.h, "information")
+        return out
+
+    def kullbackLeibler(self, other, fixed_id=-1):
+        """GraphWrapperG2O::kullbackLeibler(other) called on the baseline
+        (src/graph_wrapper_g2o.cpp:531-548). Returns the KLD; the terms are in `last_kld_terms`."""
+        t = abi.KldTerms()
+        check(self.L.spg_graph_kullback_leibler(self.h, other.h, int(fixed_id), C.byref(t)), self.ctx.h, "kullbackLeibler")
+        self.last_kld_terms = t.asdict()
+        return t.kld
+
     # round-stepping form (multi-GPU driver in parallel.py)
     def begin(self, which, opts, rank, nranks):
         which = np.ascontiguousarray(which, np.int32)

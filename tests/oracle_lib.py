@@ -43,6 +43,9 @@ def lib():
         L.spgref_graph_get_edges.argtypes = [C.c_void_p, i32p, i32p, i32p, i64p, f64p]
         L.spgref_graph_last_blankets.argtypes = [C.c_void_p, i32p, i32p, i32p, f64p, f64p, i32p]
         L.spgref_marginalize_batch_mt.argtypes = [C.POINTER(abi.Options), C.POINTER(abi.Batch), C.POINTER(abi.Result), C.c_int]
+        L.spgref_graph_information.restype = C.c_int64
+        L.spgref_graph_information.argtypes = [C.c_void_p, C.c_int32, f64p, C.c_int64]
+        L.spgref_graph_kullback_leibler.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, f64p]
         L.spgref_spd_logdet.restype = C.c_double
         L.spg_run_round.argtypes = [C.c_void_p, C.POINTER(abi.RoundDesc)]
         _LIB = L
@@ -90,6 +93,20 @@ class OracleGraph:
 
     def seconds(self):
         return self.L.spgref_graph_last_seconds(self.h)
+
+    def information(self, fixed_id):
+        """other->information() (src/graph_wrapper_g2o.cpp:351-358), fixed vertex dropped."""
+        n = int(self.L.spgref_graph_information(self.h, int(fixed_id), None, 0))
+        out = np.zeros((n, n))
+        self.L.spgref_graph_information(self.h, int(fixed_id), _p(out, C.c_double), out.size)
+        return out
+
+    def kullback_leibler(self, other, fixed_id):
+        """baseline.kullbackLeibler(other) (src/graph_wrapper_g2o.cpp:531-548) -> dict of terms"""
+        t = np.zeros(6)
+        rc = self.L.spgref_graph_kullback_leibler(self.h, other.h, int(fixed_id), _p(t, C.c_double))
+        assert rc == 0, rc
+        return dict(zip(("kld", "innerprod", "mahalanobis", "logdetx", "logdety", "n"), t))
 
     def vertices(self):
         n = self.L.spgref_graph_num_vertices(self.h)

@@ -121,3 +121,14 @@ def first_round_batch(g, which, opts, limit=None):
             "edge_vert_off": np.array(edge_vert_off, np.int32), "edge_vert": np.array(edge_vert, np.int32),
             "edge_data_off": np.array(edge_data_off, np.int64),
             "edge_data": np.concatenate(edge_data) if edge_data else np.zeros(0)}, roots
+
+
+def prefix_graph(g, which, n):
+    """Sub-graph over the first n vertices (by position in g["ids"]) and the removal ids inside it."""
+    ids = np.asarray(g["ids"])[:n]
+    keep = set(int(x) for x in ids)
+    m = np.array([int(a) in keep and int(b) in keep for a, b in g["edge_ij"]], bool)
+    sub = {"pose_dim": g["pose_dim"], "ids": ids, "poses": np.asarray(g["poses"])[:n],
+           "edge_ij": np.asarray(g["edge_ij"])[m], "edge_data": np.asarray(g["edge_data"])[m]}
+    w = np.array([int(v) for v in which if int(v) in keep and int(v) != int(ids[-1])], np.int32)
+    return sub, w
