@@ -30,8 +30,15 @@ using namespace spgdev;
 namespace {
 
 constexpr int TB = 64;    // tile edge
-constexpr int LDR = 66;   // LDS row stride of a staged tile: (row*66 + k) mod 32 is distinct over a half wave's 16 rows x 2 k
 using d4 = __attribute__((ext_vector_type(4))) double;
+
+__device__ __forceinline__ double readlane64(double v, int lane) {
+    union { double d; int i[2]; } u, r;
+    u.d = v;
+    r.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    r.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return r.d;
+}
 
 #define HIPCHK(x)                                                                                              \
     do {                                                                                                       \
@@ -44,61 +51,98 @@ using d4 = __attribute__((ext_vector_type(4))) double;
     } while (0)
 
 // ------------------------------------------------------------------------------------------ tiles
-// C(p,q) (op)= A(p,q) * B(p,q)^T over one 64x64x64 tile triple; (p,q) from the grid. Tiles are
-// addressed as base + p*stride_p + q*stride_q (elements), each with its own leading dimension.
+// C(p,q) (op)= A(p) * B(q)^T with K = 32 * kchunks: one workgroup (4 wavefronts) per 128 x 128 output tile, one
+// wavefront per 64 x 64 quadrant = 4 x 4 v_mfma_f64_16x16x4_f64 accumulators. Tiles are addressed in
+// units of 64 rows/cols — base + p64*stride_p + q64*stride_q (elements), each operand with its own
+// leading dimension — and a 128-tile at the edge of an odd tile count computes its valid 64-wide half.
+// A (128 x K) and B (128 x K) pass through LDS in K-chunks of 32 (row stride 34 doubles: the
+// fragment reads of a half wave — 16 rows x 2 k — fall on 32 distinct 8-byte bank pairs). 128 accumulator
+// registers + 70 KB of LDS leave room for two workgroups per CU, which overlap each other's loads.
 struct TileOp {
     double *C;
     const double *A, *B;
-    long long c_p, c_q, a_p, a_q, b_p, b_q;
+    long long c_p, c_q, a_p, b_q;   // element strides per 64-tile index (A depends on p only, B on q only)
     int ldc, lda, ldb;
-    int tri;       // 1: blockIdx.x enumerates the pairs q <= p of a triangle
-    int subtract;  // 1: C -= A B^T; 0: C = A B^T (C may alias A: the tile is staged before it is written)
+    int P64, Q64;  // extent in 64-tiles (rows of A / rows of B)
+    int tri;       // 1: blockIdx.x enumerates the 128-tile pairs q <= p of a triangle
+    int subtract;  // 1: C -= A B^T; 0: C = A B^T (C may alias A: A is consumed before C is written)
+    int kchunks;   // K = 32 * kchunks (2 for a 64-wide panel; 8 for the 256-wide outer block)
 };
 
-__global__ __launch_bounds__(256) void tile_abt_kernel(TileOp op) {
-    __shared__ double As[TB * LDR], Bs[TB * LDR];
+constexpr int KC = 32, LDK = 34;
+
+__global__ __launch_bounds__(256, 2) void tile_abt_kernel(TileOp op) {
+    __shared__ __attribute__((aligned(16))) double As[128 * LDK], Bs[128 * LDK];
     int p = blockIdx.x, q = blockIdx.y;
     if (op.tri) {
-        // blockIdx.x = p(p+1)/2 + q
-        int t = blockIdx.x;
+        int t = blockIdx.x;   // t = p(p+1)/2 + q
         p = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
         while ((p + 1) * (p + 2) / 2 <= t) p++;
         while (p * (p + 1) / 2 > t) p--;
         q = t - p * (p + 1) / 2;
     }
-    const double *A = op.A + p * op.a_p + q * op.a_q;
-    const double *B = op.B + p * op.b_p + q * op.b_q;
-    double *C = op.C + p * op.c_p + q * op.c_q;
+    const int rows = min(2, op.P64 - 2 * p) * TB, cols = min(2, op.Q64 - 2 * q) * TB;   // valid extent: 64 or 128
+    const double *A = op.A + 2 * p * op.a_p;
+    const double *B = op.B + 2 * q * op.b_q;
+    double *C = op.C + 2 * p * op.c_p + 2 * q * op.c_q;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // stage: a wave reads one 512-byte row segment per instruction (coalesced), LDS rows are contiguous
-    for (int i = 0; i < TB / 4; i++) {
-        int row = i * 4 + w;
-        As[row * LDR + lane] = A[(long long)row * op.lda + lane];
-        Bs[row * LDR + lane] = B[(long long)row * op.ldb + lane];
-    }
-    __syncthreads();
-    const int r0 = (w >> 1) * 32, c0 = (w & 1) * 32;   // this wave's 32x32 quadrant
+    // staging map: thread -> (row = tid / 2, 16 consecutive k at (tid & 1) * 16) of a 128 x 32 chunk
+    const int srow = tid >> 1, sk = (tid & 1) * 16;
+    const bool a_ok = srow < rows, b_ok = srow < cols;
+    const double *ga = A + (long long)srow * op.lda + sk, *gb = B + (long long)srow * op.ldb + sk;
+    auto load_chunk = [&](int chunk) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            double2 ra[4], rb[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ra[i] = a_ok ? *reinterpret_cast<const double2 *>(ga + chunk * KC + 8 * h + 2 * i) : double2{0, 0};
+                rb[i] = b_ok ? *reinterpret_cast<const double2 *>(gb + chunk * KC + 8 * h + 2 * i) : double2{0, 0};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                *reinterpret_cast<double2 *>(&As[srow * LDK + sk + 8 * h + 2 * i]) = ra[i];
+                *reinterpret_cast<double2 *>(&Bs[srow * LDK + sk + 8 * h + 2 * i]) = rb[i];
+            }
+        }
+    };
+    const int r0 = (w >> 1) * 64, c0 = (w & 1) * 64;   // this wave's quadrant
+    const bool live = r0 < rows && c0 < cols;
     const int li = lane & 15, lk = lane >> 4;
-    d4 acc[2][2];
+    d4 acc[4][4];
 #pragma unroll
-    for (int x = 0; x < 2; x++)
+    for (int x = 0; x < 4; x++)
 #pragma unroll
-        for (int y = 0; y < 2; y++) acc[x][y] = d4{0, 0, 0, 0};
-#pragma unroll 4
-    for (int k0 = 0; k0 < TB; k0 += 4) {
-        // A fragment: A[row = li][k = lk]; B fragment: B[k = lk][col = li] = Bt[col][k]
-        double a0 = As[(r0 + li) * LDR + k0 + lk], a1 = As[(r0 + 16 + li) * LDR + k0 + lk];
-        double b0 = Bs[(c0 + li) * LDR + k0 + lk], b1 = Bs[(c0 + 16 + li) * LDR + k0 + lk];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        for (int y = 0; y < 4; y++) acc[x][y] = d4{0, 0, 0, 0};
+    auto multiply = [&]() {
+        if (!live) return;
+#pragma unroll 2
+        for (int k0 = 0; k0 < KC; k0 += 4) {
+            double a[4], b[4];
+            // A fragment: A[row = li][k = lk]; B fragment: B[k = lk][col = li] = Bt[col][k]
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                a[x] = As[(r0 + 16 * x + li) * LDK + k0 + lk];
+                b[x] = Bs[(c0 + 16 * x + li) * LDK + k0 + lk];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+#pragma unroll
+                for (int y = 0; y < 4; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+    };
+    for (int ch = 0; ch < op.kchunks; ch++) {
+        if (ch) __syncthreads();
+        load_chunk(ch);
+        __syncthreads();
+        multiply();
     }
+    if (!live) return;
     // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int x = 0; x < 2; x++)
+    for (int x = 0; x < 4; x++)
 #pragma unroll
-        for (int y = 0; y < 2; y++)
+        for (int y = 0; y < 4; y++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 int row = r0 + 16 * x + lk + 4 * r, col = c0 + 16 * y + li;
@@ -108,36 +152,63 @@ __global__ __launch_bounds__(256) void tile_abt_kernel(TileOp op) {
 }
 
 // Factor the 64x64 diagonal block at Ajj (lower Cholesky, in place, strict upper zeroed) and write
-// its inverse (dense 64x64, row-major, strict upper zero) to Linv. *bad is set if a pivot is not positive.
-__global__ __launch_bounds__(256) void diag_potrf_kernel(double *Ajj, int ld, double *Linv, int *bad, int factor) {
-    __shared__ double L[TB * 65], Li[TB * 65], red[256], rdiag[TB];
-    __shared__ int flag;
+// its inverse (dense 64x64, row-major, strict upper zero) to Linv; factor = 0: the block already holds
+// a Cholesky factor, only invert it. *bad is set if a pivot is not positive. One wavefront per block,
+// register-resident: lane i owns row i of the block (64 fp64 registers); the factorisation broadcasts
+// pivot-row entries with v_readlane (as csrc/spg_dev_wave.hpp does for n <= 24), the inverse then runs
+// one independent forward substitution per lane (lane c = column c of L^-1) with the rows of L read
+// from LDS at wave-uniform addresses. No barrier and no exposed LDS round trip in either chain — the
+// LDS-cooperative version (chol_lower<256> + tri_inverse_lower) took 119 us per block, the serial
+// critical path of the blocked factorisation.
+__global__ __launch_bounds__(64) void diag_potrf_kernel(double *Ajj, int ld, double *Linv, int *bad, int factor) {
+    __shared__ double Ls[TB * 65];
     Ajj += (long long)blockIdx.x * TB * ((long long)ld + 1);
     Linv += (long long)blockIdx.x * TB * TB;
-    const int tid = threadIdx.x;
-    if (tid == 0) flag = 0;
-    for (int it = tid; it < TB * TB; it += 256) {
-        int r = it >> 6, c = it & 63;
-        L[r * 65 + c] = (c <= r) ? Ajj[(long long)r * ld + c] : 0.0;
-    }
-    __syncthreads();
-    Team<256> T{tid, red, &flag};
+    const int lane = threadIdx.x;
+    // coalesced load of the lower triangle into LDS (row stride 65: row-per-lane reads hit 64 banks)
+    for (int r = 0; r < TB; r++) Ls[r * 65 + lane] = (lane <= r) ? Ajj[(long long)r * ld + lane] : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (factor) {
-        chol_lower<256>(T, L, TB, 65, rdiag);
-        if (tid == 0 && flag) *bad = 1;
-        for (int it = tid; it < TB * TB; it += 256) {
-            int r = it >> 6, c = it & 63;
-            Ajj[(long long)r * ld + c] = L[r * 65 + c];
+        double a[TB];
+#pragma unroll
+        for (int c = 0; c < TB; c++) a[c] = Ls[lane * 65 + c];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < TB; j++) {
+            double d = readlane64(a[j], j);
+            if (!(d > 0.0) || !isfinite(d)) { ok = false; d = 1.0; }
+            double rs = fast_rsqrt(d);
+            a[j] = (lane == j) ? d * rs : a[j] * rs;     // L_jj = sqrt(d); column j scaled
+#pragma unroll
+            for (int c = j + 1; c < TB; c++) {
+                double lc = readlane64(a[j], c);          // L[c][j]
+                a[c] -= a[j] * lc;                        // rows above the diagonal carry zeros: harmless
+            }
         }
-    } else {
-        if (tid < TB) rdiag[tid] = 1.0 / L[tid * 65 + tid];
-        __syncthreads();
+        if (!ok && lane == 0) *bad = 1;
+#pragma unroll
+        for (int c = 0; c < TB; c++) Ls[lane * 65 + c] = (c <= lane) ? a[c] : 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < TB; r++) Ajj[(long long)r * ld + lane] = Ls[r * 65 + lane];
     }
-    tri_inverse_lower<256>(T, L, Li, TB, 65, rdiag);
-    for (int it = tid; it < TB * TB; it += 256) {
-        int r = it >> 6, c = it & 63;
-        Linv[it] = Li[r * 65 + c];
+    // x[i] = (L^-1)[i][lane]
+    double x[TB];
+#pragma unroll
+    for (int i = 0; i < TB; i++) {
+        double s = (lane == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= Ls[i * 65 + k] * x[k];   // wave-uniform LDS address: broadcast
+        x[i] = (lane <= i) ? s * fast_rcp(Ls[i * 65 + i]) : 0.0;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < TB; i++) Ls[i * 65 + lane] = x[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int r = 0; r < TB; r++) Linv[r * TB + lane] = Ls[r * 65 + lane];
 }
 
 // pad rows [n, N) of an N x N matrix get a unit diagonal
@@ -181,6 +252,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const double *M, int ld, int
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// rowsq[r] = (sum_{c >= r} Y[r][c] diff[c])^2: one wavefront per row of the upper-triangular Y = L_x^T
+__global__ __launch_bounds__(256) void upper_matvec_sq_kernel(const double *Y, int ldy, int n, const double *diff, double *rowsq) {
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    double v = 0;
+    for (int c = (r & ~63) + lane; c < n; c += 64)
+        if (c >= r) v += Y[(long long)r * ldy + c] * diff[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) rowsq[r] = v * v;
+}
+
 // one workgroup: out[0] = sum partial[0..np), out[1] = 2 sum_{i<n} log La[i][i], out[2] = 2 sum log Lb[i][i],
 // out[3] = || Y^T... the Mahalanobis term: sum_r (sum_c Y[r][c] diff[c])^2 with Y = L_x^T (upper)
 __global__ __launch_bounds__(256) void finish_kernel(const double *partial, int np, const double *La, int lda, const double *Lb, int ldb,
@@ -207,13 +290,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const double *partial, int 
     for (int i = threadIdx.x; i < n; i += 256) s += log(Lb[(long long)i * ldb + i]);
     double t2 = 2.0 * reduce(s);
     s = 0;
-    if (diff) {
-        for (int r = threadIdx.x; r < n; r += 256) {
-            double v = 0;
-            for (int c = r; c < n; c++) v += Y[(long long)r * ldy + c] * diff[c];
-            s += v * v;
-        }
-    }
+    if (diff)   // here: the per-row squares of upper_matvec_sq_kernel
+        for (int r = threadIdx.x; r < n; r += 256) s += diff[r];
     double t3 = reduce(s);
     if (threadIdx.x == 0) { out[0] = t0; out[1] = t1; out[2] = t2; out[3] = t3; }
 }
@@ -435,41 +513,66 @@ void launch_assemble(const GraphBufs &gb, double *M, int ld, hipStream_t s) {
     hipLaunchKernelGGL((dense_assemble_kernel<D>), dim3(gb.dev.nv), dim3(64), 0, s, gb.dev, M, ld);
 }
 
-void launch_tiles(const TileOp &op, int gx, int gy, hipStream_t s) {
-    if (gx <= 0 || gy <= 0) return;
-    hipLaunchKernelGGL(tile_abt_kernel, dim3(gx, gy), dim3(256), 0, s, op);
+void launch_tiles(const TileOp &op, hipStream_t s) {
+    if (op.P64 <= 0 || op.Q64 <= 0) return;
+    const int gp = (op.P64 + 1) / 2, gq = (op.Q64 + 1) / 2;
+    if (op.tri) hipLaunchKernelGGL(tile_abt_kernel, dim3(gp * (gp + 1) / 2), dim3(256), 0, s, op);
+    else hipLaunchKernelGGL(tile_abt_kernel, dim3(gp, gq), dim3(256), 0, s, op);
 }
 
 // Blocked right-looking lower Cholesky of the N x N matrix M (N a multiple of 64), in place.
+// Two levels: a 256-wide outer block is factorised as four 64-wide panels (diagonal block in one
+// wavefront, panel solve = product with L_jj^-T, update of the remaining columns of the outer block),
+// then the whole trailing matrix is updated ONCE with K = 256 — the trailing read-modify-write of C is
+// what bounds a K = 64 update (10 flop/B), and it shrinks with the outer width.
+constexpr int OUTER = 4;   // 64-tiles per outer block
 void potrf_lower(double *M, int N, double *linv /*64*64*/, int *bad, hipStream_t s) {
     const int nt = N / TB;
     const long long ld = N;
-    for (int j = 0; j < nt; j++) {
-        hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(256), 0, s, M + (long long)j * TB * (ld + 1), N, linv, bad, 1);
-        const int rem = nt - j - 1;
-        if (rem == 0) break;
-        double *panel = M + ((long long)(j + 1) * TB * ld + (long long)j * TB);
-        TileOp trsm{panel, panel, linv, TB * ld, 0, TB * ld, 0, 0, 0, N, N, TB, 0, 0};
-        launch_tiles(trsm, rem, 1, s);
-        double *trail = M + (long long)(j + 1) * TB * (ld + 1);
-        TileOp syrk{trail, panel, panel, TB * ld, TB, TB * ld, 0, 0, TB * ld, N, N, N, 1, 1};
-        launch_tiles(syrk, rem * (rem + 1) / 2, 1, s);
+    for (int J0 = 0; J0 < nt; J0 += OUTER) {
+        const int J1 = std::min(nt, J0 + OUTER);
+        for (int j = J0; j < J1; j++) {
+            hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(64), 0, s, M + (long long)j * TB * (ld + 1), N, linv, bad, 1);
+            const int rem = nt - j - 1;
+            if (rem == 0) break;
+            double *panel = M + ((long long)(j + 1) * TB * ld + (long long)j * TB);
+            // panel <- panel * L_jj^-T
+            TileOp trsm{panel, panel, linv, TB * ld, 0, TB * ld, 0, N, N, TB, rem, 1, 0, 0, 2};
+            launch_tiles(trsm, s);
+            // remaining columns of the outer block: M[j+1.., j+1..J1) -= panel * panel[0..J1-j-1]^T
+            // (the few tiles above the diagonal that this rectangle covers are never read)
+            const int inner = J1 - j - 1;
+            if (inner > 0) {
+                double *sub = M + (long long)(j + 1) * TB * (ld + 1);
+                TileOp upd{sub, panel, panel, TB * ld, TB, TB * ld, TB * ld, N, N, N, rem, inner, 0, 1, 2};
+                launch_tiles(upd, s);
+            }
+        }
+        const int rem = nt - J1;
+        if (rem <= 0) break;
+        // trailing(lower) -= P * P^T with P = M[J1.., J0*64 .. J1*64)
+        double *P = M + ((long long)J1 * TB * ld + (long long)J0 * TB);
+        double *trail = M + (long long)J1 * TB * (ld + 1);
+        TileOp syrk{trail, P, P, TB * ld, TB, TB * ld, TB * ld, N, N, N, rem, rem, 1, 1, 2 * (J1 - J0)};
+        launch_tiles(syrk, s);
     }
 }
 
 // Y <- Y * Ls^-T for upper-triangular Y (Ng x Ng, ldy) and lower-triangular Ls (ld), tile-aligned.
 void rsolve_lower_transposed(double *Y, int ldy, const double *Ls, int ld, int Ng, double *linv_all, int *bad, hipStream_t s) {
     const int nt = Ng / TB;
-    hipLaunchKernelGGL(diag_potrf_kernel, dim3(nt), dim3(256), 0, s, const_cast<double *>(Ls), ld, linv_all, bad, 0);
+    hipLaunchKernelGGL(diag_potrf_kernel, dim3(nt), dim3(64), 0, s, const_cast<double *>(Ls), ld, linv_all, bad, 0);
     for (int c = 0; c < nt; c++) {
         double *col = Y + (long long)c * TB;
-        TileOp scale{col, col, linv_all + (long long)c * TB * TB, (long long)TB * ldy, 0, (long long)TB * ldy, 0, 0, 0, ldy, ldy, TB, 0, 0};
-        launch_tiles(scale, c + 1, 1, s);
+        // rows 0..c of block column c: Y[:, c] <- Y[:, c] * L_cc^-T
+        TileOp scale{col, col, linv_all + (long long)c * TB * TB, (long long)TB * ldy, 0, (long long)TB * ldy, 0, ldy, ldy, TB, c + 1, 1, 0, 0, 2};
+        launch_tiles(scale, s);
         const int rem = nt - c - 1;
         if (rem == 0) break;
+        // Y[0..c, c'] -= Y[0..c, c] * Ls[c', c]^T for the block columns c' > c
         const double *lpanel = Ls + ((long long)(c + 1) * TB * ld + (long long)c * TB);
-        TileOp upd{Y + (long long)(c + 1) * TB, col, lpanel, (long long)TB * ldy, TB, (long long)TB * ldy, 0, 0, (long long)TB * ld, ldy, ldy, ld, 0, 1};
-        launch_tiles(upd, c + 1, rem, s);
+        TileOp upd{Y + (long long)(c + 1) * TB, col, lpanel, (long long)TB * ldy, TB, (long long)TB * ldy, (long long)TB * ld, ldy, ldy, ld, c + 1, rem, 0, 1, 2};
+        launch_tiles(upd, s);
     }
 }
 
@@ -514,7 +617,7 @@ int hip_dense_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &ot
     const int D = base.D, nk = n_keep / D;
     const int Nm = round_up(n_marg), Ng = round_up(std::max(n_keep, 1)), N = Nm + Ng, ntg = Ng / TB;
     GraphBufs gb, go;
-    DevBuf Mb, X, Y, linv, linv_all, bad, partial, outb, diff, vb, vo;
+    DevBuf Mb, X, Y, linv, linv_all, bad, partial, outb, diff, rowsq, vb, vo;
     int h_bad[2] = {0, 0};
     double h_out[4] = {0, 0, 0, 0};
     const int np = 1024;
@@ -531,6 +634,7 @@ int hip_dense_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &ot
     HIPCHK(hipMalloc(&partial.p, np * 8));
     HIPCHK(hipMalloc(&outb.p, 4 * 8));
     HIPCHK(hipMalloc(&diff.p, (size_t)Ng * 8));
+    HIPCHK(hipMalloc(&rowsq.p, (size_t)Ng * 8));
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     if ((rc = upload(vb, kept_vpo_base, (size_t)nk, s)) || (rc = upload(vo, kept_vpo_other, (size_t)nk, s)) ||
@@ -558,8 +662,9 @@ int hip_dense_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &ot
         const double *Ls = (const double *)Mb.p + ((long long)Nm * N + Nm);
         hipLaunchKernelGGL(transpose_lower_kernel, dim3(Ng / 32, Ng / 32), dim3(256), 0, s, (const double *)X.p, Ng, (double *)Y.p, Ng, Ng);
         // Mahalanobis and log-dets need Y = L_x^T before the solve overwrites it
+        hipLaunchKernelGGL(upper_matvec_sq_kernel, dim3(Ng / 4), dim3(256), 0, s, (const double *)Y.p, Ng, Ng, (const double *)diff.p, (double *)rowsq.p);
         hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, s, (const double *)partial.p, 0, (const double *)X.p, Ng, Ls, N, Ng,
-                           (const double *)Y.p, Ng, (const double *)diff.p, (double *)outb.p);
+                           (const double *)Y.p, Ng, (const double *)rowsq.p, (double *)outb.p);
         HIPCHK(hipMemcpyAsync(h_out, outb.p, 4 * 8, hipMemcpyDeviceToHost, s));
         rsolve_lower_transposed((double *)Y.p, Ng, Ls, N, Ng, (double *)linv_all.p, (int *)bad.p, s);
         hipLaunchKernelGGL(sumsq_kernel, dim3(np), dim3(256), 0, s, (const double *)Y.p, Ng, Ng, (double *)partial.p);
