@@ -84,6 +84,7 @@ struct RoundBlanket {
     int32_t vbeg = 0, nv = 0;     // vertex indices, removed first (asc id) then kept (asc id)
     int32_t ebeg = 0, ne = 0;     // edge ids, ascending
     int32_t rank = 0;
+    int32_t owner = -1;           // id in spg_graph::owners while the blanket is scheduled / in flight
     spg_blanket_desc desc{};
 };
 
@@ -139,8 +140,15 @@ struct spg_graph {
     static constexpr int NB = 4;                      // batches that can be in flight (= backend launch slots)
     Batch bt[NB];
     Batch *B = &bt[0];                                // batch the round functions currently work on
-    std::vector<int32_t> Dpool;                       // owner sets, flat
-    std::vector<std::pair<int32_t, int32_t>> Dspan;   // (offset, length) per owner
+    // Owner registry of the scheduler: every scheduled-but-uncommitted blanket and every vertex deferred
+    // in the current scheduling pass "owns" a vertex set; vowners[x] lists the owners whose set holds x.
+    // Blanket owners persist from the pass that selected them until their batch commits; entries die
+    // lazily: freeing an owner bumps its generation and stale references are dropped when next seen.
+    struct Owner { int32_t batch, off, len; uint32_t gen; };   // batch >= 0: bt[batch].rb_verts[off, off+len); -1: Dpool
+    struct OwnRef { int32_t oid; uint32_t gen; };
+    std::vector<Owner> owners;
+    std::vector<int32_t> owner_free, transient;       // free ids; deferred-vertex owners of the last pass
+    std::vector<int32_t> Dpool;                       // sets of the deferred-vertex owners, flat
     int shard_threshold = 2048;
     int round_no = 0, launch_seq = 0;
     bool pipelined = false;                           // two batches in flight (single rank, backend with slots)
@@ -150,8 +158,7 @@ struct spg_graph {
     // scheduler scratch
     std::vector<int32_t> vstamp, estamp;
     int32_t stamp = 0;
-    std::vector<std::vector<int32_t>> vowners;
-    std::vector<int32_t> touched;
+    std::vector<std::vector<OwnRef>> vowners;
     std::vector<int32_t> ocnt;
     std::vector<int32_t> lidx;
 };
@@ -643,7 +650,35 @@ static void new_edge_budget(const spg_options &o, int d, int k, int32_t &n_new_m
     }
 }
 
+static int32_t owner_acquire(spg_graph *g, int32_t batch, int32_t off, int32_t len) {
+    int32_t oid;
+    if (!g->owner_free.empty()) { oid = g->owner_free.back(); g->owner_free.pop_back(); }
+    else { oid = (int32_t)g->owners.size(); g->owners.push_back({0, 0, 0, 0}); g->ocnt.push_back(0); }
+    spg_graph::Owner &o = g->owners[oid];
+    o.batch = batch; o.off = off; o.len = len;
+    return oid;
+}
+static void owner_release(spg_graph *g, int32_t oid) {
+    g->owners[oid].gen++;   // every reference to it in vowners[] is stale from now on
+    g->owner_free.push_back(oid);
+}
+static const int32_t *owner_set(const spg_graph *g, const spg_graph::Owner &o) {
+    return (o.batch >= 0 ? g->bt[o.batch].rb_verts.data() : g->Dpool.data()) + o.off;
+}
+static void release_batch_owners(spg_graph *g, Batch &bt) {
+    for (RoundBlanket &r : bt.rb) if (r.owner >= 0) { owner_release(g, r.owner); r.owner = -1; }
+}
+
 // Select this round's mutually commuting blankets, in list order. Fills bt.rb; rewrites g->pending.
+#ifdef SPG_SCHED_PROF
+#include <x86intrin.h>
+static unsigned long long prof_t[8], prof_n[8];
+#define PT0 unsigned long long pt_ = __rdtsc()
+#define PT(i) do { unsigned long long n_ = __rdtsc(); prof_t[i] += n_ - pt_; prof_n[i]++; pt_ = n_; } while (0)
+#else
+#define PT0 do {} while (0)
+#define PT(i) do {} while (0)
+#endif
 static void schedule_round(spg_graph *g) {
     Batch &bt = *g->B;
     const spg_options &o = g->opts;
@@ -653,57 +688,59 @@ static void schedule_round(spg_graph *g) {
     bt.rb_verts.clear();
     bt.rb_edges.clear();
     if (g->vowners.size() < g->vid.size()) g->vowners.resize(g->vid.size());
-    for (int32_t v : g->touched) g->vowners[v].clear();
-    g->touched.clear();
+    // the deferred-vertex owners of the previous pass are void; blanket owners of batches still in
+    // flight stay registered (their removals are not in the host graph yet, so nothing that fails to
+    // commute with them may be selected now)
+    for (int32_t oid : g->transient) owner_release(g, oid);
+    g->transient.clear();
     g->Dpool.clear();
-    g->Dspan.clear();
-    g->ocnt.clear();
+    const int32_t my_batch = (int32_t)(&bt - g->bt);
     std::vector<int32_t> newpending, B, centres, Dv, tmp, work, seen_owner;
     std::vector<int32_t> hit;
     bool stop = false;
     size_t n_deferred = 0, consec = 0;
-    auto reg = [&](const std::vector<int32_t> &D) {
-        int32_t oid = (int32_t)g->Dspan.size();
-        g->Dspan.push_back({(int32_t)g->Dpool.size(), (int32_t)D.size()});
-        g->Dpool.insert(g->Dpool.end(), D.begin(), D.end());
-        g->ocnt.push_back(0);
-        for (int32_t x : D) {
-            if (g->vowners[x].empty()) g->touched.push_back(x);
-            g->vowners[x].push_back(oid);
+    auto reg = [&](int32_t batch, int32_t off, int32_t len) -> int32_t {
+        int32_t oid = owner_acquire(g, batch, off, len);
+        const uint32_t gen = g->owners[oid].gen;
+        const int32_t *set = owner_set(g, g->owners[oid]);
+        for (int32_t i = 0; i < len; i++) g->vowners[set[i]].push_back({oid, gen});
+        return oid;
+    };
+    // live owners of x, dropping stale references on the way
+    auto for_owners = [&](int32_t x, auto &&fn) {
+        auto &vo = g->vowners[x];
+        for (size_t i = 0; i < vo.size();) {
+            const spg_graph::OwnRef r = vo[i];
+            if (g->owners[r.oid].gen != r.gen) { vo[i] = vo.back(); vo.pop_back(); continue; }
+            fn(r.oid);
+            i++;
         }
     };
-    // blankets of the batch that is still in flight: their removals are not in the host graph yet, so
-    // nothing that fails to commute with them may be selected now
     bool inflight = false;
-    for (int bi = 0; bi < spg_graph::NB; bi++) {
-        Batch &other = g->bt[bi];
-        if (&other == &bt || !other.round_open) continue;
-        inflight = true;
-        for (const RoundBlanket &ob : other.rb) {
-            B.assign(other.rb_verts.begin() + ob.vbeg, other.rb_verts.begin() + ob.vbeg + ob.nv);
-            reg(B);
-        }
-    }
+    for (int bi = 0; bi < spg_graph::NB; bi++) inflight |= (&g->bt[bi] != &bt && g->bt[bi].round_open);
     // The scan touches only a prefix of the pending list: entries that have to wait are written back
     // right in front of the untouched tail, so a call costs O(scanned), not O(pending).
     size_t pos = g->pend_head;
     for (; pos < g->pending.size() && !stop; pos++) {
         int32_t v = g->pending[pos];
         if (!g->valive[v]) continue;  // absorbed by an earlier cluster (`deleted`, src/vertex_remover.cpp:91)
+        PT0;
         if (dense) extended_blanket(g, v, B, centres);
         else { closed_neighbourhood(g, v, B); centres.assign(1, v); }
+        PT(0);
         bool inD = false, conflict = false;
         hit.clear();
         for (int32_t x : B) {
             bool is_c = false;
             for (int32_t c : centres) is_c |= (c == x);
-            for (int32_t oid : g->vowners[x]) {
+            for_owners(x, [&](int32_t oid) {
                 if (is_c) inD = true;
                 if (g->ocnt[oid]++ == 0) hit.push_back(oid);
                 if (g->ocnt[oid] >= 2) conflict = true;
-            }
+            });
         }
         for (int32_t oid : hit) g->ocnt[oid] = 0;
+        PT(1);
         if (!inD && !conflict) {
             RoundBlanket rbk;
             rbk.root = v;
@@ -725,9 +762,10 @@ static void schedule_round(spg_graph *g) {
             rbk.ebeg = (int32_t)bt.rb_edges.size();
             rbk.ne = (int32_t)work.size();
             bt.rb_edges.insert(bt.rb_edges.end(), work.begin(), work.end());
-            reg(B);
+            rbk.owner = reg(my_batch, rbk.vbeg, rbk.nv);
             bt.rb.push_back(std::move(rbk));
             consec = 0;
+            PT(2);
         } else {
             newpending.push_back(v);
             n_deferred++;
@@ -742,19 +780,20 @@ static void schedule_round(spg_graph *g) {
             seen_owner.clear();
             while (wi < work.size() && Dv.size() <= DCAP) {
                 int32_t c = work[wi++];
-                for (int32_t oid : g->vowners[c]) {
+                for_owners(c, [&](int32_t oid) {
                     bool seen = false;
                     for (int32_t so : seen_owner) seen |= (so == oid);
-                    if (seen) continue;
+                    if (seen) return;
                     seen_owner.push_back(oid);
-                    for (int32_t yi = g->Dspan[oid].first; yi < g->Dspan[oid].first + g->Dspan[oid].second; yi++) {
-                        int32_t y = g->Dpool[yi];
+                    const spg_graph::Owner ow = g->owners[oid];
+                    for (int32_t yi = 0; yi < ow.len; yi++) {
+                        int32_t y = owner_set(g, ow)[yi];   // (re-resolved: work/addv never touch the pools)
                         bool fresh = g->vstamp[y] != st;
                         addv(y);
                         // Dense: a newly reachable removable vertex is itself absorbed and brings its neighbourhood
                         if (dense && fresh && g->in_set[y] && g->valive[y]) work.push_back(y);
                     }
-                }
+                });
                 if (dense && c != v) {
                     // neighbourhood of an absorbed vertex (stamps are in use: gather without closed_neighbourhood)
                     for (int32_t eid : g->adj[c]) {
@@ -769,13 +808,18 @@ static void schedule_round(spg_graph *g) {
                 }
             }
             if (Dv.size() > DCAP) { stop = true; continue; }  // (v is already in newpending; the loop ends here)
-            reg(Dv);
+            {
+                int32_t off = (int32_t)g->Dpool.size();
+                g->Dpool.insert(g->Dpool.end(), Dv.begin(), Dv.end());
+                g->transient.push_back(reg(-1, off, (int32_t)Dv.size()));
+            }
             // stop scanning once a long run of list entries had to wait: whatever follows is
             // (almost always) waiting on them too, and not scanning only defers more
             // (with another batch in flight the blocked stretch is usually exactly the part of the list
             //  that waits for it: give up sooner, the next call comes right after that batch commits)
             size_t patience = inflight ? 12 + bt.rb.size() / 16 : 48 + bt.rb.size() / 8;
             if (++consec > patience || n_deferred > 256 + 2 * bt.rb.size()) stop = true;
+            PT(3);
         }
     }
     {
@@ -1103,6 +1147,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
         }
     }
     bt.round_open = false;
+    release_batch_owners(g, bt);
     g->stats.n_rounds = g->round_no;
     g->stats.host_seconds += now_s() - t1;
     g->stats.commit_seconds += now_s() - t1;
@@ -1113,23 +1158,33 @@ extern "C" int spg_graph_marginalize_end(spg_graph *g, spg_marg_stats *stats) {
     if (!g || !g->active) return SPG_ESTATE;
     g->active = false;
     for (int i = 0; i < spg_graph::NB; i++) (void)harvest_kld(g, g->bt[i]);
-    for (int i = 0; i < spg_graph::NB; i++) g->bt[i].round_open = false;
+    for (int i = 0; i < spg_graph::NB; i++) { g->bt[i].round_open = false; release_batch_owners(g, g->bt[i]); g->bt[i].rb.clear(); }
+    for (int32_t oid : g->transient) owner_release(g, oid);
+    g->transient.clear();
     g->B = &g->bt[0];
     if (g->ctx->is_hip) g->stats.n_launches = spg::hip_backend_launches(&g->ctx->be);
+#ifdef SPG_SCHED_PROF
+    if (getenv("SPG_SCHED_PROF")) {
+        const char *nm[4] = {"neighbourhood", "owner scan", "select", "defer"};
+        for (int i = 0; i < 4; i++) { fprintf(stderr, "sched %-14s %10llu calls %8.3f Mcycles\n", nm[i], prof_n[i], prof_t[i] * 1e-6); prof_t[i] = prof_n[i] = 0; }
+    }
+#endif
     if (stats) *stats = g->stats;
     return g->stats.n_bad_status ? SPG_EBLANKET : 0;
 }
 
 // Move blankets [from, to) of a freshly scheduled batch into another (idle) batch: all of them are
 // mutually independent, so the parts can be launched back to back on different slots.
-static void move_blankets(Batch &a, size_t from, size_t to, Batch &b) {
+static void move_blankets(spg_graph *g, Batch &a, size_t from, size_t to, Batch &b) {
     b.rb.clear(); b.rb_verts.clear(); b.rb_edges.clear();
+    const int32_t bidx = (int32_t)(&b - g->bt);
     for (size_t i = from; i < to; i++) {
         RoundBlanket r = a.rb[i];
         int32_t vb = (int32_t)b.rb_verts.size(), eb = (int32_t)b.rb_edges.size();
         b.rb_verts.insert(b.rb_verts.end(), a.rb_verts.begin() + r.vbeg, a.rb_verts.begin() + r.vbeg + r.nv);
         b.rb_edges.insert(b.rb_edges.end(), a.rb_edges.begin() + r.ebeg, a.rb_edges.begin() + r.ebeg + r.ne);
         r.vbeg = vb; r.ebeg = eb;
+        if (r.owner >= 0) { g->owners[r.owner].batch = bidx; g->owners[r.owner].off = vb; }
         b.rb.push_back(r);
     }
 }
@@ -1167,6 +1222,9 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
         // device work of the others. With nothing schedulable, wait for the oldest batch and apply it.
         constexpr int NB = spg_graph::NB;
         rc = 0;
+        const char *e1 = getenv("SPG_SPLIT_MIN"), *e2 = getenv("SPG_MAX_INFLIGHT");
+        const size_t split_min = e1 ? (size_t)atoi(e1) : 24;
+        const int max_inflight = e2 ? std::max(1, std::min(NB, atoi(e2))) : NB;
         auto commit_all = [&]() -> int {
             for (;;) {
                 Batch *o = nullptr;
@@ -1193,6 +1251,8 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
             bool launched = false;
             int f = -1, nfree = 0;
             for (int i = 0; i < NB; i++) if (!g->bt[i].round_open) { if (f < 0) f = i; nfree++; }
+            nfree -= NB - max_inflight;
+            if (nfree <= 0) f = -1;
             if (f >= 0 && g->pend_head < g->pending.size()) {
                 Batch &bt = g->bt[f];
                 g->B = &bt;
@@ -1212,13 +1272,13 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
                     continue;
                 } else {
                     size_t S = bt.rb.size();
-                    int parts = (int)std::min<size_t>((size_t)nfree, std::max<size_t>(1, S / 24));
+                    int parts = (int)std::min<size_t>((size_t)nfree, std::max<size_t>(1, S / split_min));
                     // hand parts 1..parts-1 to other idle batches, keep part 0 here
                     std::vector<Batch *> tgt;
                     for (int i = 0; i < NB && (int)tgt.size() < parts - 1; i++) if (i != f && !g->bt[i].round_open) tgt.push_back(&g->bt[i]);
                     parts = (int)tgt.size() + 1;
                     size_t per = (S + parts - 1) / parts;
-                    for (int pi = 1; pi < parts; pi++) move_blankets(bt, std::min(S, per * pi), std::min(S, per * (pi + 1)), *tgt[pi - 1]);
+                    for (int pi = 1; pi < parts; pi++) move_blankets(g, bt, std::min(S, per * pi), std::min(S, per * (pi + 1)), *tgt[pi - 1]);
                     bt.rb.resize(std::min(S, per));
                     if ((rc = launch_batch(bt, t0)) != 0) break;
                     for (int pi = 1; pi < parts && rc == 0; pi++) if (!tgt[pi - 1]->rb.empty()) rc = launch_batch(*tgt[pi - 1], now_s());

@@ -1161,7 +1161,7 @@ struct HipBackend {
         if (need <= S.c_stage) return 0;
         size_t nc = std::max(need, S.c_stage * 2);
         if (S.h_stage) { HIPCHK(hipStreamSynchronize(S.stream)); HIPCHK(hipHostFree(S.h_stage)); S.h_stage = nullptr; }
-        HIPCHK(hipHostMalloc(&S.h_stage, nc, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&S.h_stage, nc, hipHostMallocMapped));
         S.c_stage = nc;
         return 0;
     }
@@ -1262,8 +1262,18 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         size_t p = 0;
         for (int i = 0; i < NB; i++) for (int32_t b : bins[i].list) lst[p++] = b;
     }
-    // one host->device copy for all descriptors of the round
-    HIPCHK(hipMemcpyAsync(S.d_desc, st, tot, hipMemcpyHostToDevice, S.stream));
+    // Small launches read their descriptors straight from the pinned staging buffer (it is mapped into
+    // the device's address space): a copy engine hop in front of a latency-bound kernel costs more
+    // than a few scalar loads over PCIe. Large launches take one host->device copy.
+    static const int mapped_limit = [] { const char *e = getenv("SPG_MAPPED_DESC"); return e ? atoi(e) : 512; }();
+    char *desc_base = (char *)S.d_desc;
+    if ((long long)rd->count <= (long long)mapped_limit) {
+        void *dv = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&dv, S.h_stage, 0));
+        desc_base = (char *)dv;
+    } else {
+        HIPCHK(hipMemcpyAsync(S.d_desc, st, tot, hipMemcpyHostToDevice, S.stream));
+    }
     double *mail_dev = nullptr;
     if (rd->mail_len > 0) {
         size_t need = (size_t)rd->mail_len * 8;
@@ -1280,10 +1290,10 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     // ---- launch each non-empty bin
     KArgs ka;
     ka.arena = (double *)arena;
-    ka.blk = (const spg_blanket_desc *)((char *)S.d_desc + o_blk);
-    ka.vpo = (const int64_t *)((char *)S.d_desc + o_vpo);
-    ka.er = (const spg_edge_ref *)((char *)S.d_desc + o_er);
-    ka.ev = (const int32_t *)((char *)S.d_desc + o_ev);
+    ka.blk = (const spg_blanket_desc *)(desc_base + o_blk);
+    ka.vpo = (const int64_t *)(desc_base + o_vpo);
+    ka.er = (const spg_edge_ref *)(desc_base + o_er);
+    ka.ev = (const int32_t *)(desc_base + o_ev);
     ka.mail = mail_dev;
     ka.mail_base = rd->mail_base;
     ka.gws = nullptr; ka.gws_stride = 0;
@@ -1292,7 +1302,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     for (int i = 0; i < NB; i++) {
         int nb = (int)bins[i].list.size();
         if (nb == 0) continue;
-        ka.list = (const int32_t *)((char *)S.d_desc + o_list) + list_off;
+        ka.list = (const int32_t *)(desc_base + o_list) + list_off;
         list_off += nb;
         int rc;
         if (i < NB - 1) {

@@ -7,7 +7,7 @@
 The inputs are data files of the reference (datasets/*.g2o); the expected
 outputs come from oracle/libspg_ref.so, NOT from the reference (which cannot be built here), so
 they pin the oracle against regressions and carry the parity bar to the GPU box, where
-/root/reference does not exist.  Usage: python tests/golden/make_golden.py
+/root/reference does not exist.  Usage: python tests/golden/make_golden.py [case ...]
 """
 import os
 import sys
@@ -30,6 +30,8 @@ CASES = [
     ("intel_glc_tree_10pct", "intel.g2o", 942, abi.ALG_GLC, abi.TOPO_TREE, ("mod10", 5)),
     ("intel_nfr_tree_sp3", "intel.g2o", 942, abi.ALG_NFR, abi.TOPO_TREE, ("sparsity", 3)),
     ("sphere_glc_tree", "sphere.g2o", 399, abi.ALG_GLC, abi.TOPO_TREE, ("sparsity", 2)),
+    # BASELINE.json config 2 at full size: all 3500 vertices, Dense clustering (blankets up to k+m = 33)
+    ("manhattan_full_glc_dense", "manhattan.g2o", 3499, abi.ALG_GLC, abi.TOPO_DENSE, ("sparsity", 2)),
 ]
 
 
@@ -48,7 +50,10 @@ def removal_list(rule, last):
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    only = set(sys.argv[1:])   # optional: regenerate just the named cases
     for name, fname, maxid, alg, topo, rule in CASES:
+        if only and name not in only:
+            continue
         g = prefix(g2o_io.load_g2o(os.path.join(DATASETS, fname)), maxid)
         which = removal_list(rule, int(g["ids"][-1]))
         opts = abi.make_options(g["pose_dim"], alg, topo)

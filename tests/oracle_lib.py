@@ -149,11 +149,18 @@ def canonical_edges(e, d):
 # Injected compute backend: host memory as "arena", the oracle's spg_run_round as the arithmetic.
 # Lets the CPU suite drive the product's host scheduler / round protocol without a GPU.
 class OracleBackend:
-    def __init__(self):
+    """spg_backend whose arithmetic is the oracle's spg_run_round. With slots=True it also offers what
+    the HIP backend offers the pipelined driver: per-slot host mailboxes (the out records of a launch
+    are copied there, ready words included) and per-slot synchronisation — so the CPU suite drives the
+    product's multi-batch-in-flight path (scheduling against uncommitted batches, batch splitting,
+    mailbox polling, late KLD harvest) without a GPU."""
+
+    NSLOT = 4
+
+    def __init__(self, slots=False):
         self.L = lib()
         self.bufs = {}
-        libc = C.CDLL(None)
-        self._memmove = C.memmove
+        self.mail = [None] * self.NSLOT
 
         def _alloc(user, doubles):
             buf = (C.c_double * max(int(doubles), 1))()
@@ -173,18 +180,39 @@ class OracleBackend:
             return 0
 
         def _run_round(user, arena, rd):
-            return self.L.spg_run_round(arena, rd)
+            rc = self.L.spg_run_round(arena, rd)
+            r = rd.contents
+            if rc == 0 and slots and r.mail_len > 0:
+                sl = r.slot % self.NSLOT
+                if self.mail[sl] is None or len(self.mail[sl]) < r.mail_len:
+                    self.mail[sl] = (C.c_double * int(max(r.mail_len, 2 * len(self.mail[sl] or []))))()
+                C.memmove(self.mail[sl], arena + r.mail_base * 8, int(r.mail_len) * 8)
+            return rc
 
         def _sync(user):
             return 0
 
+        def _mailbox(user):
+            return C.addressof(self.mail[0]) if self.mail[0] is not None else None
+
+        def _sync_slot(user, slot):
+            return 0
+
+        def _mailbox_slot(user, slot):
+            m = self.mail[slot % self.NSLOT]
+            return C.addressof(m) if m is not None else None
+
         self.cb = (abi._ALLOC(_alloc), abi._RELEASE(_release), abi._UPLOAD(_upload), abi._DOWNLOAD(_download),
                    abi._RUN_ROUND(_run_round), abi._SYNC(_sync))
-        self.struct = abi.Backend(None, *self.cb, abi._MAILBOX(), abi._SYNC_SLOT(), abi._MAILBOX_SLOT())
+        if slots:
+            self.cb += (abi._MAILBOX(_mailbox), abi._SYNC_SLOT(_sync_slot), abi._MAILBOX_SLOT(_mailbox_slot))
+            self.struct = abi.Backend(None, *self.cb)
+        else:
+            self.struct = abi.Backend(None, *self.cb, abi._MAILBOX(), abi._SYNC_SLOT(), abi._MAILBOX_SLOT())
 
 
-def injected_context():
+def injected_context(slots=False):
     """Context of the PRODUCT library whose compute backend is the oracle (CPU tests only)."""
     from sparsifyposegraph_amd.lib import Context
-    be = OracleBackend()
+    be = OracleBackend(slots)
     return Context.injected(be.struct, keep=be)

@@ -14,6 +14,50 @@ def ictx():
     return oracle_lib.injected_context()
 
 
+@pytest.fixture(scope="module")
+def pctx():
+    """injected backend with launch slots and mailboxes: the library takes its pipelined driver"""
+    return oracle_lib.injected_context(slots=True)
+
+
+@pytest.mark.parametrize("case", util.golden_cases())
+def test_pipelined_driver_equals_sequential(case, pctx):
+    """Several batches in flight (scheduling against uncommitted batches, batch splitting over launch
+    slots, commit by polling the mailbox ready words, late KLD harvest) == the sequential loop."""
+    g, which, opts, gold_edges, gold_bl, gold_vids = util.load_golden(case)
+    hg = GraphWrapperHIP.from_dict(g, ctx=pctx, useGLC=bool(opts.algorithm))
+    st = hg.marginalizeNoOptimize(which, opts)
+    assert st["n_bad_status"] == 0
+    ids, _ = hg.vertices()
+    assert np.array_equal(ids, gold_vids)
+    util.compare_edge_sets(g["pose_dim"], gold_edges, hg.edges(), rtol=1e-11)
+    bl = hg.blankets()
+    order, gorder = np.argsort(bl["root"], kind="stable"), np.argsort(gold_bl["root"], kind="stable")
+    assert np.array_equal(bl["root"][order], gold_bl["root"][gorder])
+    assert np.array_equal(bl["status"][order], gold_bl["status"][gorder])
+    k1, k2 = bl["kld"][order], gold_bl["kld"][gorder]
+    fin = np.isfinite(k2)
+    assert np.array_equal(fin, np.isfinite(k1))
+    if fin.any():
+        assert np.max(np.abs(k1[fin] - k2[fin]) / np.maximum(np.abs(k2[fin]), 1.0)) <= 1e-11
+        assert abs(st["kld_sum"] - np.sum(k2[fin])) <= 1e-9 * max(1.0, abs(np.sum(k2[fin])))
+
+
+def test_pipelined_driver_other_orders(pctx):
+    g = g2o_io.synth_sphere(n_poses=3000, ring=60)
+    rng = np.random.default_rng(11)
+    for which in (np.array([i for i in range(4, 3000) if i % 2]), rng.permutation(np.arange(4, 3000))[:1400],
+                  np.array([i for i in range(4, 3000) if i % 3])):
+        which = which.astype(np.int32)
+        opts = abi.make_options(6)
+        og = oracle_lib.OracleGraph.from_dict(g)
+        assert og.marginalize(which, opts) == 0
+        hg = GraphWrapperHIP.from_dict(g, ctx=pctx)
+        st = hg.marginalizeNoOptimize(which, opts)
+        assert st["n_removed"] == len(which) and st["n_bad_status"] == 0
+        util.compare_edge_sets(6, og.edges(), hg.edges(), rtol=1e-11)
+
+
 @pytest.mark.parametrize("case", util.golden_cases())
 def test_rounds_equal_sequential(case, ictx):
     g, which, opts, gold_edges, gold_bl, gold_vids = util.load_golden(case)
