@@ -109,6 +109,7 @@ struct Batch {
     int seq = 0;                       // launch order
     int round_no = 0;
     int tag = 0;                       // ready tag of the launch (out record word [5])
+    double t_launch = 0;               // SPG_TRACE=1 diagnostics
     // blankets committed from the mailbox before their KLD tail finished: (log index, mailbox offset)
     std::vector<std::pair<int32_t, int64_t>> kld_pending;
 };
@@ -153,6 +154,7 @@ struct spg_graph {
     int round_no = 0, launch_seq = 0;
     bool pipelined = false;                           // two batches in flight (single rank, backend with slots)
     spg_marg_stats stats{};
+    double tr_age = 0, tr_wait = 0; long tr_n = 0;   // SPG_TRACE=1: launch->commit-start, wait inside commit
     std::vector<BlanketLog> log;
     std::vector<double> hdr_buf;
     // scheduler scratch
@@ -1041,6 +1043,7 @@ extern "C" int spg_graph_round_compute(spg_graph *g) {
     // the mailbox of this slot is about to be rewritten: collect what the previous launch left in it
     if (int hrc = harvest_kld(g, bt)) return hrc;
     bt.used_mailbox = rd.mail_len > 0;
+    bt.t_launch = t0;
     int rc = g->ctx->be.run_round(g->ctx->be.user, g->dev, &rd);
     g->stats.device_seconds += now_s() - t0;
     g->stats.launch_seconds += now_s() - t0;
@@ -1085,6 +1088,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
         rc = slotted ? g->ctx->be.synchronize_slot(g->ctx->be.user, bt.slot) : g->ctx->be.synchronize(g->ctx->be.user);
         if (rc) return rc;
     }
+    g->tr_n++; g->tr_wait += now_s() - t0; g->tr_age += t0 - bt.t_launch;
     // read back the out-record part of every rank chunk (mailbox: already in host memory)
     for (int q = 0; q < nr; q++) {
         if (bt.chunk_hdr[q] == 0) continue;
@@ -1162,6 +1166,10 @@ extern "C" int spg_graph_marginalize_end(spg_graph *g, spg_marg_stats *stats) {
     for (int32_t oid : g->transient) owner_release(g, oid);
     g->transient.clear();
     g->B = &g->bt[0];
+    if (g->tr_n && getenv("SPG_TRACE"))
+        fprintf(stderr, "spg trace: %ld batches; per batch: launch call -> commit start %.1f us, wait for the ready words %.1f us\n",
+                g->tr_n, 1e6 * g->tr_age / g->tr_n, 1e6 * g->tr_wait / g->tr_n);
+    g->tr_n = 0; g->tr_age = g->tr_wait = 0;
     if (g->ctx->is_hip) g->stats.n_launches = spg::hip_backend_launches(&g->ctx->be);
 #ifdef SPG_SCHED_PROF
     if (getenv("SPG_SCHED_PROF")) {

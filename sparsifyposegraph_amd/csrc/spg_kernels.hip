@@ -21,6 +21,7 @@
 // 3x3 / 6x6 information blocks, Jacobians and the n x n tiles (n = d*k) live in LDS; HBM traffic is
 // the algorithmic minimum: every pose and edge record is read once, every new record written once.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1137,17 +1138,19 @@ struct HipBackend {
         void *h_stage = nullptr;                      // pinned host staging for the descriptor upload
         size_t c_stage = 0;
         std::vector<Timed> pending;
+        // per slot, so that a submission thread working on one slot and the graph thread draining
+        // another never share state
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+        double prof_ms = 0, prof_bytes = 0;
+        long long prof_launches = 0, prof_blankets = 0;
     };
     static constexpr int NSLOT = 4;
     Slot slots[NSLOT];
     int lds_limit = 160 * 1024;
-    int n_launches = 0;
+    std::atomic<int> n_launches{0};
     bool force_one_wave = false;  // SPG_ONE_WAVE=1: never use the two-wavefront latency variant (A/B timing)
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
     bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
-    double prof_ms = 0, prof_bytes = 0;
-    long long prof_launches = 0, prof_blankets = 0;
 
     int ensure(Slot &S, void **p, size_t *cap, size_t need) {
         if (need <= *cap) return 0;
@@ -1175,10 +1178,10 @@ static int launch_bin(HipBackend *hb, HipBackend::Slot &S, const KArgs &ka, int 
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HipBackend::Timed t{};
     if (hb->profiling) {
-        if (hb->pool.empty()) {
+        if (S.pool.empty()) {
             HIPCHK(hipEventCreate(&t.a));
             HIPCHK(hipEventCreate(&t.b));
-        } else { t.a = hb->pool.back().first; t.b = hb->pool.back().second; hb->pool.pop_back(); }
+        } else { t.a = S.pool.back().first; t.b = S.pool.back().second; S.pool.pop_back(); }
         t.bytes = alg_bytes; t.blankets = nblocks;
         HIPCHK(hipEventRecord(t.a, S.stream));
     }
@@ -1196,9 +1199,9 @@ static void drain_profile(HipBackend *hb, HipBackend::Slot &S) {
     for (auto &t : S.pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
-            hb->prof_ms += ms; hb->prof_bytes += t.bytes; hb->prof_launches++; hb->prof_blankets += t.blankets;
+            S.prof_ms += ms; S.prof_bytes += t.bytes; S.prof_launches++; S.prof_blankets += t.blankets;
         }
-        hb->pool.push_back({t.a, t.b});
+        S.pool.push_back({t.a, t.b});
     }
     S.pending.clear();
 }
@@ -1444,17 +1447,18 @@ void hip_backend_destroy(spg_backend *b) {
 void *hip_backend_stream(spg_backend *b) { return b->user ? (void *)((HipBackend *)b->user)->slots[0].stream : nullptr; }
 const char *hip_backend_error(spg_backend *b) { return b->user ? ((HipBackend *)b->user)->err : ""; }
 int hip_backend_device(spg_backend *b) { return b->user ? ((HipBackend *)b->user)->device : -1; }
-int hip_backend_launches(spg_backend *b) { return b->user ? ((HipBackend *)b->user)->n_launches : 0; }
+int hip_backend_launches(spg_backend *b) { return b->user ? ((HipBackend *)b->user)->n_launches.load() : 0; }
 void hip_backend_profile(spg_backend *b, int enable) {
     HipBackend *hb = (HipBackend *)b->user;
     if (!hb) return;
     hb->profiling = enable != 0;
-    hb->prof_ms = hb->prof_bytes = 0; hb->prof_launches = hb->prof_blankets = 0;
+    for (auto &S : hb->slots) { S.prof_ms = S.prof_bytes = 0; S.prof_launches = S.prof_blankets = 0; }
 }
 void hip_backend_profile_read(spg_backend *b, double *ms, double *bytes, long long *launches, long long *blankets) {
     HipBackend *hb = (HipBackend *)b->user;
     if (!hb) return;
-    *ms = hb->prof_ms; *bytes = hb->prof_bytes; *launches = hb->prof_launches; *blankets = hb->prof_blankets;
+    *ms = *bytes = 0; *launches = *blankets = 0;
+    for (auto &S : hb->slots) { *ms += S.prof_ms; *bytes += S.prof_bytes; *launches += S.prof_launches; *blankets += S.prof_blankets; }
 }
 
 }  // namespace spg
