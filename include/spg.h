@@ -71,7 +71,7 @@ typedef struct {
     double chord_ratio;           /* reference default 1 */
 } spg_options;
 enum {
-    SPG_FLAG_GLC_KLD = 1,   /* also evaluate the per-blanket KLD (src/logdet_function.cpp:119-133) for GLC edges */
+    SPG_FLAG_RESERVED0 = 1, /* bit 0 is reserved (the oracle uses it for a private GLC diagnostic) */
     SPG_FLAG_FORCE_EIG = 2  /* always take the eigen-decomposition route of src/logdet_function.cpp:14-64
                                (default: the equivalent gauge/Cholesky route whenever its guard holds) */
     /* bits 8..15: diagnostic pipeline truncation used by tools/phase_bench.py */

@@ -601,7 +601,7 @@ inline void run_glc(const spg_options &o, const BlanketIn &in, BlanketOut &out) 
             if (st != SPG_OK) { out.status = st; return; }
         }
     }
-    if (o.flags & SPG_FLAG_GLC_KLD) {
+    if (o.flags & 1) {   // oracle-private diagnostic (bit 0 is reserved in include/spg.h; the product ignores it)
         // diagnostic defined by this build: value() of src/logdet_function.cpp:119-133 evaluated at
         // the product information of the GLC edges, spectrum as in the LogdetFunction constructor
         int ps = pose_stride(d);

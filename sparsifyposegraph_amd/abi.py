@@ -17,7 +17,6 @@ ST_OK, ST_HMM_NOT_PD, ST_EIG_FAIL, ST_NONFINITE, ST_TIKHONOV_NOT_PD, ST_CLOSED_F
     ST_KLD_NOT_PD, ST_NEEDS_INTERIOR_POINT, ST_MARGINAL_NOT_PD, ST_EMPTY_BLANKET, ST_UNSUPPORTED, \
     ST_NEEDS_LOCAL_OPTIMIZATION = range(12)
 INFO_RANK_DEFICIENT, INFO_GLC_ROOT_EDGE = 1, 2
-FLAG_GLC_KLD = 1
 FLAG_FORCE_EIG = 2
 EINVAL, ENODEV, ENOMEM, ECAPACITY, EHIP, EIO, ESTATE, EBLANKET, ENOTPD = -1, -2, -3, -4, -5, -6, -7, -8, -9
 OUT_HDR = 6

@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256, 2) void tile_abt_kernel(TileOp op) {
 // a Cholesky factor, only invert it. *bad is set if a pivot is not positive. One wavefront per block,
 // register-resident: lane i owns row i of the block (64 fp64 registers); the factorisation broadcasts
 // pivot-row entries with v_readlane (as csrc/spg_dev_wave.hpp does for n <= 24), the inverse then runs
-// one independent forward substitution per lane (lane c = column c of L^-1) with the rows of L read
-// from LDS at wave-uniform addresses. No barrier and no exposed LDS round trip in either chain — the
+// one independent forward substitution per lane (lane c = column c of L^-1) with L[i][k] broadcast from
+// lane i's registers. No barrier and no LDS round trip in either chain — the
 // LDS-cooperative version (chol_lower<256> + tri_inverse_lower) took 119 us per block, the serial
 // critical path of the blocked factorisation.
 __global__ __launch_bounds__(64) void diag_potrf_kernel(double *Ajj, int ld, double *Linv, int *bad, int factor) {
@@ -166,13 +166,20 @@ __global__ __launch_bounds__(64) void diag_potrf_kernel(double *Ajj, int ld, dou
     Linv += (long long)blockIdx.x * TB * TB;
     const int lane = threadIdx.x;
     // coalesced load of the lower triangle into LDS (row stride 65: row-per-lane reads hit 64 banks)
-    for (int r = 0; r < TB; r++) Ls[r * 65 + lane] = (lane <= r) ? Ajj[(long long)r * ld + lane] : 0.0;
+    // (16 independent loads in flight per step: a rolled loop waits one full memory latency per row)
+    for (int r0 = 0; r0 < TB; r0 += 16) {
+        double t[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) t[i] = (lane <= r0 + i) ? Ajj[(long long)(r0 + i) * ld + lane] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) Ls[(r0 + i) * 65 + lane] = t[i];
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (factor) {
-        double a[TB];
+    double a[TB];   // row `lane` of the block (of L once factorised)
 #pragma unroll
-        for (int c = 0; c < TB; c++) a[c] = Ls[lane * 65 + c];
+    for (int c = 0; c < TB; c++) a[c] = Ls[lane * 65 + c];
+    if (factor) {
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < TB; j++) {
@@ -193,14 +200,14 @@ __global__ __launch_bounds__(64) void diag_potrf_kernel(double *Ajj, int ld, dou
         __builtin_amdgcn_wave_barrier();
         for (int r = 0; r < TB; r++) Ajj[(long long)r * ld + lane] = Ls[r * 65 + lane];
     }
-    // x[i] = (L^-1)[i][lane]
+    // x[i] = (L^-1)[i][lane]: one forward substitution per lane; L[i][k] is broadcast from lane i's registers
     double x[TB];
 #pragma unroll
     for (int i = 0; i < TB; i++) {
         double s = (lane == i) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < i; k++) s -= Ls[i * 65 + k] * x[k];   // wave-uniform LDS address: broadcast
-        x[i] = (lane <= i) ? s * fast_rcp(Ls[i * 65 + i]) : 0.0;
+        for (int k = 0; k < i; k++) s -= readlane64(a[k], i) * x[k];
+        x[i] = (lane <= i) ? s * fast_rcp(readlane64(a[i], i)) : 0.0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -13,4 +13,6 @@ python bench.py --steps $STEPS --warmup 1 > $OUT/prof_bench.json 2> $OUT/prof_be
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o run -- python3 bench.py --steps $STEPS --warmup 1 --no-cpu-baseline > $OUT/prof_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch -o run -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write -o run -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kld -o run -- python3 tools/kld_bench.py 2500 > $OUT/prof_kld.log 2>&1
+python tools/throughput_bench.py 64 512 16384 131072 > $OUT/prof_throughput.log 2>&1
 find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -name '*.csv' | head -20

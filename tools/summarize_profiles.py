@@ -74,6 +74,15 @@ summary = {
     ],
 }
 json.dump(summary, open(os.path.join(prof, f"{tag}_pmc_summary.json"), "w"), indent=1)
+# dense global KLD (tools/kld_bench.py 2500) and the blanket kernel in throughput mode
+try:
+    shutil.copy(one("prof_kld/**/*kernel_stats.csv"), os.path.join(prof, f"{tag}_kld_kernel_stats.csv"))
+    lines = [l for l in open(os.path.join(out, "prof_kld.log")) if l.startswith("{")]
+    open(os.path.join(prof, f"{tag}_kld_bench.json"), "w").write(lines[-1])
+    lines = [l for l in open(os.path.join(out, "prof_throughput.log")) if l.startswith("{")]
+    open(os.path.join(prof, f"{tag}_throughput_bench.jsonl"), "w").writelines(lines)
+except SystemExit as e:
+    print("no KLD / throughput profile:", e)
 print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}, indent=1))
 for k, v in kernels.items():
     print(k[:90], v)
