@@ -70,10 +70,10 @@ extern "C" int spg_marginalize_batch(spg_ctx *, const spg_options *o, const spg_
 }
 
 // ------------------------------------------------------------------------------ round entry
-extern "C" int spg_run_round(double *arena, const spg_round_desc *rd) {
+static int run_round_range(double *arena, const spg_round_desc *rd, int lo, int hi, int step) {
     const spg_options &o = *rd->opts;
     int d = o.pose_dim, ps = pose_stride(d);
-    for (int bi = rd->first; bi < rd->first + rd->count; bi++) {
+    for (int bi = lo; bi < hi; bi += step) {
         const spg_blanket_desc &bd = rd->blankets[bi];
         std::vector<double> poses((size_t)bd.n_vert * ps);
         for (int v = 0; v < bd.n_vert; v++)
@@ -113,6 +113,27 @@ extern "C" int spg_run_round(double *arena, const spg_round_desc *rd) {
         if (bd.tinfo_off >= 0 && out.target.r > 0)
             std::memcpy(arena + bd.tinfo_off, out.target.a.data(), out.target.a.size() * sizeof(double));
     }
+    return 0;
+}
+
+
+extern "C" int spg_run_round(double *arena, const spg_round_desc *rd) {
+    return run_round_range(arena, rd, rd->first, rd->first + rd->count, 1);
+}
+
+// The same round with its (independent) blankets spread over host threads: bench.py's second CPU
+// baseline. Blankets write disjoint records, so no synchronisation is needed.
+static int g_round_threads = 1;
+extern "C" void spgref_set_round_threads(int n) { g_round_threads = n < 1 ? 1 : n; }
+extern "C" int spg_run_round_mt(double *arena, const spg_round_desc *rd) {
+    int nt = std::min(g_round_threads, std::max(1, rd->count / 8));
+    if (nt <= 1) return spg_run_round(arena, rd);
+    std::vector<std::thread> th;
+    std::vector<int> rc(nt, 0);
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([&, t] { rc[t] = run_round_range(arena, rd, rd->first + t, rd->first + rd->count, nt); });
+    for (auto &x : th) x.join();
+    for (int t = 0; t < nt; t++) if (rc[t]) return rc[t];
     return 0;
 }
 

@@ -48,6 +48,8 @@ def lib():
         L.spgref_graph_kullback_leibler.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, f64p]
         L.spgref_spd_logdet.restype = C.c_double
         L.spg_run_round.argtypes = [C.c_void_p, C.POINTER(abi.RoundDesc)]
+        L.spg_run_round_mt.argtypes = [C.c_void_p, C.POINTER(abi.RoundDesc)]
+        L.spgref_set_round_threads.argtypes = [C.c_int]
         _LIB = L
     return _LIB
 
@@ -157,8 +159,10 @@ class OracleBackend:
 
     NSLOT = 4
 
-    def __init__(self, slots=False):
+    def __init__(self, slots=False, threads=1):
         self.L = lib()
+        self.L.spgref_set_round_threads(int(threads))
+        run = self.L.spg_run_round_mt if threads > 1 else self.L.spg_run_round
         self.bufs = {}
         self.mail = [None] * self.NSLOT
 
@@ -180,7 +184,7 @@ class OracleBackend:
             return 0
 
         def _run_round(user, arena, rd):
-            rc = self.L.spg_run_round(arena, rd)
+            rc = run(arena, rd)
             r = rd.contents
             if rc == 0 and slots and r.mail_len > 0:
                 sl = r.slot % self.NSLOT
@@ -211,8 +215,9 @@ class OracleBackend:
             self.struct = abi.Backend(None, *self.cb, abi._MAILBOX(), abi._SYNC_SLOT(), abi._MAILBOX_SLOT())
 
 
-def injected_context(slots=False):
-    """Context of the PRODUCT library whose compute backend is the oracle (CPU tests only)."""
+def injected_context(slots=False, threads=1):
+    """Context of the PRODUCT library whose compute backend is the oracle (CPU tests and bench.py's
+    all-cores CPU baseline only)."""
     from sparsifyposegraph_amd.lib import Context
-    be = OracleBackend(slots)
+    be = OracleBackend(slots, threads)
     return Context.injected(be.struct, keep=be)
