@@ -674,7 +674,7 @@ static void release_batch_owners(spg_graph *g, Batch &bt) {
 // Select this round's mutually commuting blankets, in list order. Fills bt.rb; rewrites g->pending.
 #ifdef SPG_SCHED_PROF
 #include <x86intrin.h>
-static unsigned long long prof_t[8], prof_n[8];
+static unsigned long long prof_t[16], prof_n[16];
 #define PT0 unsigned long long pt_ = __rdtsc()
 #define PT(i) do { unsigned long long n_ = __rdtsc(); prof_t[i] += n_ - pt_; prof_n[i]++; pt_ = n_; } while (0)
 #else
@@ -760,10 +760,12 @@ static void schedule_round(spg_graph *g) {
             bt.rb_verts.insert(bt.rb_verts.end(), centres.begin(), centres.end());
             bt.rb_verts.insert(bt.rb_verts.end(), tmp.begin(), tmp.end());
             rbk.nv = (int32_t)(centres.size() + tmp.size());
+            PT(5);
             collect_edges(g, bt.rb_verts.data() + rbk.vbeg, rbk.nv, centres, o.include_intra_clique != 0, work);
             rbk.ebeg = (int32_t)bt.rb_edges.size();
             rbk.ne = (int32_t)work.size();
             bt.rb_edges.insert(bt.rb_edges.end(), work.begin(), work.end());
+            PT(6);
             rbk.owner = reg(my_batch, rbk.vbeg, rbk.nv);
             bt.rb.push_back(std::move(rbk));
             consec = 0;
@@ -819,7 +821,8 @@ static void schedule_round(spg_graph *g) {
             // (almost always) waiting on them too, and not scanning only defers more
             // (with another batch in flight the blocked stretch is usually exactly the part of the list
             //  that waits for it: give up sooner, the next call comes right after that batch commits)
-            size_t patience = inflight ? 12 + bt.rb.size() / 16 : 48 + bt.rb.size() / 8;
+            static const int pat_inflight = [] { const char *e = getenv("SPG_PATIENCE"); return e ? atoi(e) : 12; }();
+            size_t patience = inflight ? pat_inflight + bt.rb.size() / 16 : 48 + bt.rb.size() / 8;
             if (++consec > patience || n_deferred > 256 + 2 * bt.rb.size()) stop = true;
             PT(3);
         }
@@ -1112,6 +1115,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
         const spg_blanket_desc &bd = r.desc;
         const double *rec = g->host.data() + bd.out_off;
         int status = (int)rec[0], inf = (int)rec[1], n_new = (int)rec[4];
+        PT0;
         g->log.push_back({g->vid[r.root], bt.round_no, status, inf, rec[2], rec[3]});
         if (polled && (status == SPG_OK)) bt.kld_pending.push_back({(int32_t)g->log.size() - 1, bd.out_off - (bt.rinfo.region_off + bt.rinfo.chunk_len * bt.eff_rank)});
         g->stats.max_blanket = std::max(g->stats.max_blanket, r.nv);
@@ -1120,6 +1124,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
         bool fine = (status == SPG_OK || status == SPG_ST_KLD_NOT_PD);
         if (!fine) { g->stats.n_bad_status++; continue; }
         if (!polled && std::isfinite(rec[2])) g->stats.kld_sum += rec[2];
+        PT(7);
         for (int ei_ = 0; ei_ < r.ne; ei_++) {
             int32_t eid = redges[ei_];
             GEdge &e = g->edges[eid];
@@ -1130,6 +1135,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
                 for (size_t j = 0; j < av.size(); j++) if (av[j] == eid) { av[j] = av.back(); av.pop_back(); break; }
             }
         }
+        PT(8);
         for (int i = 0; i < r.n_remove; i++) {
             int32_t v = rverts[i];
             g->valive[v] = 0;
@@ -1137,6 +1143,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
             g->n_live_v--;
             g->stats.n_removed++;
         }
+        PT(9);
         int vpos = 0;
         for (int e = 0; e < n_new; e++) {
             int kind = (int)rec[SPG_OUT_HDR + 4 * e + 0];
@@ -1149,6 +1156,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
             add_edge_idx(g, kind, nv, vix.data(), bd.new_off + rel, len);
             g->stats.n_new_edges++;
         }
+        PT(10);
     }
     bt.round_open = false;
     release_batch_owners(g, bt);
@@ -1173,8 +1181,8 @@ extern "C" int spg_graph_marginalize_end(spg_graph *g, spg_marg_stats *stats) {
     if (g->ctx->is_hip) g->stats.n_launches = spg::hip_backend_launches(&g->ctx->be);
 #ifdef SPG_SCHED_PROF
     if (getenv("SPG_SCHED_PROF")) {
-        const char *nm[4] = {"neighbourhood", "owner scan", "select", "defer"};
-        for (int i = 0; i < 4; i++) { fprintf(stderr, "sched %-14s %10llu calls %8.3f Mcycles\n", nm[i], prof_n[i], prof_t[i] * 1e-6); prof_t[i] = prof_n[i] = 0; }
+        const char *nm[12] = {"neighbourhood", "owner scan", "select:reg", "defer", "-", "select:sort", "select:edges", "commit:log", "commit:rm edges", "commit:rm verts", "commit:add", "prepare"};
+        for (int i = 0; i < 12; i++) { fprintf(stderr, "sched %-14s %10llu calls %8.3f Mcycles\n", nm[i], prof_n[i], prof_t[i] * 1e-6); prof_t[i] = prof_n[i] = 0; }
     }
 #endif
     if (stats) *stats = g->stats;

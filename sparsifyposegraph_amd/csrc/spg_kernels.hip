@@ -1438,6 +1438,8 @@ void hip_backend_destroy(spg_backend *b) {
         if (S.d_gws) (void)hipFree(S.d_gws);
         if (S.h_mail) (void)hipHostFree(S.h_mail);
         if (S.h_stage) (void)hipHostFree(S.h_stage);
+        for (auto &t : S.pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+        for (auto &pr : S.pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         (void)hipStreamDestroy(S.stream);
     }
     delete hb;

@@ -84,3 +84,18 @@ def test_oracle_global_kld_mahalanobis_term():
     k = ids.index(int(sub["ids"][7]))
     diff[3 * k:3 * k + 3] = [-0.01, 0.02, -0.003]     # baseline minus other
     assert abs(t["mahalanobis"] - diff @ Hm @ diff) <= 1e-9 * max(1.0, t["mahalanobis"])
+
+
+def test_product_global_kld_needs_the_device():
+    """The product has no CPU path for the dense KLD: with an injected (CPU) backend the entry points
+    fail loudly instead of falling back."""
+    from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    from sparsifyposegraph_amd.lib import SpgError
+    g, which, opts, *_ = util.load_golden("intel_nfr_tree_sp3")
+    sub, w = util.prefix_graph(g, which, 30)
+    ictx = oracle_lib.injected_context()
+    a, b = GraphWrapperHIP.from_dict(sub, ctx=ictx), GraphWrapperHIP.from_dict(sub, ctx=ictx)
+    with pytest.raises(SpgError, match="HIP backend"):
+        a.kullbackLeibler(b)
+    with pytest.raises(SpgError, match="HIP backend"):
+        a.information()
