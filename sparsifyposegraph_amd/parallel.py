@@ -60,7 +60,14 @@ def marginalize_sharded(graph, which, opts, device=None, group=None, stepwise=Fa
             state["view"], state["ptr"] = arena_tensor(graph, device), arena_ptr
         region = state["view"][region_off:region_off + ws * chunk_len]
         mine = region[rank * chunk_len:(rank + 1) * chunk_len]
-        dist.all_gather_into_tensor(region, mine, group=group)
+        if on_gpu and dist.get_backend(group) == "gloo":
+            # device arena, host-only collective (several ranks sharing one GPU, no RCCL): stage
+            # through host memory. Same data movement, used by the single-GPU sharding test.
+            out = torch.empty(ws * chunk_len, dtype=region.dtype)
+            dist.all_gather_into_tensor(out, mine.cpu(), group=group)
+            region.copy_(out)
+        else:
+            dist.all_gather_into_tensor(region, mine, group=group)
         if on_gpu:
             torch.cuda.synchronize()
 
