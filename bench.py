@@ -7,12 +7,15 @@ conflict-free rounds + the per-blanket HIP kernel + graph update. Inputs (poses 
 resident in HBM before the timed region starts; per round only int descriptors go up and the
 per-blanket output records come back.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds a replica, each
-round's blankets are sharded over the ranks and one all-gather (RCCL over xGMI) per round exchanges
-the recovered edge records — total work is fixed, so scaling is "strong".
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds a replica; batches of
+>= 2048 blankets are sharded over the ranks with one all-gather (RCCL over xGMI) of the recovered edge
+records, narrower (latency-bound) batches are computed redundantly by every rank — total work is
+fixed, so scaling is "strong" (DESIGN.md 6 explains why it stays near 1x on this workload).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel,
-HIP-event timed on its own stream) and, at N = 1, `cpu_baseline` (the CPU oracle, 1 core).
+HIP-event timed on its own stream) and, at N = 1, `cpu_baseline` (the CPU oracle: strictly sequential
+on 1 core = the reference's execution model, plus `rounds_all_cores`: the same rounds over the host
+cores) and `parity` (the device result of the last step against that sequential oracle run).
 """
 import argparse
 import json
