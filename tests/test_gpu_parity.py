@@ -175,6 +175,58 @@ def test_synthetic_properties(hip_ctx):
     assert hg.numEdges() >= hg.numVertices() - 1
 
 
+def test_full_size_properties_100k(hip_ctx, monkeypatch):
+    """BASELINE.json config 5 at full size (100 000 poses, 49 998 removals) through properties that do
+    not need the oracle: all removals done with status OK, every kept vertex survives, the graph stays
+    connected, edge count = E - removed blanket edges + recovered tree edges (V-1 <= E), recovered
+    information symmetric PD, unit quaternions, per-blanket KLD >= 0 and k = 2 blankets exactly 0,
+    and the pipelined and the strictly serial driver (different batch compositions, both kernel
+    variants) produce the same graph. bench.py additionally checks this workload against the
+    sequential oracle on every run (`parity` in its JSON line)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    n = 100000
+    g = g2o_io.synth_sphere(n_poses=n, ring=400)
+    which = np.array([i for i in range(4, n) if i % 2], np.int32)
+    opts = abi.make_options(6)
+    results = []
+    for serial in ("0", "1"):
+        monkeypatch.setenv("SPG_NO_PIPELINE", serial)
+        hg = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+        st = hg.marginalizeNoOptimize(which, opts)
+        assert st["n_bad_status"] == 0 and st["n_removed"] == len(which)
+        results.append((hg, st))
+    monkeypatch.delenv("SPG_NO_PIPELINE")
+    (hg, st), (hs, ss) = results
+    assert ss["n_rounds"] < st["n_rounds"]            # the pipelined driver cut the rounds into parts
+    ids, _ = hg.vertices()
+    assert np.array_equal(ids, np.setdiff1d(g["ids"], which))
+    e = hg.edges()
+    assert (e["kind"] == abi.EDGE_BINARY).all()
+    ij = e["vert_ids"].reshape(-1, 2)
+    pos = {int(v): i for i, v in enumerate(ids)}
+    a = np.fromiter((pos[int(x)] for x in ij[:, 0]), np.int64, len(ij))
+    b = np.fromiter((pos[int(x)] for x in ij[:, 1]), np.int64, len(ij))
+    ncomp, _ = connected_components(coo_matrix((np.ones(len(a)), (a, b)), shape=(len(ids), len(ids))), directed=False)
+    assert ncomp == 1
+    assert len(ij) >= len(ids) - 1
+    data = e["data"].reshape(-1, 28)
+    iu = np.triu_indices(6)
+    M = np.zeros((len(data), 6, 6))
+    M[:, iu[0], iu[1]] = data[:, 7:]
+    M = M + np.transpose(M, (0, 2, 1)) - np.einsum("nij,ij->nij", M, np.eye(6))
+    assert np.linalg.eigvalsh(M).min() > 0
+    assert np.abs(np.linalg.norm(data[:, 3:7], axis=1) - 1).max() < 1e-12
+    bl = hg.blankets()
+    assert (bl["status"] == 0).all() and len(bl["root"]) == len(which)
+    assert (bl["kld"] > -1e-9).all() and np.isfinite(bl["kld"]).all()
+    assert abs(st["kld_sum"] - bl["kld"].sum()) <= 1e-9 * bl["kld"].sum()
+    # same graph from both drivers (commuting removals only change order; kernel variants differ in rounding)
+    worst = util.compare_edge_sets(6, hs.edges(), e, rtol=1e-10)
+    assert abs(ss["kld_sum"] - st["kld_sum"]) <= 1e-10 * st["kld_sum"]
+    print(f"100k: rounds pipelined {st['n_rounds']} / serial {ss['n_rounds']}, kld_sum {st['kld_sum']:.6f}, drivers agree to {worst:.1e}")
+
+
 def test_arena_tensor_and_inplace_allgather_on_device(hip_ctx):
     """The multi-GPU exchange path on real hardware, as far as one GPU allows: the zero-copy torch view
     of the device arena (CUDA array interface) really aliases it, and an in-place RCCL
