@@ -236,6 +236,20 @@ typedef struct {
  * graphs must live on the same device. SPG_ENOTPD if either information matrix is not PD. */
 int spg_graph_kullback_leibler(spg_graph *baseline, spg_graph *other, int32_t fixed_id, spg_kld_terms *out);
 
+/* ---- optimize() -------------------------------------------------------------
+ * GraphWrapperG2O::optimize() (src/graph_wrapper_g2o.cpp:250-269): one vertex fixed (fixed_id < 0: the
+ * smallest id), g2o's Levenberg-Marquardt for up to `iterations` iterations (the reference uses 50),
+ * no robust kernel. Dense on the device (Hessian assembly, blocked fp64-MFMA Cholesky of H + lambda I,
+ * triangular solves, pose updates, chi2): for graphs of up to 32k scalar variables. The estimates of
+ * the graph are updated in place. */
+typedef struct {
+    int32_t iterations, trials;          /* LM iterations run; linear systems solved */
+    double chi2_initial, chi2_final, lambda_final;
+    int64_t n;                           /* scalar variables */
+    double device_seconds;
+} spg_optimize_stats;
+int spg_graph_optimize(spg_graph *g, int iterations, int32_t fixed_id, spg_optimize_stats *out);
+
 /* ---- round-stepping form of the same call, for multi-GPU sharding ---------------------------
  * All ranks hold a replica and run the same deterministic scheduler; rank r computes its slice of
  * each round's blankets; the caller exchanges the round's output region of the arena between

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <map>
 #include <set>
+#include <limits>
 #include <thread>
 #include "ref_blanket.hpp"
 
@@ -442,6 +443,182 @@ int spgref_graph_kullback_leibler(void *hb, void *ho, int32_t fixed_id, double *
     }
     terms[0] = 0.5 * (innerprod + mahal - logdetx - logdety - n);
     terms[1] = innerprod; terms[2] = mahal; terms[3] = logdetx; terms[4] = logdety; terms[5] = n;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ optimize()
+// GraphWrapperG2O::optimize (src/graph_wrapper_g2o.cpp:250-269): vertex 0 fixed, then
+// SparseOptimizer::optimize(50) with g2o's OptimizationAlgorithmLevenberg. g2o is an un-vendored,
+// un-pinned dependency of the reference; its LM is restated here from the published algorithm
+// (g2o/core/optimization_algorithm_levenberg.cpp): lambda_0 = 1e-5 * max|diag H|; per iteration up to 10
+// trials of (H + lambda I) x = b, gain ratio rho = (chi2 - chi2') / (x.(lambda x + b) + 1e-3),
+// good step: lambda *= clamp(1 - (2 rho - 1)^3, 1/3, 2/3), ni = 2; bad step: lambda *= ni, ni *= 2;
+// Terminate when 10 trials failed, rho == 0 or lambda is not finite. Dense linear algebra.
+namespace {
+struct LinSys { Mat H; std::vector<double> b; double chi2 = 0; std::vector<int> ids; };
+
+// chi2, H = sum J^T Omega J and b = -sum J^T Omega e over the live edges, fixed vertex dropped
+LinSys build_system(RGraph *g, int fixed_id, bool want_H) {
+    int d = g->d, ps = pose_stride(d);
+    LinSys S;
+    std::map<int, int> loc;
+    for (auto &kv : g->pose) if (kv.first != fixed_id) { loc[kv.first] = (int)S.ids.size(); S.ids.push_back(kv.first); }
+    int n = d * (int)S.ids.size();
+    if (want_H) S.H = Mat(n, n);
+    S.b.assign(n, 0.0);
+    for (auto &e : g->edges) {
+        if (!e.alive) continue;
+        int q = (int)e.ids.size();
+        std::vector<Mat> A(q);          // weighted Jacobian blocks: sqrt-information form, rows = error dim
+        std::vector<double> r;          // weighted error
+        if (e.kind == SPG_EDGE_BINARY) {
+            Mat Ji, Jj;
+            double err[6];
+            binary_edge_jac(d, g->pose[e.ids[0]].data(), g->pose[e.ids[1]].data(), e.data.data(), Ji, Jj, err);
+            Mat O = info_from_upper(e.data.data() + ps, d);
+            // contributions with the information matrix itself (no square root needed)
+            Mat OJi = matmul(O, Ji), OJj = matmul(O, Jj);
+            std::vector<double> Oe(d, 0.0);
+            for (int i = 0; i < d; i++) for (int k = 0; k < d; k++) Oe[i] += O(i, k) * err[k];
+            for (int i = 0; i < d; i++) S.chi2 += err[i] * Oe[i];
+            const Mat *J[2] = {&Ji, &Jj};
+            const Mat *OJ[2] = {&OJi, &OJj};
+            for (int a = 0; a < 2; a++) {
+                auto ia = loc.find(e.ids[a]);
+                if (ia == loc.end()) continue;
+                for (int rr = 0; rr < d; rr++) {
+                    double s = 0;
+                    for (int k = 0; k < d; k++) s += (*J[a])(k, rr) * Oe[k];
+                    S.b[ia->second * d + rr] -= s;
+                }
+                if (!want_H) continue;
+                for (int c = 0; c < 2; c++) {
+                    auto ic = loc.find(e.ids[c]);
+                    if (ic == loc.end()) continue;
+                    if (a != c && e.ids[0] == e.ids[1]) continue;
+                    Mat blk = matmul(transpose(*J[a]), *OJ[c]);
+                    for (int rr = 0; rr < d; rr++) for (int cc = 0; cc < d; cc++) S.H(ia->second * d + rr, ic->second * d + cc) += blk(rr, cc);
+                }
+            }
+        } else {
+            std::vector<const double *> poses(q);
+            for (int i = 0; i < q; i++) poses[i] = g->pose[e.ids[i]].data();
+            int nq = d * q, rdim = (int)((e.data.size() - nq) / nq);
+            std::vector<double> rerr;
+            Mat Jr;
+            glc_reparam(d, q, poses.data(), e.data.data(), &rerr, &Jr);
+            Mat W(rdim, nq);
+            for (int i = 0; i < rdim; i++) for (int j = 0; j < nq; j++) W(i, j) = e.data[nq + (size_t)i * nq + j];
+            Mat Aw = matmul(W, Jr);
+            std::vector<double> wr(rdim, 0.0);
+            for (int i = 0; i < rdim; i++) for (int j = 0; j < nq; j++) wr[i] += W(i, j) * rerr[j];
+            for (int i = 0; i < rdim; i++) S.chi2 += wr[i] * wr[i];
+            for (int a = 0; a < q; a++) {
+                auto ia = loc.find(e.ids[a]);
+                if (ia == loc.end()) continue;
+                for (int rr = 0; rr < d; rr++) {
+                    double s = 0;
+                    for (int p = 0; p < rdim; p++) s += Aw(p, a * d + rr) * wr[p];
+                    S.b[ia->second * d + rr] -= s;
+                }
+                if (!want_H) continue;
+                for (int c = 0; c < q; c++) {
+                    auto ic = loc.find(e.ids[c]);
+                    if (ic == loc.end()) continue;
+                    for (int rr = 0; rr < d; rr++) for (int cc = 0; cc < d; cc++) {
+                        double s = 0;
+                        for (int p = 0; p < rdim; p++) s += Aw(p, a * d + rr) * Aw(p, c * d + cc);
+                        S.H(ia->second * d + rr, ic->second * d + cc) += s;
+                    }
+                }
+            }
+        }
+    }
+    return S;
+}
+
+// VertexSE2 / VertexSE3 oplus: additive (x, y, theta wrapped) / right-multiplicative fromVectorMQT
+void apply_update(RGraph *g, const std::vector<int> &ids, const std::vector<double> &x) {
+    int d = g->d;
+    for (size_t i = 0; i < ids.size(); i++) {
+        std::vector<double> &p = g->pose[ids[i]];
+        if (d == 3) {
+            p[0] += x[i * 3]; p[1] += x[i * 3 + 1]; p[2] = normalize_theta(p[2] + x[i * 3 + 2]);
+        } else {
+            Iso3 X = se3_oplus(iso_from_tq(p.data()), &x[i * 6]);
+            iso_to_tq(X, p.data());
+            double nq = std::sqrt(p[3] * p[3] + p[4] * p[4] + p[5] * p[5] + p[6] * p[6]);
+            for (int a = 3; a < 7; a++) p[a] /= nq;
+        }
+    }
+}
+}  // namespace
+
+// stats: iterations done, LM trials, chi2 before, chi2 after, final lambda
+int spgref_graph_optimize(void *h, int iterations, int32_t fixed_id, double *stats) {
+    RGraph *g = (RGraph *)h;
+    double lambda = 0, ni = 2;
+    int it = 0, trials = 0;
+    double chi_first = NAN, chi_last = NAN;
+    for (; it < iterations; it++) {
+        LinSys S = build_system(g, fixed_id, true);
+        int n = (int)S.b.size();
+        double currentChi = S.chi2;
+        if (it == 0) {
+            chi_first = currentChi;
+            double md = 0;
+            for (int i = 0; i < n; i++) md = std::max(md, std::fabs(S.H(i, i)));
+            lambda = 1e-5 * md;
+            ni = 2;
+        }
+        chi_last = currentChi;
+        double rho = 0;
+        int qmax = 0;
+        bool lambda_ok = true;
+        do {
+            std::map<int, std::vector<double>> backup = g->pose;       // push()
+            Mat A = S.H;
+            for (int i = 0; i < n; i++) A(i, i) += lambda;
+            bool ok2 = chol_lower(A);
+            Mat X(n, 1);
+            for (int i = 0; i < n; i++) X(i, 0) = S.b[i];
+            std::vector<double> x(n, 0.0);
+            if (ok2) { chol_solve(A, X); for (int i = 0; i < n; i++) x[i] = X(i, 0); }
+            apply_update(g, S.ids, x);
+            double tempChi = build_system(g, fixed_id, false).chi2;
+            if (!ok2) tempChi = std::numeric_limits<double>::max();
+            double scale = 1e-3;
+            for (int i = 0; i < n; i++) scale += x[i] * (lambda * x[i] + S.b[i]);
+            rho = (currentChi - tempChi) / scale;
+            trials++;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1.0 - std::pow(2 * rho - 1, 3);
+                alpha = std::min(alpha, 2.0 / 3.0);
+                lambda *= std::max(1.0 / 3.0, alpha);
+                ni = 2;
+                currentChi = tempChi;
+                chi_last = tempChi;
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                g->pose = backup;                                       // pop()
+                if (!std::isfinite(lambda)) { lambda_ok = false; break; }
+            }
+            qmax++;
+        } while (rho < 0 && qmax < 10);
+        if (qmax == 10 || rho == 0 || !lambda_ok) { it++; break; }      // Terminate
+    }
+    if (stats) { stats[0] = it; stats[1] = trials; stats[2] = chi_first; stats[3] = chi_last; stats[4] = lambda; }
+    return 0;
+}
+
+double spgref_graph_chi2(void *h, int32_t fixed_id) { return build_system((RGraph *)h, fixed_id, false).chi2; }
+
+int spgref_graph_set_estimate(void *h, int id, const double *pose) {
+    RGraph *g = (RGraph *)h;
+    auto it = g->pose.find(id);
+    if (it == g->pose.end()) return SPG_EINVAL;
+    it->second.assign(pose, pose + pose_stride(g->d));
     return 0;
 }
 

@@ -70,6 +70,15 @@ class KldTerms(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class OptimizeStats(C.Structure):
+    """spg_optimize_stats (include/spg.h)"""
+    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
+                ("lambda_final", C.c_double), ("n", C.c_int64), ("device_seconds", C.c_double)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class RoundInfo(C.Structure):
     _fields_ = [("n_blankets", C.c_int32), ("my_first", C.c_int32), ("my_count", C.c_int32),
                 ("region_off", C.c_int64), ("chunk_len", C.c_int64), ("exchange", C.c_int32), ("pad_", C.c_int32)]

@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <limits>
+#include <cmath>
 #include <vector>
 
 #include "spg_dev_geom.hpp"
@@ -328,7 +330,7 @@ __device__ __forceinline__ void load_pose(const double *arena, int64_t off, doub
 template <int D>
 __global__ __launch_bounds__(64) void glc_weighted_jacobian_kernel(GraphDev g) {
     constexpr int DD = D * D, PSZ = (D == 6) ? kIso : 3;
-    extern __shared__ double Jb[];   // q x (Ji0 | Jii)
+    extern __shared__ double Jb[];   // q x (Ji0 | Jii), then q x D reparametrisation errors
     const int e = blockIdx.x, tid = threadIdx.x;
     const spg_edge_ref er = g.er[e];
     if (er.kind != SPG_EDGE_GLC) return;
@@ -339,18 +341,25 @@ __global__ __launch_bounds__(64) void glc_weighted_jacobian_kernel(GraphDev g) {
         double X0[PSZ], Xi[PSZ];
         load_pose<D>(g.arena, g.vpo[g.ev[er.vbegin]], X0);
         load_pose<D>(g.arena, g.vpo[g.ev[er.vbegin + i]], Xi);
+        double *er_i = Jb + q * 2 * DD + i * D;   // GLCEdge::computeError before the weighting (src/glc_edge.cpp:28-38)
         if (D == 6) {
             double Z[kIso], Xz[kIso] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
             iso_from_mqt(rec + 6 * i, Z);
-            if (i == 0) se3_edge_jac(Xz, X0, Z, Jb, Jb + DD, nullptr);
-            else se3_edge_jac(X0, Xi, Z, Jb + i * 2 * DD, Jb + i * 2 * DD + DD, nullptr);
+            if (i == 0) se3_edge_jac(Xz, X0, Z, Jb, Jb + DD, er_i);
+            else se3_edge_jac(X0, Xi, Z, Jb + i * 2 * DD, Jb + i * 2 * DD + DD, er_i);
         } else {
             double xz[3] = {0, 0, 0};
-            if (i == 0) se2_edge_jac(xz, X0, rec, Jb, Jb + DD, nullptr);
-            else se2_edge_jac(X0, Xi, rec + 3 * i, Jb + i * 2 * DD, Jb + i * 2 * DD + DD, nullptr);
+            if (i == 0) se2_edge_jac(xz, X0, rec, Jb, Jb + DD, er_i);
+            else se2_edge_jac(X0, Xi, rec + 3 * i, Jb + i * 2 * DD, Jb + i * 2 * DD + DD, er_i);
         }
     }
     __syncthreads();
+    for (int row = tid; row < rr; row += 64) {     // weighted error r = W * err
+        const double *Wr = rec + dq + (int64_t)row * dq, *er = Jb + q * 2 * DD;
+        double s = 0;
+        for (int j = 0; j < dq; j++) s += Wr[j] * er[j];
+        Aw[(int64_t)rr * dq + row] = s;
+    }
     for (int it = tid; it < rr * dq; it += 64) {
         int row = it / dq, col = it - row * dq, blk = col / D, c = col - blk * D;
         const double *Wr = rec + dq + (int64_t)row * dq;
@@ -370,9 +379,10 @@ __global__ __launch_bounds__(64) void glc_weighted_jacobian_kernel(GraphDev g) {
 // deterministic (edges in ascending index), no atomics. Only the lower block triangle (pos(u) <=
 // pos(v)) is written; diagonal blocks are written in full.
 template <int D>
-__global__ __launch_bounds__(64) void dense_assemble_kernel(GraphDev g, double *M, int ld) {
+__global__ __launch_bounds__(64) void dense_assemble_kernel(GraphDev g, double *M, int ld, double *bvec) {
     constexpr int DD = D * D, PS = (D == 6) ? 7 : 3, PSZ = (D == 6) ? kIso : 3;
-    __shared__ double Jv[DD], Ju[DD], Om[DD], Tv[DD], Tu[DD];
+    __shared__ double Jv[DD], Ju[DD], Om[DD], Tv[DD], Tu[DD], Er[D];
+    double bacc = 0;   // lanes < D: b_v[lane] = -sum_e (J_v^T Omega e)[lane]  (g2o's right-hand side)
     const int v = blockIdx.x, tid = threadIdx.x;
     const int pv = g.pos[v];
     if (pv < 0) return;
@@ -394,9 +404,9 @@ __global__ __launch_bounds__(64) void dense_assemble_kernel(GraphDev g, double *
                 if (D == 6) {
                     double Z[kIso];
                     iso_from_tq(rec, Z);
-                    se3_edge_jac(Xi, Xj, Z, Ji, Jj, nullptr);
+                    se3_edge_jac(Xi, Xj, Z, Ji, Jj, Er);
                 } else {
-                    se2_edge_jac(Xi, Xj, rec, Ji, Jj, nullptr);
+                    se2_edge_jac(Xi, Xj, rec, Ji, Jj, Er);
                 }
             }
             if (act) {
@@ -419,6 +429,10 @@ __global__ __launch_bounds__(64) void dense_assemble_kernel(GraphDev g, double *
                 diag += sd;
                 if (pu >= 0 && pu < pv) M[(long long)(pv + r) * ld + pu + c] += so;
             }
+            if (tid < D) {
+#pragma unroll
+                for (int p = 0; p < D; p++) bacc -= Tv[p * D + tid] * Er[p];
+            }
             __syncthreads();
         } else {
             const int q = er.nv, dq = D * q, rr = (er.len - dq) / dq;
@@ -435,9 +449,159 @@ __global__ __launch_bounds__(64) void dense_assemble_kernel(GraphDev g, double *
                     else M[(long long)(pv + r) * ld + pu + c] += s;
                 }
             }
+            if (tid < D) {
+                const double *wr = Aw + (int64_t)rr * dq;
+                for (int p = 0; p < rr; p++) bacc -= Aw[(int64_t)p * dq + iv * D + tid] * wr[p];
+            }
         }
     }
     if (act) M[(long long)(pv + r) * ld + pv + c] = diag;
+    if (bvec && tid < D) bvec[pv + tid] = bacc;
+}
+
+// chi2 per edge (binary: e^T Omega e; GLC: ||W e||^2 from glc_weighted_jacobian_kernel), one lane per edge
+template <int D>
+__global__ void edge_chi2_kernel(GraphDev g, double *chi) {
+    constexpr int DD = D * D, PS = (D == 6) ? 7 : 3, PSZ = (D == 6) ? kIso : 3;
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= g.ne) return;
+    const spg_edge_ref er = g.er[e];
+    double s = 0;
+    if (er.kind == SPG_EDGE_BINARY) {
+        const double *rec = g.arena + er.off;
+        double Xi[PSZ], Xj[PSZ], Ji[DD], Jj[DD], err[D];
+        load_pose<D>(g.arena, g.vpo[g.ev[er.vbegin]], Xi);
+        load_pose<D>(g.arena, g.vpo[g.ev[er.vbegin + 1]], Xj);
+        if (D == 6) {
+            double Z[kIso];
+            iso_from_tq(rec, Z);
+            se3_edge_jac(Xi, Xj, Z, Ji, Jj, err);
+        } else {
+            se2_edge_jac(Xi, Xj, rec, Ji, Jj, err);
+        }
+        int p = PS;
+#pragma unroll
+        for (int i = 0; i < D; i++)
+#pragma unroll
+            for (int j = i; j < D; j++) { s += ((i == j) ? 1.0 : 2.0) * err[i] * rec[p] * err[j]; p++; }
+    } else {
+        const int dq = D * er.nv, rr = (er.len - dq) / dq;
+        const double *wr = g.aw + g.aw_off[e] + (int64_t)rr * dq;
+        for (int p = 0; p < rr; p++) s += wr[p] * wr[p];
+    }
+    chi[e] = s;
+}
+
+// out[slot] = sum v[0..n) in a fixed order (one workgroup)
+__global__ __launch_bounds__(256) void sum_kernel(const double *v, int n, double *out, int slot) {
+    __shared__ double red[256];
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[slot] = red[0];
+}
+
+// out[0] = max_i |M[i][i]|, i < n
+__global__ __launch_bounds__(256) void max_diag_kernel(const double *M, int ld, int n, double *out, int slot) {
+    __shared__ double red[256];
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s = fmax(s, fabs(M[(long long)i * ld + i]));
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[slot] = red[0];
+}
+
+__global__ void add_diag_kernel(double *M, int ld, int n, double lambda) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) M[(long long)i * ld + i] += lambda;
+}
+
+// out[slot] = sum_i x[i] * (lambda * x[i] + b[i])   (OptimizationAlgorithmLevenberg::computeScale)
+__global__ __launch_bounds__(256) void lm_scale_kernel(const double *x, const double *b, int n, double lambda, double *out, int slot) {
+    __shared__ double red[256];
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i] * (lambda * x[i] + b[i]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[slot] = red[0];
+}
+
+// One block step of L y = rhs (lower, forward). Workgroup 0 stores y_j = L_jj^-1 rhs_j; workgroup g >= 1
+// updates rhs_{j+g} -= L[j+g, j] y_j. Every workgroup recomputes y_j (a 64 x 64 product) itself.
+__global__ __launch_bounds__(64) void trsv_forward_step(const double *L, int ld, const double *Linv_all, double *rhs, double *sol, int j) {
+    __shared__ double xj[TB];
+    const int lane = threadIdx.x, g = blockIdx.x;
+    const double *Li = Linv_all + (long long)j * TB * TB;
+    double s = 0;
+    for (int c = 0; c <= lane; c++) s += Li[lane * TB + c] * rhs[j * TB + c];
+    xj[lane] = s;
+    __syncthreads();
+    if (g == 0) { sol[j * TB + lane] = s; return; }
+    const double *row = L + (long long)((j + g) * TB + lane) * ld + (long long)j * TB;
+    double u = 0;
+#pragma unroll 8
+    for (int c = 0; c < TB; c++) u += row[c] * xj[c];
+    rhs[(j + g) * TB + lane] -= u;
+}
+
+// One block step of L^T x = rhs (backward). Workgroup 0 stores x_j = L_jj^-T rhs_j; workgroup g >= 1
+// updates rhs_{g-1} -= L[j, g-1]^T x_j for the blocks above.
+__global__ __launch_bounds__(64) void trsv_backward_step(const double *L, int ld, const double *Linv_all, double *rhs, double *sol, int j) {
+    __shared__ double xj[TB];
+    const int lane = threadIdx.x, g = blockIdx.x;
+    const double *Li = Linv_all + (long long)j * TB * TB;
+    double s = 0;
+    for (int r = lane; r < TB; r++) s += Li[r * TB + lane] * rhs[j * TB + r];
+    xj[lane] = s;
+    __syncthreads();
+    if (g == 0) { sol[j * TB + lane] = s; return; }
+    const int i = g - 1;
+    const double *blk = L + (long long)j * TB * ld + (long long)i * TB;   // L[j-block rows][i-block cols]
+    double u = 0;
+#pragma unroll 8
+    for (int r = 0; r < TB; r++) u += blk[(long long)r * ld + lane] * xj[r];
+    rhs[i * TB + lane] -= u;
+}
+
+// VertexSE2 / VertexSE3 oplus with the solution vector; mode 0: apply, 1: save poses, 2: restore poses
+template <int D>
+__global__ void pose_update_kernel(double *arena, const int64_t *vpo, const int32_t *pos, int nv, const double *x, double *backup, int mode) {
+    constexpr int PS = (D == 6) ? 7 : 3;
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv || pos[v] < 0) return;
+    double *p = arena + vpo[v];
+    if (mode == 1) { for (int a = 0; a < PS; a++) backup[(long long)v * PS + a] = p[a]; return; }
+    if (mode == 2) { for (int a = 0; a < PS; a++) p[a] = backup[(long long)v * PS + a]; return; }
+    const double *dx = x + pos[v];
+    if (D == 3) {
+        p[0] += dx[0]; p[1] += dx[1]; p[2] = normalize_theta(p[2] + dx[2]);
+    } else {
+        // X <- X * fromVectorMQT(dx), kept as translation + unit quaternion
+        double X[kIso], Dl[kIso], R[9], q[4];
+        iso_from_tq(p, X);
+        iso_from_mqt(dx, Dl);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) R[i * 3 + k] = X[i * 3] * Dl[k] + X[i * 3 + 1] * Dl[3 + k] + X[i * 3 + 2] * Dl[6 + k];
+            p[i] = X[9 + i] + X[i * 3] * Dl[9] + X[i * 3 + 1] * Dl[10] + X[i * 3 + 2] * Dl[11];
+        }
+        R_to_quat(R, q);
+        p[3] = q[0]; p[4] = q[1]; p[5] = q[2]; p[6] = q[3];
+    }
 }
 
 // estimateDifference (src/graph_wrapper_g2o.cpp:550-575): one lane per kept vertex
@@ -491,11 +655,11 @@ int stage_graph(const spg::DenseGraphIn &in, GraphBufs &gb, hipStream_t s) {
         int q = in.er[e].nv, dq = in.D * q;
         if (q <= 0 || in.er[e].len < dq || (in.er[e].len - dq) % dq) return SPG_EINVAL;
         awoff[e] = aw_total;
-        aw_total += (int64_t)(in.er[e].len - dq);
+        aw_total += (int64_t)(in.er[e].len - dq) + (in.er[e].len - dq) / dq;   // A_e (r x dq) + weighted error (r)
         gb.max_q = std::max(gb.max_q, q);
         gb.has_glc = true;
     }
-    if ((size_t)gb.max_q * 2 * in.D * in.D * sizeof(double) > 60000) return SPG_ECAPACITY;   // LDS staging of one GLC edge's Jacobians
+    if ((size_t)gb.max_q * (2 * in.D * in.D + in.D) * sizeof(double) > 60000) return SPG_ECAPACITY;   // LDS staging of one GLC edge's Jacobians
     int rc;
     if ((rc = upload(gb.pos, in.pos, (size_t)in.nv, s))) return rc;
     if ((rc = upload(gb.vpo, in.vpo, (size_t)in.nv, s))) return rc;
@@ -512,12 +676,12 @@ int stage_graph(const spg::DenseGraphIn &in, GraphBufs &gb, hipStream_t s) {
 }
 
 template <int D>
-void launch_assemble(const GraphBufs &gb, double *M, int ld, hipStream_t s) {
+void launch_assemble(const GraphBufs &gb, double *M, int ld, hipStream_t s, double *bvec = nullptr) {
     if (gb.has_glc) {
-        size_t sh = (size_t)gb.max_q * 2 * D * D * sizeof(double);
+        size_t sh = (size_t)gb.max_q * (2 * D * D + D) * sizeof(double);
         hipLaunchKernelGGL((glc_weighted_jacobian_kernel<D>), dim3(gb.dev.ne), dim3(64), sh, s, gb.dev);
     }
-    hipLaunchKernelGGL((dense_assemble_kernel<D>), dim3(gb.dev.nv), dim3(64), 0, s, gb.dev, M, ld);
+    hipLaunchKernelGGL((dense_assemble_kernel<D>), dim3(gb.dev.nv), dim3(64), 0, s, gb.dev, M, ld, bvec);
 }
 
 void launch_tiles(const TileOp &op, hipStream_t s) {
@@ -698,6 +862,138 @@ int hip_dense_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &ot
         terms[1] = innerprod; terms[2] = mahal; terms[3] = logdetx; terms[4] = logdety; terms[5] = n_keep;
         if (seconds) *seconds = 1e-3 * ms;
     }
+done:
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+}
+
+// GraphWrapperG2O::optimize (src/graph_wrapper_g2o.cpp:250-269) = g2o Levenberg-Marquardt with one
+// vertex fixed, dense on the device. in.pos orders the free vertices by id (no padding between them),
+// n = D * (free vertices). The poses are updated in place in the arena. LM control flow as in g2o's
+// OptimizationAlgorithmLevenberg (an un-vendored dependency of the reference, restated from its
+// published algorithm): lambda_0 = 1e-5 max|diag H|; per iteration up to 10 trials of
+// (H + lambda I) x = b with gain ratio rho = (chi2 - chi2') / (x.(lambda x + b) + 1e-3); good step:
+// lambda *= clamp(1 - (2 rho - 1)^3, 1/3, 2/3), ni = 2; bad step: lambda *= ni, ni *= 2, estimates
+// restored; stop after 10 failed trials, rho == 0 or a non-finite lambda. The host sees four scalars
+// per trial.
+int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iterations, double *stats, double *seconds,
+                       char *err, size_t errlen) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = 0;
+    const int D = in.D, PS = (D == 6) ? 7 : 3;
+    const int N = round_up(std::max(n, 1)), nt = N / TB;
+    GraphBufs gb;
+    DevBuf H, A, linv, linv_all, bad, b, rhs, sol, chi, scal, backup;
+    double h_s[4] = {0, 0, 0, 0};
+    int h_bad = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0;
+    double lambda = 0, ni = 2, chi_first = 0, chi_last = 0;
+    int it = 0, trials = 0;
+    if (hipMalloc(&H.p, (size_t)N * N * 8) != hipSuccess || hipMalloc(&A.p, (size_t)N * N * 8) != hipSuccess) {
+        snprintf(err, errlen, "hipMalloc of two %d x %d matrices failed", N, N);
+        return SPG_ENOMEM;
+    }
+    HIPCHK(hipMalloc(&linv.p, TB * TB * 8));
+    HIPCHK(hipMalloc(&linv_all.p, (size_t)nt * TB * TB * 8));
+    HIPCHK(hipMalloc(&bad.p, sizeof(int)));
+    HIPCHK(hipMalloc(&b.p, (size_t)N * 8));
+    HIPCHK(hipMalloc(&rhs.p, (size_t)N * 8));
+    HIPCHK(hipMalloc(&sol.p, (size_t)N * 8));
+    HIPCHK(hipMalloc(&chi.p, (size_t)std::max(in.ne, 1) * 8));
+    HIPCHK(hipMalloc(&scal.p, 4 * 8));
+    HIPCHK(hipMalloc(&backup.p, (size_t)std::max(in.nv, 1) * PS * 8));
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    if ((rc = stage_graph(in, gb, s))) { snprintf(err, errlen, "staging the graph for the optimiser failed (%d)", rc); goto done; }
+    HIPCHK(hipEventRecord(e0, s));
+    {
+        double *arena = (double *)const_cast<void *>(in.dev_arena);
+        auto poses = [&](int mode) {
+            if (D == 6) hipLaunchKernelGGL((pose_update_kernel<6>), dim3((in.nv + 63) / 64), dim3(64), 0, s, arena, gb.dev.vpo, gb.dev.pos, in.nv, (const double *)sol.p, (double *)backup.p, mode);
+            else hipLaunchKernelGGL((pose_update_kernel<3>), dim3((in.nv + 63) / 64), dim3(64), 0, s, arena, gb.dev.vpo, gb.dev.pos, in.nv, (const double *)sol.p, (double *)backup.p, mode);
+        };
+        // chi2 of the current estimates into scal[slot] (the GLC kernel refreshes the weighted errors)
+        auto chi2_into = [&](int slot, bool refresh_glc) {
+            if (refresh_glc && gb.has_glc) {
+                size_t sh = (size_t)gb.max_q * (2 * D * D + D) * sizeof(double);
+                if (D == 6) hipLaunchKernelGGL((glc_weighted_jacobian_kernel<6>), dim3(in.ne), dim3(64), sh, s, gb.dev);
+                else hipLaunchKernelGGL((glc_weighted_jacobian_kernel<3>), dim3(in.ne), dim3(64), sh, s, gb.dev);
+            }
+            if (in.ne > 0) {
+                if (D == 6) hipLaunchKernelGGL((edge_chi2_kernel<6>), dim3((in.ne + 63) / 64), dim3(64), 0, s, gb.dev, (double *)chi.p);
+                else hipLaunchKernelGGL((edge_chi2_kernel<3>), dim3((in.ne + 63) / 64), dim3(64), 0, s, gb.dev, (double *)chi.p);
+            }
+            hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, (const double *)chi.p, in.ne, (double *)scal.p, slot);
+        };
+        bool terminate = false;
+        for (; it < iterations && !terminate; it++) {
+            // buildSystem: H, b and chi2 at the current estimates
+            HIPCHK(hipMemsetAsync(H.p, 0, (size_t)N * N * 8, s));
+            HIPCHK(hipMemsetAsync(b.p, 0, (size_t)N * 8, s));
+            if (D == 6) launch_assemble<6>(gb, (double *)H.p, N, s, (double *)b.p);
+            else launch_assemble<3>(gb, (double *)H.p, N, s, (double *)b.p);
+            if (N > n) hipLaunchKernelGGL(pad_identity_kernel, dim3((N - n + 255) / 256), dim3(256), 0, s, (double *)H.p, N, n, N);
+            chi2_into(0, false);
+            hipLaunchKernelGGL(max_diag_kernel, dim3(1), dim3(256), 0, s, (const double *)H.p, N, n, (double *)scal.p, 1);
+            HIPCHK(hipMemcpyAsync(h_s, scal.p, 2 * 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            double currentChi = h_s[0];
+            if (it == 0) { chi_first = currentChi; lambda = 1e-5 * h_s[1]; ni = 2; }
+            chi_last = currentChi;
+            double rho = 0;
+            int qmax = 0;
+            bool lambda_ok = true;
+            do {
+                poses(1);                                                        // push()
+                HIPCHK(hipMemcpyAsync(A.p, H.p, (size_t)N * N * 8, hipMemcpyDeviceToDevice, s));
+                hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (double *)A.p, N, n, lambda);
+                HIPCHK(hipMemsetAsync(bad.p, 0, sizeof(int), s));
+                potrf_lower((double *)A.p, N, (double *)linv.p, (int *)bad.p, s);
+                hipLaunchKernelGGL(diag_potrf_kernel, dim3(nt), dim3(64), 0, s, (double *)A.p, N, (double *)linv_all.p, (int *)bad.p, 0);
+                HIPCHK(hipMemcpyAsync(rhs.p, b.p, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+                for (int j = 0; j < nt; j++)
+                    hipLaunchKernelGGL(trsv_forward_step, dim3(nt - j), dim3(64), 0, s, (const double *)A.p, N, (const double *)linv_all.p, (double *)rhs.p, (double *)sol.p, j);
+                HIPCHK(hipMemcpyAsync(rhs.p, sol.p, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+                for (int j = nt - 1; j >= 0; j--)
+                    hipLaunchKernelGGL(trsv_backward_step, dim3(j + 1), dim3(64), 0, s, (const double *)A.p, N, (const double *)linv_all.p, (double *)rhs.p, (double *)sol.p, j);
+                HIPCHK(hipMemcpyAsync(&h_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                const bool ok2 = h_bad == 0;
+                if (!ok2) HIPCHK(hipMemsetAsync(sol.p, 0, (size_t)N * 8, s));   // x = 0: the trial is rejected below
+                poses(0);                                                        // update(x)
+                chi2_into(2, true);
+                hipLaunchKernelGGL(lm_scale_kernel, dim3(1), dim3(256), 0, s, (const double *)sol.p, (const double *)b.p, n, lambda, (double *)scal.p, 3);
+                HIPCHK(hipMemcpyAsync(h_s, scal.p, 4 * 8, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                double tempChi = ok2 ? h_s[2] : std::numeric_limits<double>::max();
+                rho = (currentChi - tempChi) / (h_s[3] + 1e-3);
+                trials++;
+                if (rho > 0 && std::isfinite(tempChi)) {
+                    double alpha = 1.0 - std::pow(2 * rho - 1, 3);
+                    alpha = std::min(alpha, 2.0 / 3.0);
+                    lambda *= std::max(1.0 / 3.0, alpha);
+                    ni = 2;
+                    currentChi = tempChi;
+                    chi_last = tempChi;
+                } else {
+                    lambda *= ni;
+                    ni *= 2;
+                    poses(2);                                                    // pop()
+                    if (!std::isfinite(lambda)) { lambda_ok = false; break; }
+                }
+                qmax++;
+            } while (rho < 0 && qmax < 10);
+            if (qmax == 10 || rho == 0 || !lambda_ok) terminate = true;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    stats[0] = it; stats[1] = trials; stats[2] = chi_first; stats[3] = chi_last; stats[4] = lambda;
+    if (seconds) *seconds = 1e-3 * ms;
 done:
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);

@@ -1741,3 +1741,38 @@ extern "C" int spg_graph_kullback_leibler(spg_graph *base, spg_graph *other, int
     out->logdety = terms[4]; out->n = (int64_t)terms[5]; out->n_marginalized = n_marg; out->device_seconds = secs;
     return 0;
 }
+
+// ================================================================================= optimize() (8f.1)
+extern "C" int spg_graph_optimize(spg_graph *g, int iterations, int32_t fixed_id, spg_optimize_stats *out) {
+    if (!g || g->active || iterations < 0) return SPG_EINVAL;
+    spg_ctx *ctx = g->ctx;
+    if (!ctx->is_hip) return set_err(ctx, SPG_ESTATE, "spg_graph_optimize needs the HIP backend");
+    std::vector<int32_t> order = live_vertices_by_id(g);
+    int fixed = resolve_fixed(g, order, fixed_id);
+    if (fixed < 0) return set_err(ctx, SPG_EINVAL, "spg_graph_optimize: the fixed vertex is not in the graph");
+    const int64_t n = (int64_t)g->d * ((int64_t)order.size() - 1);
+    if (n <= 0) return set_err(ctx, SPG_EINVAL, "spg_graph_optimize: nothing to optimise");
+    if (n > 32000) return set_err(ctx, SPG_ECAPACITY, "spg_graph_optimize: dense formulation limited to 32k variables (2 x 8 GB)");
+    if (int rc = sync_device(g)) return rc;
+    if (int rc = ctx->be.synchronize(ctx->be.user)) return rc;
+    DenseStage st;
+    st.pos.assign(g->vid.size(), -1);
+    int p = 0;
+    for (int32_t v : order) if (v != fixed) { st.pos[v] = p; p += g->d; }
+    build_dense_stage(g, st);
+    double stats[5] = {0, 0, 0, 0, 0}, secs = 0;
+    ctx->err[0] = 0;
+    int rc = spg::hip_dense_optimize(spg::hip_backend_stream(&ctx->be), st.in, (int)n, iterations, stats, &secs, ctx->err, sizeof ctx->err);
+    // the estimates changed on the device: refresh the host mirror's copies
+    if (int rc2 = sync_host(g)) return rc2;
+    for (int32_t v : order) {
+        if (int rc2 = ctx->be.download(ctx->be.user, g->host.data() + g->vpose[v], (char *)g->dev + g->vpose[v] * 8, g->ps)) return rc2;
+    }
+    if (rc) return rc;
+    if (out) {
+        out->iterations = (int32_t)stats[0]; out->trials = (int32_t)stats[1];
+        out->chi2_initial = stats[2]; out->chi2_final = stats[3]; out->lambda_final = stats[4]; out->device_seconds = secs;
+        out->n = n;
+    }
+    return 0;
+}

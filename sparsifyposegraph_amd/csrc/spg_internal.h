@@ -33,4 +33,7 @@ int hip_dense_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &ot
                   const int64_t *kept_vpo_base, const int64_t *kept_vpo_other, double *terms, double *seconds,
                   char *err, size_t errlen);
 
+int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iterations, double *stats, double *seconds,
+                       char *err, size_t errlen);
+
 }  // namespace spg

@@ -148,6 +148,14 @@ class GraphWrapperHIP:
                                                _p(meas, C.c_double), _p(info, C.c_double)), self.ctx.h, "computeSubstituteEdge")
         return f.value, t.value, meas, info
 
+    def optimize(self, iterations=50, fixed_id=-1):
+        """GraphWrapperG2O::optimize (src/graph_wrapper_g2o.cpp:250-269): g2o Levenberg-Marquardt with
+        the first vertex fixed, dense on the device. Returns the stats dict."""
+        st = abi.OptimizeStats()
+        check(self.L.spg_graph_optimize(self.h, int(iterations), int(fixed_id), C.byref(st)), self.ctx.h, "optimize")
+        self.last_optimize_stats = st.asdict()
+        return self.last_optimize_stats
+
     def information(self, fixed_id=-1):
         """GraphWrapperG2O::information (src/graph_wrapper_g2o.cpp:351-358): dense Gauss-Newton
         information at the stored estimates, all vertices but the fixed one (default: smallest id)."""

@@ -46,6 +46,10 @@ def lib():
         L.spgref_graph_information.restype = C.c_int64
         L.spgref_graph_information.argtypes = [C.c_void_p, C.c_int32, f64p, C.c_int64]
         L.spgref_graph_kullback_leibler.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, f64p]
+        L.spgref_graph_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int32, f64p]
+        L.spgref_graph_chi2.restype = C.c_double
+        L.spgref_graph_chi2.argtypes = [C.c_void_p, C.c_int32]
+        L.spgref_graph_set_estimate.argtypes = [C.c_void_p, C.c_int, f64p]
         L.spgref_spd_logdet.restype = C.c_double
         L.spg_run_round.argtypes = [C.c_void_p, C.POINTER(abi.RoundDesc)]
         L.spg_run_round_mt.argtypes = [C.c_void_p, C.POINTER(abi.RoundDesc)]
@@ -95,6 +99,20 @@ class OracleGraph:
 
     def seconds(self):
         return self.L.spgref_graph_last_seconds(self.h)
+
+    def optimize(self, iterations=50, fixed_id=0):
+        """GraphWrapperG2O::optimize (src/graph_wrapper_g2o.cpp:250-269): g2o LM restated, dense."""
+        st = np.zeros(5)
+        rc = self.L.spgref_graph_optimize(self.h, int(iterations), int(fixed_id), _p(st, C.c_double))
+        assert rc == 0, rc
+        return dict(zip(("iterations", "trials", "chi2_initial", "chi2_final", "lambda_final"), st))
+
+    def chi2(self, fixed_id=0):
+        return float(self.L.spgref_graph_chi2(self.h, int(fixed_id)))
+
+    def set_estimate(self, vid, pose):
+        pose = np.ascontiguousarray(pose, np.float64)
+        return self.L.spgref_graph_set_estimate(self.h, int(vid), _p(pose, C.c_double))
 
     def information(self, fixed_id):
         """other->information() (src/graph_wrapper_g2o.cpp:351-358), fixed vertex dropped."""
