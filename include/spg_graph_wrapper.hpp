@@ -213,6 +213,13 @@ public:
         }
         return out;
     }
+    // GraphWrapperG2O::optimize (src/graph_wrapper_g2o.cpp:250-269): first vertex fixed, g2o LM x 50, dense on
+    // the device (graphs of up to 32k scalar variables; larger ones need the sparse solver of SURVEY.md 8f.1)
+    spg_optimize_stats optimize(int iterations = 50) {
+        spg_optimize_stats st;
+        check(spg_graph_optimize(_g, iterations, -1, &st), "optimize");
+        return st;
+    }
     // GraphWrapperG2O::information (src/graph_wrapper_g2o.cpp:351-358): n x n row-major, first vertex fixed
     std::vector<double> information() {
         int64_t n = spg_graph_information(_g, -1, nullptr, 0);
