@@ -113,3 +113,33 @@ def test_device_lm_matches_oracle(case, n, glc, hip_ctx):
         assert np.abs(ph - po).max() <= 1e-7 * max(1.0, np.abs(po).max())
         print(f"{case} sparsified={sparsify}: chi2 {got['chi2_initial']:.6g} -> {got['chi2_final']:.6g} in {got['iterations']} it / "
               f"{got['trials']} solves (oracle {ref['iterations']:.0f}/{ref['trials']:.0f}), {got['device_seconds'] * 1e3:.1f} ms")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,glc", [("intel_nfr_tree_sp3", False), ("manhattan_glc_tree", True)])
+def test_reference_pipeline_end_to_end(case, glc, hip_ctx):
+    """The reference's evaluation flow (src/evaluate.cpp:103-195 with globalDecimate) on the device:
+    optimise the baseline, marginalise, optimise the sparsified graph, global KLD against the baseline —
+    every step through the product, checked against the same flow through the oracle."""
+    from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    sub, w, opts = _perturbed(case, 220, sigma=0.02)
+    fid = int(sub["ids"][0])
+    base_h, base_o = GraphWrapperHIP.from_dict(sub, ctx=hip_ctx), oracle_lib.OracleGraph.from_dict(sub)
+    base_h.optimize(50, fid)
+    base_o.optimize(50, fid)
+    # the sparsified graph starts from the optimised baseline (clonePortion + marginalize in the reference)
+    ids, ph = base_h.vertices()
+    _, po = base_o.vertices()
+    gh, go = dict(sub), dict(sub)
+    gh["poses"], go["poses"] = ph, po
+    sp_h, sp_o = GraphWrapperHIP.from_dict(gh, ctx=hip_ctx, useGLC=glc), oracle_lib.OracleGraph.from_dict(go)
+    st = sp_h.marginalizeNoOptimize(w, opts)
+    assert st["n_bad_status"] == 0 and sp_o.marginalize(w, opts) == 0
+    oh, oo = sp_h.optimize(50, fid), sp_o.optimize(50, fid)
+    assert oh["chi2_final"] == pytest.approx(oo["chi2_final"], rel=1e-6, abs=1e-10)
+    kld = base_h.kullbackLeibler(sp_h, fid)
+    ref = base_o.kullback_leibler(sp_o, fid)
+    assert kld == pytest.approx(ref["kld"], rel=1e-6, abs=1e-6 * ref["n"])
+    assert base_h.last_kld_terms["mahalanobis"] == pytest.approx(ref["mahalanobis"], rel=1e-5, abs=1e-9)
+    print(f"{case}: baseline chi2 {base_h.last_optimize_stats['chi2_final']:.6g}, sparsified chi2 {oh['chi2_final']:.6g}, "
+          f"global KLD {kld:.9g} (oracle {ref['kld']:.9g}), mahalanobis {ref['mahalanobis']:.3g}")
