@@ -469,12 +469,16 @@ extern "C" int spg_graph_load_g2o(spg_ctx *ctx, const char *path, spg_graph **ou
     if (!f) return set_err(ctx, SPG_EIO, "cannot open %s", path);
     struct V { int id; double p[7]; };
     struct E { int a, b; double r[28]; };
+    struct GE { std::vector<int32_t> ids; int r = 0, n = 0; std::vector<double> meas, W; };
     std::vector<V> vs;
     std::vector<E> es;
+    std::vector<GE> ges;
     int d = 0;
-    std::vector<char> line(1 << 16);
-    while (fgets(line.data(), (int)line.size(), f)) {
-        char *s = line.data();
+    char *lbuf = nullptr;   // getline: a Dense GLC edge is one line of r*n numbers, far beyond any fixed buffer
+    size_t lcap = 0;
+    bool bad_glc = false;
+    while (getline(&lbuf, &lcap, f) >= 0) {
+        char *s = lbuf;
         while (*s == ' ' || *s == '\t') s++;
         char tag[64];
         int adv = 0;
@@ -516,15 +520,70 @@ extern "C" int spg_graph_load_g2o(spg_ctx *ctx, const char *path, spg_graph **ou
             if (!readi(e.a) || !readi(e.b) || !readn(e.r, 28)) continue;
             normalize_quat(e.r + 3);
             es.push_back(e);
+        } else if (!strcmp(tag, "GLC_EDGE")) {
+            // GLCEdge::read (src/glc_edge.cpp:65-93) behind g2o's hyper-edge prefix "id id ... ||":
+            // <reparam tag> r n, measurement (n), W (r x n, row-major), information (upper triangle, r x r)
+            GE ge;
+            for (;;) {
+                while (*s == ' ' || *s == '\t') s++;
+                if (s[0] == '|' && s[1] == '|') { s += 2; break; }
+                int id;
+                if (!readi(id)) { bad_glc = true; break; }
+                ge.ids.push_back(id);
+            }
+            char rtag[64];
+            int adv2 = 0;
+            if (bad_glc || sscanf(s, "%63s%n", rtag, &adv2) != 1) { bad_glc = true; continue; }
+            s += adv2;
+            if (!readi(ge.r) || !readi(ge.n) || ge.r < 1 || ge.n < 1 || ge.ids.empty() || ge.n % (int)ge.ids.size()) { bad_glc = true; continue; }
+            ge.meas.resize(ge.n);
+            ge.W.resize((size_t)ge.r * ge.n);
+            std::vector<double> info((size_t)ge.r * (ge.r + 1) / 2);
+            if (!readn(ge.meas.data(), ge.n) || !readn(ge.W.data(), ge.r * ge.n) || !readn(info.data(), (int)info.size())) { bad_glc = true; continue; }
+            // the reference writes information = I_r; a general SPD information is folded into W (W <- L^T W, Omega = L L^T)
+            bool ident = true;
+            {
+                size_t p2 = 0;
+                for (int i = 0; i < ge.r; i++) for (int j = i; j < ge.r; j++) { ident &= (info[p2] == (i == j ? 1.0 : 0.0)); p2++; }
+            }
+            if (!ident) {
+                std::vector<double> Lm((size_t)ge.r * ge.r, 0.0);
+                size_t p2 = 0;
+                for (int i = 0; i < ge.r; i++) for (int j = i; j < ge.r; j++) { Lm[(size_t)j * ge.r + i] = info[p2]; p2++; }   // lower triangle
+                bool pd = true;
+                for (int j = 0; j < ge.r && pd; j++) {
+                    double dj = Lm[(size_t)j * ge.r + j];
+                    for (int k = 0; k < j; k++) dj -= Lm[(size_t)j * ge.r + k] * Lm[(size_t)j * ge.r + k];
+                    if (!(dj > 0)) { pd = false; break; }
+                    double l = std::sqrt(dj);
+                    Lm[(size_t)j * ge.r + j] = l;
+                    for (int i = j + 1; i < ge.r; i++) {
+                        double sacc = Lm[(size_t)i * ge.r + j];
+                        for (int k = 0; k < j; k++) sacc -= Lm[(size_t)i * ge.r + k] * Lm[(size_t)j * ge.r + k];
+                        Lm[(size_t)i * ge.r + j] = sacc / l;
+                    }
+                }
+                if (!pd) { bad_glc = true; continue; }
+                std::vector<double> W2((size_t)ge.r * ge.n, 0.0);
+                for (int i = 0; i < ge.r; i++) for (int k = i; k < ge.r; k++) for (int c = 0; c < ge.n; c++) W2[(size_t)i * ge.n + c] += Lm[(size_t)k * ge.r + i] * ge.W[(size_t)k * ge.n + c];
+                ge.W.swap(W2);
+            }
+            ges.push_back(std::move(ge));
         }
     }
+    free(lbuf);
     fclose(f);
+    if (bad_glc) return set_err(ctx, SPG_EIO, "malformed GLC_EDGE record in %s", path);
     if (!d) return set_err(ctx, SPG_EIO, "no SE2/SE3 vertices in %s", path);
     std::stable_sort(vs.begin(), vs.end(), [](const V &a, const V &b) { return a.id < b.id; });
     spg_graph *g;
     if (int rc = spg_graph_create(ctx, d, &g)) return rc;
     for (auto &v : vs) if (int rc = spg_graph_add_vertex(g, v.id, v.p)) { spg_graph_destroy(g); return rc; }
     for (auto &e : es) if (int rc = spg_graph_add_edge(g, e.a, e.b, e.r, e.r + g->ps)) { spg_graph_destroy(g); return rc; }
+    for (auto &ge : ges) {
+        if (ge.n != d * (int)ge.ids.size()) { spg_graph_destroy(g); return set_err(ctx, SPG_EIO, "GLC_EDGE dimension does not match its vertices in %s", path); }
+        if (int rc = spg_graph_add_glc_edge(g, (int)ge.ids.size(), ge.ids.data(), ge.r, ge.meas.data(), ge.W.data())) { spg_graph_destroy(g); return rc; }
+    }
     *out = g;
     return 0;
 }

@@ -67,6 +67,37 @@ def test_g2o_roundtrip_native_vs_python(d, tmp_path):
         bar = t.index("||")
         q, r, n = bar - 1, int(t[bar + 2]), int(t[bar + 3])
         assert n == 3 * q and len(t) == bar + 4 + n + r * n + r * (r + 1) // 2
+    # what was written loads back as the same graph, GLC_EDGE records included (GLCEdge::read, src/glc_edge.cpp:65-93)
+    back = GraphWrapperHIP.load(out, ctx=ictx, useGLC=(d == 3))
+    assert back.numVertices() == hg.numVertices() and back.numEdges() == hg.numEdges()
+    util.compare_edge_sets(d, hg.edges(), back.edges(), rtol=1e-15)
+    i1, p1 = hg.vertices()
+    i2, p2 = back.vertices()
+    assert np.array_equal(i1, i2) and np.allclose(p1, p2, rtol=0, atol=1e-15)
+
+
+def test_glc_edge_with_general_information_is_folded_into_w(tmp_path):
+    """A GLC_EDGE whose information is not the identity (the reference always writes I_r) loads as the
+    equivalent edge W' = L^T W with Omega = L L^T, i.e. the same W^T Omega W."""
+    ictx = oracle_lib.injected_context()
+    rng = np.random.default_rng(2)
+    W = rng.standard_normal((2, 6))
+    A = rng.standard_normal((2, 2))
+    Om = A @ A.T + np.eye(2)
+    meas = rng.standard_normal(6)
+    path = str(tmp_path / "g.g2o")
+    with open(path, "w") as f:
+        f.write("VERTEX_SE2 0 0 0 0\nVERTEX_SE2 1 1 0 0.1\nVERTEX_SE2 2 2 0.5 0.2\n")
+        f.write("EDGE_SE2 0 1 1 0 0.1 10 0 0 10 0 5\n")
+        nums = list(meas) + list(W.reshape(-1)) + [Om[0, 0], Om[0, 1], Om[1, 1]]
+        f.write("GLC_EDGE 1 2 || GLC_REPARAM_SE2_ISAM 2 6 " + " ".join(repr(float(x)) for x in nums) + "\n")
+    hg = GraphWrapperHIP.load(path, ctx=ictx, useGLC=True)
+    e = hg.edges()
+    k = int(np.nonzero(e["kind"] == abi.EDGE_GLC)[0][0])
+    rec = e["data"][e["data_off"][k]:e["data_off"][k + 1]]
+    assert np.allclose(rec[:6], meas, rtol=0, atol=1e-15)
+    W2 = rec[6:].reshape(2, 6)
+    assert np.allclose(W2.T @ W2, W.T @ Om @ W, rtol=1e-13, atol=1e-13)
 
 
 def test_reference_dataset_loads_if_present():
