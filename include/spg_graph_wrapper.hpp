@@ -17,8 +17,8 @@
 //                                                            inverse / vector()
 //
 // Eigen is not a dependency: information matrices travel as row-major std::vector<double> (d*d).
-// optimize() (g2o Levenberg-Marquardt, src/graph_wrapper_g2o.cpp:250-269) is outside the
-// accelerated path: marginalize() here equals the reference's marginalizeNoOptimize().
+// optimize() (g2o Levenberg-Marquardt, src/graph_wrapper_g2o.cpp:250-269) runs dense on the device for
+// graphs of up to 32k scalar variables; marginalize() = marginalizeNoOptimize() + optimize() as in the reference.
 // Errors: the reference asserts/aborts; this façade throws std::runtime_error with the library's
 // message. Thread model: one GraphWrapperHIP per host thread (as the reference's one VertexRemover
 // per call, src/vertex_remover.h:92-98).
@@ -185,8 +185,12 @@ public:
         std::vector<int32_t> w(which.begin(), which.end());
         check(spg_graph_marginalize(_g, w.data(), (int)w.size(), &so, &_stats), "marginalize");
     }
-    // GraphWrapper::marginalize without the trailing optimize() (LM is outside the accelerated path)
-    void marginalize(const std::vector<int> &which, const SparsityOptions &o) override { marginalizeNoOptimize(which, o); }
+    // GraphWrapperG2O::marginalize (src/graph_wrapper_g2o.cpp:455-463): marginalizeNoOptimize + optimize().
+    // The dense optimiser takes graphs of up to 32k scalar variables: beyond that call marginalizeNoOptimize.
+    void marginalize(const std::vector<int> &which, const SparsityOptions &o) override {
+        marginalizeNoOptimize(which, o);
+        optimize();
+    }
     void write(const char *fname) override { check(spg_graph_write_g2o(_g, fname), "write"); }
     void setEstimate(int vertexid, const IsometryXd &est) override { check(spg_graph_set_estimate(_g, vertexid, est.vector().data()), "setEstimate"); }
 

@@ -64,7 +64,7 @@ def clusterDecimate(last, endvert, opts):
 
 class GraphWrapperHIP:
     """GraphWrapperG2O(verbose, useGLC) (src/graph_wrapper_g2o.cpp:102) with the marginalisation
-    path on the MI355X. optimize() (LM) is outside the accelerated path and not provided."""
+    path, optimize() and the global KLD on the MI355X."""
 
     def __init__(self, ctx=None, pose_dim=6, useGLC=False, _handle=None):
         self.L = load()
@@ -134,9 +134,11 @@ class GraphWrapperHIP:
         return self.last_stats
 
     def marginalize(self, which, options, flags=0):
-        """src/graph_wrapper_g2o.cpp:455-463 without the trailing optimize(): LM is outside the
-        accelerated path."""
-        return self.marginalizeNoOptimize(which, options, flags)
+        """src/graph_wrapper_g2o.cpp:455-463: marginalizeNoOptimize followed by optimize(). The dense
+        optimiser takes graphs of up to 32k scalar variables; beyond that call marginalizeNoOptimize."""
+        st = self.marginalizeNoOptimize(which, options, flags)
+        self.optimize()
+        return st
 
     def computeSubstituteEdge(self, marginalized, maxid, frm, to):
         """src/compute_substitute_edge.cpp:13-96 -> (from, to, meas, info_upper)"""

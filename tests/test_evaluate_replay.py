@@ -1,0 +1,69 @@
+"""Replay harness (src/evaluate.cpp:100-195 with online / cluster decimation,
+computeSubstituteEdge and optimize()): the same loop (sparsifyposegraph_amd/evaluate.py) driven once
+through the product on the GPU and once through the oracle; the KLD series must agree."""
+import numpy as np
+import pytest
+
+from sparsifyposegraph_amd import abi
+from sparsifyposegraph_amd.evaluate import EvaluateInfo, evaluate
+from sparsifyposegraph_amd.graph import (DecimateOptions, GraphWrapperHIP, SparsityOptions, clusterDecimate,
+                                         globalDecimate, onlineDecimate)
+from tests import oracle_lib, util
+
+
+class OracleWrapper:
+    """GraphWrapper-shaped adapter over the oracle's sequential graph (test infrastructure)."""
+
+    def __init__(self, d, use_glc):
+        self.g = oracle_lib.OracleGraph(d)
+        self.d, self.use_glc = d, use_glc
+
+    def addVertex(self, i, pose):
+        p = np.ascontiguousarray(pose, np.float64)
+        self.g.L.spgref_graph_add_vertex(self.g.h, int(i), oracle_lib._p(p, oracle_lib.C.c_double))
+
+    def addEdge(self, frm, to, meas, info):
+        rec = np.concatenate([np.asarray(meas, float), np.asarray(info, float)[np.triu_indices(self.d)]])
+        assert self.g.add_edge(abi.EDGE_BINARY, [frm, to], rec) == 0
+
+    def optimize(self):
+        return self.g.optimize(50, 0)
+
+    def marginalize(self, which, sopts):
+        o = sopts.to_abi(self.d, self.use_glc)
+        assert self.g.marginalize(np.asarray(which, np.int32), o) == 0
+        self.g.optimize(50, 0)
+
+    def kullbackLeibler(self, other):
+        return self.g.kullback_leibler(other.g, 0)["kld"]
+
+
+def test_evaluate_loop_on_the_oracle_alone():
+    """CPU: the loop runs end to end (global decimation, no substitute edges needed) and the KLD of a
+    Dense-free Tree sparsification is positive at the end."""
+    g, which, opts, *_ = util.load_golden("intel_nfr_tree_sp3")
+    sub, _ = util.prefix_graph(g, which, 40)
+    info = EvaluateInfo(globalDecimate, DecimateOptions(2), SparsityOptions(SparsityOptions.Tree, linPoint=SparsityOptions.Global), "nfr", kldPeriod=13)
+    series, inc, base = evaluate(sub, info, lambda glc: OracleWrapper(3, glc), substitute_source=None)
+    assert [i for i, _ in series] == [13, 26, 39]
+    assert series[0][1] == pytest.approx(0.0, abs=1e-9) and series[-1][1] > 0   # nothing removed before the last vertex
+    assert len(inc.g.vertices()[0]) == 40 - len([i for i in range(4, 40) if i % 2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("profile,alg", [("online", "nfr"), ("cluster", "nfr"), ("online", "glc")])
+def test_replay_matches_oracle(profile, alg, hip_ctx):
+    g, which, opts, *_ = util.load_golden("manhattan_nfr_tree" if alg == "nfr" else "manhattan_glc_tree")
+    sub, _ = util.prefix_graph(g, which, 70)
+    dec = {"online": (onlineDecimate, DecimateOptions(2)), "cluster": (clusterDecimate, DecimateOptions(2, 10))}[profile]
+    so = SparsityOptions(SparsityOptions.Tree, linPoint=SparsityOptions.Global)
+    info = EvaluateInfo(dec[0], dec[1], so, alg, kldPeriod=10)
+    full = GraphWrapperHIP.from_dict(sub, ctx=hip_ctx)     # computeSubstituteEdge walks the full graph (host side)
+    got, inc_h, base_h = evaluate(sub, info, lambda glc: GraphWrapperHIP(ctx=hip_ctx, pose_dim=3, useGLC=glc), full)
+    ref, inc_o, base_o = evaluate(sub, info, lambda glc: OracleWrapper(3, glc), full)
+    assert [i for i, _ in got] == [i for i, _ in ref]
+    for (i, a), (_, b) in zip(got, ref):
+        assert a == pytest.approx(b, rel=1e-5, abs=1e-6), (i, a, b)
+    assert got[-1][1] > -1e-9    # (online removal of a just-added chain vertex is exact: KLD 0 is legitimate)
+    assert np.array_equal(inc_h.vertices()[0], inc_o.g.vertices()[0])
+    print(profile, alg, [(i, round(k, 6)) for i, k in got])
