@@ -249,6 +249,12 @@ typedef struct {
     double device_seconds;
 } spg_optimize_stats;
 int spg_graph_optimize(spg_graph *g, int iterations, int32_t fixed_id, spg_optimize_stats *out);
+/* The same with a set of vertices held fixed at their current estimates — the inner step of
+ * GraphWrapperG2O::chi2(other) (src/graph_wrapper_g2o.cpp:503-529): fix other's vertices at other's
+ * estimates, optimise the rest, read chi2. n_fixed may cover every vertex (chi2 is evaluated, nothing moves). */
+int spg_graph_optimize_fixed(spg_graph *g, int iterations, const int32_t *fixed_ids, int n_fixed, spg_optimize_stats *out);
+/* _so->chi2(): sum of e^T Omega e over all edges at the current estimates (src/graph_wrapper_g2o.cpp:501,519) */
+int spg_graph_chi2(spg_graph *g, double *chi2);
 
 /* ---- round-stepping form of the same call, for multi-GPU sharding ---------------------------
  * All ranks hold a replica and run the same deterministic scheduler; rank r computes its slice of

@@ -458,11 +458,11 @@ namespace {
 struct LinSys { Mat H; std::vector<double> b; double chi2 = 0; std::vector<int> ids; };
 
 // chi2, H = sum J^T Omega J and b = -sum J^T Omega e over the live edges, fixed vertex dropped
-LinSys build_system(RGraph *g, int fixed_id, bool want_H) {
+LinSys build_system(RGraph *g, const std::set<int> &fixed, bool want_H) {
     int d = g->d, ps = pose_stride(d);
     LinSys S;
     std::map<int, int> loc;
-    for (auto &kv : g->pose) if (kv.first != fixed_id) { loc[kv.first] = (int)S.ids.size(); S.ids.push_back(kv.first); }
+    for (auto &kv : g->pose) if (!fixed.count(kv.first)) { loc[kv.first] = (int)S.ids.size(); S.ids.push_back(kv.first); }
     int n = d * (int)S.ids.size();
     if (want_H) S.H = Mat(n, n);
     S.b.assign(n, 0.0);
@@ -555,8 +555,7 @@ void apply_update(RGraph *g, const std::vector<int> &ids, const std::vector<doub
 }  // namespace
 
 // stats: iterations done, LM trials, chi2 before, chi2 after, final lambda
-int spgref_graph_optimize(void *h, int iterations, int32_t fixed_id, double *stats) {
-    RGraph *g = (RGraph *)h;
+static int optimize_fixed(RGraph *g, int iterations, const std::set<int> &fixed_id, double *stats) {
     double lambda = 0, ni = 2;
     int it = 0, trials = 0;
     double chi_first = NAN, chi_last = NAN;
@@ -612,7 +611,16 @@ int spgref_graph_optimize(void *h, int iterations, int32_t fixed_id, double *sta
     return 0;
 }
 
-double spgref_graph_chi2(void *h, int32_t fixed_id) { return build_system((RGraph *)h, fixed_id, false).chi2; }
+int spgref_graph_optimize(void *h, int iterations, int32_t fixed_id, double *stats) {
+    return optimize_fixed((RGraph *)h, iterations, std::set<int>{fixed_id}, stats);
+}
+// optimize() with several vertices held fixed: the inner step of GraphWrapperG2O::chi2(other)
+// (src/graph_wrapper_g2o.cpp:503-529)
+int spgref_graph_optimize_fixed(void *h, int iterations, const int32_t *fixed_ids, int n_fixed, double *stats) {
+    return optimize_fixed((RGraph *)h, iterations, std::set<int>(fixed_ids, fixed_ids + n_fixed), stats);
+}
+
+double spgref_graph_chi2(void *h, int32_t fixed_id) { return build_system((RGraph *)h, std::set<int>{fixed_id}, false).chi2; }
 
 int spgref_graph_set_estimate(void *h, int id, const double *pose) {
     RGraph *g = (RGraph *)h;

@@ -948,7 +948,7 @@ int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iteratio
             do {
                 poses(1);                                                        // push()
                 HIPCHK(hipMemcpyAsync(A.p, H.p, (size_t)N * N * 8, hipMemcpyDeviceToDevice, s));
-                hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (double *)A.p, N, n, lambda);
+                if (n > 0) hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (double *)A.p, N, n, lambda);
                 HIPCHK(hipMemsetAsync(bad.p, 0, sizeof(int), s));
                 potrf_lower((double *)A.p, N, (double *)linv.p, (int *)bad.p, s);
                 hipLaunchKernelGGL(diag_potrf_kernel, dim3(nt), dim3(64), 0, s, (double *)A.p, N, (double *)linv_all.p, (int *)bad.p, 0);

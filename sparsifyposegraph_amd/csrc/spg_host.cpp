@@ -1802,22 +1802,20 @@ extern "C" int spg_graph_kullback_leibler(spg_graph *base, spg_graph *other, int
 }
 
 // ================================================================================= optimize() (8f.1)
-extern "C" int spg_graph_optimize(spg_graph *g, int iterations, int32_t fixed_id, spg_optimize_stats *out) {
-    if (!g || g->active || iterations < 0) return SPG_EINVAL;
+static int optimize_with_fixed(spg_graph *g, int iterations, const std::vector<int32_t> &fixed_vertices, spg_optimize_stats *out) {
     spg_ctx *ctx = g->ctx;
-    if (!ctx->is_hip) return set_err(ctx, SPG_ESTATE, "spg_graph_optimize needs the HIP backend");
     std::vector<int32_t> order = live_vertices_by_id(g);
-    int fixed = resolve_fixed(g, order, fixed_id);
-    if (fixed < 0) return set_err(ctx, SPG_EINVAL, "spg_graph_optimize: the fixed vertex is not in the graph");
-    const int64_t n = (int64_t)g->d * ((int64_t)order.size() - 1);
-    if (n <= 0) return set_err(ctx, SPG_EINVAL, "spg_graph_optimize: nothing to optimise");
+    std::vector<uint8_t> is_fixed(g->vid.size(), 0);
+    for (int32_t v : fixed_vertices) is_fixed[v] = 1;
+    int64_t n = 0;
+    for (int32_t v : order) if (!is_fixed[v]) n += g->d;
     if (n > 32000) return set_err(ctx, SPG_ECAPACITY, "spg_graph_optimize: dense formulation limited to 32k variables (2 x 8 GB)");
     if (int rc = sync_device(g)) return rc;
     if (int rc = ctx->be.synchronize(ctx->be.user)) return rc;
     DenseStage st;
     st.pos.assign(g->vid.size(), -1);
     int p = 0;
-    for (int32_t v : order) if (v != fixed) { st.pos[v] = p; p += g->d; }
+    for (int32_t v : order) if (!is_fixed[v]) { st.pos[v] = p; p += g->d; }
     build_dense_stage(g, st);
     double stats[5] = {0, 0, 0, 0, 0}, secs = 0;
     ctx->err[0] = 0;
@@ -1825,6 +1823,7 @@ extern "C" int spg_graph_optimize(spg_graph *g, int iterations, int32_t fixed_id
     // the estimates changed on the device: refresh the host mirror's copies
     if (int rc2 = sync_host(g)) return rc2;
     for (int32_t v : order) {
+        if (is_fixed[v]) continue;
         if (int rc2 = ctx->be.download(ctx->be.user, g->host.data() + g->vpose[v], (char *)g->dev + g->vpose[v] * 8, g->ps)) return rc2;
     }
     if (rc) return rc;
@@ -1833,5 +1832,40 @@ extern "C" int spg_graph_optimize(spg_graph *g, int iterations, int32_t fixed_id
         out->chi2_initial = stats[2]; out->chi2_final = stats[3]; out->lambda_final = stats[4]; out->device_seconds = secs;
         out->n = n;
     }
+    return 0;
+}
+
+extern "C" int spg_graph_optimize(spg_graph *g, int iterations, int32_t fixed_id, spg_optimize_stats *out) {
+    if (!g || g->active || iterations < 0) return SPG_EINVAL;
+    if (!g->ctx->is_hip) return set_err(g->ctx, SPG_ESTATE, "spg_graph_optimize needs the HIP backend");
+    std::vector<int32_t> order = live_vertices_by_id(g);
+    int fixed = resolve_fixed(g, order, fixed_id);
+    if (fixed < 0) return set_err(g->ctx, SPG_EINVAL, "spg_graph_optimize: the fixed vertex is not in the graph");
+    if (order.size() < 2) return set_err(g->ctx, SPG_EINVAL, "spg_graph_optimize: nothing to optimise");
+    return optimize_with_fixed(g, iterations, std::vector<int32_t>{(int32_t)fixed}, out);
+}
+
+extern "C" int spg_graph_optimize_fixed(spg_graph *g, int iterations, const int32_t *fixed_ids, int n_fixed, spg_optimize_stats *out) {
+    if (!g || g->active || iterations < 0 || n_fixed < 0 || (n_fixed > 0 && !fixed_ids)) return SPG_EINVAL;
+    if (!g->ctx->is_hip) return set_err(g->ctx, SPG_ESTATE, "spg_graph_optimize_fixed needs the HIP backend");
+    std::vector<int32_t> fx;
+    for (int i = 0; i < n_fixed; i++) {
+        auto it = g->vidx.find(fixed_ids[i]);
+        if (it == g->vidx.end() || !g->valive[it->second]) return set_err(g->ctx, SPG_EINVAL, "spg_graph_optimize_fixed: a fixed vertex is not in the graph");
+        fx.push_back(it->second);
+    }
+    return optimize_with_fixed(g, iterations, fx, out);
+}
+
+extern "C" int spg_graph_chi2(spg_graph *g, double *chi2) {
+    if (!g || !chi2 || g->active) return SPG_EINVAL;
+    // zero iterations with every vertex fixed: the optimiser's entry evaluates chi2 and returns
+    std::vector<int32_t> all;
+    for (size_t i = 0; i < g->vid.size(); i++) if (g->valive[i]) all.push_back((int32_t)i);
+    if (!g->ctx->is_hip) return set_err(g->ctx, SPG_ESTATE, "spg_graph_chi2 needs the HIP backend");
+    spg_optimize_stats st{};
+    int rc = optimize_with_fixed(g, 1, all, &st);
+    if (rc) return rc;
+    *chi2 = st.chi2_initial;
     return 0;
 }

@@ -17,12 +17,13 @@ class EvaluateInfo:
     """The fields of the reference's EvaluateInfo that the loop reads (src/evaluate.h:14-40)."""
     NFR, GLC, NoSparsification = "nfr", "glc", "none"
 
-    def __init__(self, decimate, decimateOptions, sparsityOptions, algorithm="nfr", kldPeriod=10):
+    def __init__(self, decimate, decimateOptions, sparsityOptions, algorithm="nfr", kldPeriod=10, useChi2=False):
         self.decimate = decimate
         self.decimateOptions = decimateOptions
         self.sparsityOptions = sparsityOptions
         self.algorithm = algorithm
         self.kldPeriod = int(kldPeriod)
+        self.useChi2 = bool(useChi2)   # record baseline.chi2(incremental) - baseline.chi2() instead of the KLD
 
 
 def _info_matrix(d, upper):
@@ -85,7 +86,9 @@ def evaluate(g, info, make_graph, substitute_source):
         if i % info.kldPeriod == 0 or i == last:
             if not sparsify:
                 baseline.optimize()
-                series.append((i, 0.0))
+                series.append((i, float(baseline.chi2()) if info.useChi2 else 0.0))
+            elif info.useChi2:
+                series.append((i, float(baseline.chi2(incremental) - baseline.chi2())))
             else:
                 series.append((i, float(baseline.kullbackLeibler(incremental))))
     return series, incremental, baseline

@@ -158,6 +158,31 @@ class GraphWrapperHIP:
         self.last_optimize_stats = st.asdict()
         return self.last_optimize_stats
 
+    def chi2(self, other=None, iterations=50):
+        """GraphWrapperG2O::chi2() / chi2(other) (src/graph_wrapper_g2o.cpp:501-529). Without `other`: the
+        chi2 of the current estimates. With it: this graph's vertices that also exist in `other` are set
+        to other's estimates and held fixed, the rest is optimised, chi2 is read and the estimates are
+        restored (push / pop in the reference)."""
+        if other is None:
+            v = C.c_double()
+            check(self.L.spg_graph_chi2(self.h, C.byref(v)), self.ctx.h, "chi2")
+            return v.value
+        ids, poses = self.vertices()
+        mine = {int(i) for i in ids}
+        oids, oposes = other.vertices()
+        fixed = [int(i) for i in oids if int(i) in mine]
+        for i, p in zip(oids, oposes):
+            if int(i) in mine:
+                self.setEstimate(int(i), p)
+        fx = np.ascontiguousarray(sorted(set(fixed) | {int(ids[0])}), np.int32)
+        st = abi.OptimizeStats()
+        try:
+            check(self.L.spg_graph_optimize_fixed(self.h, int(iterations), _p(fx, C.c_int32), len(fx), C.byref(st)), self.ctx.h, "chi2(other)")
+        finally:
+            for i, p in zip(ids, poses):
+                self.setEstimate(int(i), p)
+        return st.chi2_final
+
     def information(self, fixed_id=-1):
         """GraphWrapperG2O::information (src/graph_wrapper_g2o.cpp:351-358): dense Gauss-Newton
         information at the stored estimates, all vertices but the fixed one (default: smallest id)."""

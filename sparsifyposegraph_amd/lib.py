@@ -54,6 +54,8 @@ SYMBOLS = {
     "spg_graph_information": (C.c_int64, [C.c_void_p, C.c_int32, _f64p, C.c_int64]),
     "spg_graph_kullback_leibler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(abi.KldTerms)]),
     "spg_graph_optimize": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.POINTER(abi.OptimizeStats)]),
+    "spg_graph_optimize_fixed": (C.c_int, [C.c_void_p, C.c_int, _i32p, C.c_int, C.POINTER(abi.OptimizeStats)]),
+    "spg_graph_chi2": (C.c_int, [C.c_void_p, _f64p]),
     "spg_graph_marginalize_begin": (C.c_int, [C.c_void_p, _i32p, C.c_int, C.POINTER(abi.Options), C.c_int, C.c_int]),
     "spg_graph_set_shard_threshold": (C.c_int, [C.c_void_p, C.c_int]),
     "spg_graph_round_prepare": (C.c_int, [C.c_void_p, C.POINTER(abi.RoundInfo)]),

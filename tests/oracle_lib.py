@@ -47,6 +47,7 @@ def lib():
         L.spgref_graph_information.argtypes = [C.c_void_p, C.c_int32, f64p, C.c_int64]
         L.spgref_graph_kullback_leibler.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, f64p]
         L.spgref_graph_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int32, f64p]
+        L.spgref_graph_optimize_fixed.argtypes = [C.c_void_p, C.c_int, i32p, C.c_int, f64p]
         L.spgref_graph_chi2.restype = C.c_double
         L.spgref_graph_chi2.argtypes = [C.c_void_p, C.c_int32]
         L.spgref_graph_set_estimate.argtypes = [C.c_void_p, C.c_int, f64p]
@@ -105,6 +106,12 @@ class OracleGraph:
         st = np.zeros(5)
         rc = self.L.spgref_graph_optimize(self.h, int(iterations), int(fixed_id), _p(st, C.c_double))
         assert rc == 0, rc
+        return dict(zip(("iterations", "trials", "chi2_initial", "chi2_final", "lambda_final"), st))
+
+    def optimize_fixed(self, fixed_ids, iterations=50):
+        fx = np.ascontiguousarray(fixed_ids, np.int32)
+        st = np.zeros(5)
+        assert self.L.spgref_graph_optimize_fixed(self.h, int(iterations), _p(fx, C.c_int32), len(fx), _p(st, C.c_double)) == 0
         return dict(zip(("iterations", "trials", "chi2_initial", "chi2_final", "lambda_final"), st))
 
     def chi2(self, fixed_id=0):

@@ -37,6 +37,18 @@ class OracleWrapper:
     def kullbackLeibler(self, other):
         return self.g.kullback_leibler(other.g, 0)["kld"]
 
+    def chi2(self, other=None):
+        if other is None:
+            return self.g.chi2(0)
+        saved = dict(zip(*self.g.vertices()))
+        ids_o, poses_o = other.g.vertices()
+        for i, p in zip(ids_o, poses_o):
+            self.g.set_estimate(int(i), p)
+        out = self.g.optimize_fixed(sorted({int(i) for i in ids_o} | {0}), 50)["chi2_final"]
+        for i, p in saved.items():
+            self.g.set_estimate(int(i), p)
+        return out
+
 
 def test_evaluate_loop_on_the_oracle_alone():
     """CPU: the loop runs end to end (global decimation, no substitute edges needed) and the KLD of a
@@ -51,13 +63,15 @@ def test_evaluate_loop_on_the_oracle_alone():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("profile,alg", [("online", "nfr"), ("cluster", "nfr"), ("online", "glc")])
+@pytest.mark.parametrize("profile,alg", [("online", "nfr"), ("cluster", "nfr"), ("online", "glc"), ("cluster", "nfr-chi2")])
 def test_replay_matches_oracle(profile, alg, hip_ctx):
+    use_chi2 = alg.endswith("-chi2")
+    alg = alg.split("-")[0]
     g, which, opts, *_ = util.load_golden("manhattan_nfr_tree" if alg == "nfr" else "manhattan_glc_tree")
     sub, _ = util.prefix_graph(g, which, 70)
     dec = {"online": (onlineDecimate, DecimateOptions(2)), "cluster": (clusterDecimate, DecimateOptions(2, 10))}[profile]
     so = SparsityOptions(SparsityOptions.Tree, linPoint=SparsityOptions.Global)
-    info = EvaluateInfo(dec[0], dec[1], so, alg, kldPeriod=10)
+    info = EvaluateInfo(dec[0], dec[1], so, alg, kldPeriod=10, useChi2=use_chi2)
     full = GraphWrapperHIP.from_dict(sub, ctx=hip_ctx)     # computeSubstituteEdge walks the full graph (host side)
     got, inc_h, base_h = evaluate(sub, info, lambda glc: GraphWrapperHIP(ctx=hip_ctx, pose_dim=3, useGLC=glc), full)
     ref, inc_o, base_o = evaluate(sub, info, lambda glc: OracleWrapper(3, glc), full)

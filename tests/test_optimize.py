@@ -143,3 +143,37 @@ def test_reference_pipeline_end_to_end(case, glc, hip_ctx):
     assert base_h.last_kld_terms["mahalanobis"] == pytest.approx(ref["mahalanobis"], rel=1e-5, abs=1e-9)
     print(f"{case}: baseline chi2 {base_h.last_optimize_stats['chi2_final']:.6g}, sparsified chi2 {oh['chi2_final']:.6g}, "
           f"global KLD {kld:.9g} (oracle {ref['kld']:.9g}), mahalanobis {ref['mahalanobis']:.3g}")
+
+
+@pytest.mark.gpu
+def test_chi2_and_chi2_other_match_oracle(hip_ctx):
+    """GraphWrapperG2O::chi2() and chi2(other) (src/graph_wrapper_g2o.cpp:501-529): the baseline's
+    chi2 with the sparsified graph's vertices imposed and held fixed, the marginalised ones re-optimised;
+    the baseline's own estimates are restored afterwards."""
+    from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    sub, w, opts = _perturbed("manhattan_nfr_tree", 160, sigma=0.02)
+    fid = int(sub["ids"][0])
+    base_h, base_o = GraphWrapperHIP.from_dict(sub, ctx=hip_ctx), oracle_lib.OracleGraph.from_dict(sub)
+    assert base_h.chi2() == pytest.approx(base_o.chi2(fid), rel=1e-12)
+    base_h.optimize(50, fid)
+    base_o.optimize(50, fid)
+    sp_h, sp_o = GraphWrapperHIP.from_dict(sub, ctx=hip_ctx), oracle_lib.OracleGraph.from_dict(sub)
+    sp_h.marginalizeNoOptimize(w, opts)
+    assert sp_o.marginalize(w, opts) == 0
+    sp_h.optimize(50, fid)
+    sp_o.optimize(50, fid)
+    before = base_h.vertices()[1].copy()
+    got = base_h.chi2(sp_h)
+    assert np.array_equal(base_h.vertices()[1], before)          # pop(): estimates restored
+    # the same through the oracle
+    ids_o, poses_o = sp_o.vertices()
+    saved = dict(zip(*base_o.vertices()))
+    for i, p in zip(ids_o, poses_o):
+        base_o.set_estimate(int(i), p)
+    ref = base_o.optimize_fixed(sorted({int(i) for i in ids_o} | {fid}), 50)["chi2_final"]
+    for i, p in saved.items():
+        base_o.set_estimate(int(i), p)
+    assert got == pytest.approx(ref, rel=1e-6)
+    delta = got - base_h.chi2()                                 # the reference's "delta chi2" measure
+    assert delta > -1e-6
+    print(f"chi2(other) = {got:.9g} (oracle {ref:.9g}); delta chi2 = {delta:.6g}")
