@@ -64,6 +64,57 @@ struct HostMirror {
     }
 };
 
+// Small vector of trivially copyable T with N inline slots sharing their storage with the heap pointer of
+// the spilled form: sizeof == 8 + N*sizeof(T), so per-vertex adjacency (N = 6 edge ids) and owner lists
+// (N = 3 references) are one dense 32-byte record each instead of a vector header plus a heap chunk — the
+// scheduler and the graph update are bound by the cache misses on exactly these lists.
+template <class T, int N>
+struct InlVec {
+    int32_t n = 0, cap = N;
+    union { T inl[N]; T *ptr; };
+    InlVec() {}
+    InlVec(const InlVec &o) : n(o.n), cap(o.cap) {
+        if (cap > N) { ptr = (T *)malloc(sizeof(T) * (size_t)cap); memcpy(ptr, o.ptr, sizeof(T) * (size_t)n); }
+        else memcpy(inl, o.inl, sizeof inl);
+    }
+    InlVec(InlVec &&o) noexcept : n(o.n), cap(o.cap) {
+        if (cap > N) { ptr = o.ptr; o.cap = N; o.n = 0; }
+        else memcpy(inl, o.inl, sizeof inl);
+    }
+    InlVec &operator=(InlVec o) noexcept {
+        if (cap > N) free(ptr);
+        n = o.n; cap = o.cap;
+        if (cap > N) { ptr = o.ptr; o.cap = N; o.n = 0; }
+        else memcpy(inl, o.inl, sizeof inl);
+        return *this;
+    }
+    ~InlVec() { if (cap > N) free(ptr); }
+    T *data() { return cap > N ? ptr : inl; }
+    const T *data() const { return cap > N ? ptr : inl; }
+    T *begin() { return data(); }
+    T *end() { return data() + n; }
+    const T *begin() const { return data(); }
+    const T *end() const { return data() + n; }
+    size_t size() const { return (size_t)n; }
+    bool empty() const { return n == 0; }
+    T &operator[](size_t i) { return data()[i]; }
+    const T &operator[](size_t i) const { return data()[i]; }
+    T &back() { return data()[n - 1]; }
+    void pop_back() { n--; }
+    void clear() { n = 0; }
+    void push_back(const T &v) {
+        if (n == cap) {
+            int32_t nc = cap * 2;
+            T *p = (T *)malloc(sizeof(T) * (size_t)nc);
+            if (!p) abort();
+            memcpy(p, data(), sizeof(T) * (size_t)n);
+            if (cap > N) free(ptr);
+            ptr = p; cap = nc;
+        }
+        data()[n++] = v;
+    }
+};
+
 struct spg_ctx {
     spg_backend be{};
     bool is_hip = false;
@@ -121,7 +172,7 @@ struct spg_graph {
     std::unordered_map<int32_t, int32_t> vidx;
     std::vector<uint8_t> valive;
     std::vector<int64_t> vpose;
-    std::vector<std::vector<int32_t>> adj;
+    std::vector<InlVec<int32_t, 6>> adj;
     std::vector<GEdge> edges;
     std::vector<int32_t> everts;
     int n_live_v = 0, n_live_e = 0;
@@ -160,7 +211,7 @@ struct spg_graph {
     // scheduler scratch
     std::vector<int32_t> vstamp, estamp;
     int32_t stamp = 0;
-    std::vector<std::vector<OwnRef>> vowners;
+    std::vector<InlVec<OwnRef, 3>> vowners;
     std::vector<int32_t> ocnt;
     std::vector<int32_t> lidx;
 };
