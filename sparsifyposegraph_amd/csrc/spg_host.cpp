@@ -122,9 +122,15 @@ struct spg_ctx {
     char err[768] = {0};
 };
 
+// 24 bytes; a pose-pose edge carries its two endpoints inline (vtx[0], vtx[1]) — the scheduler walks
+// edges by the million and would otherwise take a second cache miss per edge for the endpoint list;
+// an n-ary GLC edge keeps its vertices in spg_graph::everts at index vtx[0].
 struct GEdge {
-    int32_t kind, nv, vbeg, len;
     int64_t off;
+    int32_t len;
+    int32_t vtx[2];
+    int16_t nv;
+    int8_t kind;
     uint8_t alive;
 };
 
@@ -215,6 +221,10 @@ struct spg_graph {
     std::vector<int32_t> ocnt;
     std::vector<int32_t> lidx;
 };
+
+static inline const int32_t *edge_verts(const spg_graph *g, const GEdge &e) {
+    return e.nv == 2 ? e.vtx : g->everts.data() + e.vtx[0];
+}
 
 static int set_err(spg_ctx *c, int code, const char *fmt, const char *a = "") {
     if (c) snprintf(c->err, sizeof c->err, fmt, a);
@@ -382,9 +392,11 @@ extern "C" int spg_graph_add_vertex(spg_graph *g, int id, const double *pose) {
 
 static int add_edge_idx(spg_graph *g, int kind, int nv, const int32_t *vix, int64_t off, int32_t len) {
     GEdge e;
-    e.kind = kind; e.nv = nv; e.vbeg = (int32_t)g->everts.size(); e.len = len; e.off = off; e.alive = 1;
+    e.kind = (int8_t)kind; e.nv = (int16_t)nv; e.len = len; e.off = off; e.alive = 1;
+    if (nv == 2) { e.vtx[0] = vix[0]; e.vtx[1] = vix[1]; }
+    else { e.vtx[0] = (int32_t)g->everts.size(); e.vtx[1] = 0; }
     int32_t eid = (int32_t)g->edges.size();
-    for (int i = 0; i < nv; i++) g->everts.push_back(vix[i]);
+    if (nv != 2) for (int i = 0; i < nv; i++) g->everts.push_back(vix[i]);
     g->edges.push_back(e);
     for (int i = 0; i < nv; i++) {
         bool dup = false;
@@ -476,7 +488,7 @@ extern "C" int spg_graph_get_edges(spg_graph *g, int32_t *kind, int32_t *vert_of
     for (auto &e : g->edges) {
         if (!e.alive) continue;
         kind[ne] = e.kind;
-        for (int i = 0; i < e.nv; i++) vert_ids[nv++] = g->vid[g->everts[e.vbeg + i]];
+        for (int i = 0; i < e.nv; i++) vert_ids[nv++] = g->vid[edge_verts(g, e)[i]];
         memcpy(data + nd, g->host.data() + e.off, (size_t)e.len * 8);
         nd += e.len;
         ne++;
@@ -656,13 +668,13 @@ extern "C" int spg_graph_write_g2o(spg_graph *g, const char *path) {
     for (auto &e : g->edges) {
         if (!e.alive) continue;
         if (e.kind == SPG_EDGE_BINARY) {
-            fprintf(f, "%s %d %d", et, g->vid[g->everts[e.vbeg]], g->vid[g->everts[e.vbeg + 1]]);
+            fprintf(f, "%s %d %d", et, g->vid[edge_verts(g, e)[0]], g->vid[edge_verts(g, e)[1]]);
             for (int i = 0; i < e.len; i++) fprintf(f, " %.17g", g->host[e.off + i]);
         } else {
             // GLCEdge::write (src/glc_edge.cpp:95-119): "|| <reparam tag> r dq meas W info(upper of I_r)"
             int n = g->d * e.nv, r = (e.len - n) / n;
             fprintf(f, "GLC_EDGE");
-            for (int i = 0; i < e.nv; i++) fprintf(f, " %d", g->vid[g->everts[e.vbeg + i]]);
+            for (int i = 0; i < e.nv; i++) fprintf(f, " %d", g->vid[edge_verts(g, e)[i]]);
             fprintf(f, " || %s %d %d", g->d == 3 ? "GLC_REPARAM_SE2_ISAM" : "GLC_REPARAM_SE3", r, n);
             for (int i = 0; i < e.len; i++) fprintf(f, " %.17g", g->host[e.off + i]);
             for (int i = 0; i < r; i++) for (int j = i; j < r; j++) fprintf(f, " %d", i == j ? 1 : 0);
@@ -689,7 +701,7 @@ static void closed_neighbourhood(spg_graph *g, int32_t v, std::vector<int32_t> &
     for (int32_t eid : g->adj[v]) {
         const GEdge &e = g->edges[eid];
         for (int i = 0; i < e.nv; i++) {
-            int32_t u = g->everts[e.vbeg + i];
+            int32_t u = edge_verts(g, e)[i];
             if (g->vstamp[u] != g->stamp) { g->vstamp[u] = g->stamp; out.push_back(u); }
         }
     }
@@ -733,7 +745,7 @@ static void collect_edges(spg_graph *g, const int32_t *verts, int nverts, const 
             const GEdge &e = g->edges[eid];
             bool ok = true, hub = false;
             for (int i = 0; i < e.nv; i++) {
-                int32_t u = g->everts[e.vbeg + i];
+                int32_t u = edge_verts(g, e)[i];
                 if (g->vstamp[u] != st) { ok = false; break; }
                 if (!intra) for (int32_t c : centres) hub |= (c == u);
             }
@@ -913,7 +925,7 @@ static void schedule_round(spg_graph *g) {
                     for (int32_t eid : g->adj[c]) {
                         const GEdge &e = g->edges[eid];
                         for (int i = 0; i < e.nv; i++) {
-                            int32_t y = g->everts[e.vbeg + i];
+                            int32_t y = edge_verts(g, e)[i];
                             bool fresh = g->vstamp[y] != st;
                             addv(y);
                             if (fresh && g->in_set[y] && g->valive[y]) work.push_back(y);
@@ -1057,7 +1069,7 @@ static int prepare_scheduled(spg_graph *g, spg_round_info *info, double t0) {
                 if (e.kind == SPG_EDGE_GLC) scratch = std::max(scratch, e.len - d * e.nv + e.nv * 2 * d * d);
                 spg_edge_ref er;
                 er.off = e.off; er.len = e.len; er.kind = e.kind; er.vbegin = (int32_t)bt.h_ev.size(); er.nv = e.nv;
-                for (int i = 0; i < e.nv; i++) bt.h_ev.push_back(lidx[g->everts[e.vbeg + i]]);
+                for (int i = 0; i < e.nv; i++) bt.h_ev.push_back(lidx[edge_verts(g, e)[i]]);
                 bt.h_er.push_back(er);
             }
             new_edge_budget(o, d, k, bd.n_new_max, bd.n_new_vert_max, bd.new_len);
@@ -1241,7 +1253,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
             e.alive = 0;
             g->n_live_e--;
             for (int i = 0; i < e.nv; i++) {
-                auto &av = g->adj[g->everts[e.vbeg + i]];
+                auto &av = g->adj[edge_verts(g, e)[i]];
                 for (size_t j = 0; j < av.size(); j++) if (av[j] == eid) { av[j] = av.back(); av.pop_back(); break; }
             }
         }
@@ -1663,7 +1675,7 @@ extern "C" int spg_graph_substitute_edge(spg_graph *g, const int32_t *marginaliz
                 for (int32_t eid : g->adj[v]) {
                     const GEdge &e = g->edges[eid];
                     if (e.nv != 2) continue;
-                    int a = g->vid[g->everts[e.vbeg]], b = g->vid[g->everts[e.vbeg + 1]];
+                    int a = g->vid[edge_verts(g, e)[0]], b = g->vid[edge_verts(g, e)[1]];
                     int other = (a == r) ? b : a;
                     if (visited.count(other) == 0 && other <= maxid && other != 0) newFrontier.insert(other);
                 }
@@ -1686,7 +1698,7 @@ extern "C" int spg_graph_substitute_edge(spg_graph *g, const int32_t *marginaliz
         for (int32_t eid : es) {
             const GEdge &e = g->edges[eid];
             if (e.nv != 2 || e.kind != SPG_EDGE_BINARY) continue;
-            int a = g->vid[g->everts[e.vbeg]], b = g->vid[g->everts[e.vbeg + 1]];
+            int a = g->vid[edge_verts(g, e)[0]], b = g->vid[edge_verts(g, e)[1]];
             if (!(last.count(a) || last.count(b))) continue;
             const double *rec = g->host.data() + e.off;
             std::vector<double> info((size_t)d * d);
@@ -1739,7 +1751,7 @@ void build_dense_stage(spg_graph *g, DenseStage &st) {
         if (!ge.alive) continue;
         remap[e] = (int32_t)st.er.size();
         st.er.push_back({ge.off, ge.len, ge.kind, (int32_t)st.ev.size(), ge.nv});
-        for (int i = 0; i < ge.nv; i++) st.ev.push_back(g->everts[ge.vbeg + i]);
+        for (int i = 0; i < ge.nv; i++) st.ev.push_back(edge_verts(g, ge)[i]);
     }
     st.rowptr.assign((size_t)nv + 1, 0);
     for (int v = 0; v < nv; v++) {
