@@ -171,6 +171,8 @@ struct Batch {
     std::vector<std::pair<int32_t, int64_t>> kld_pending;
 };
 
+struct OwnRefT { int32_t oid; uint32_t gen; };
+
 struct spg_graph {
     spg_ctx *ctx = nullptr;
     int d = 0, ps = 0, rec = 0;
@@ -178,7 +180,9 @@ struct spg_graph {
     std::unordered_map<int32_t, int32_t> vidx;
     std::vector<uint8_t> valive;
     std::vector<int64_t> vpose;
-    std::vector<InlVec<int32_t, 6>> adj;
+    // per vertex, one cache line: adjacency (live edge ids) + the scheduler's owner list
+    struct alignas(64) VRec { InlVec<int32_t, 6> adj; InlVec<struct OwnRefT, 3> own; };
+    std::vector<VRec> vr;
     std::vector<GEdge> edges;
     std::vector<int32_t> everts;
     int n_live_v = 0, n_live_e = 0;
@@ -203,7 +207,7 @@ struct spg_graph {
     // Blanket owners persist from the pass that selected them until their batch commits; entries die
     // lazily: freeing an owner bumps its generation and stale references are dropped when next seen.
     struct Owner { int32_t batch, off, len; uint32_t gen; };   // batch >= 0: bt[batch].rb_verts[off, off+len); -1: Dpool
-    struct OwnRef { int32_t oid; uint32_t gen; };
+    using OwnRef = OwnRefT;
     std::vector<Owner> owners;
     std::vector<int32_t> owner_free, transient;       // free ids; deferred-vertex owners of the last pass
     std::vector<int32_t> Dpool;                       // sets of the deferred-vertex owners, flat
@@ -217,7 +221,6 @@ struct spg_graph {
     // scheduler scratch
     std::vector<int32_t> vstamp, estamp;
     int32_t stamp = 0;
-    std::vector<InlVec<OwnRef, 3>> vowners;
     std::vector<int32_t> ocnt;
     std::vector<int32_t> lidx;
 };
@@ -384,7 +387,7 @@ extern "C" int spg_graph_add_vertex(spg_graph *g, int id, const double *pose) {
     g->vid.push_back(id);
     g->vidx[id] = idx;
     g->valive.push_back(1);
-    g->adj.emplace_back();
+    g->vr.emplace_back();
     g->vpose.push_back(arena_push(g, pose, g->ps));
     g->n_live_v++;
     return 0;
@@ -401,7 +404,7 @@ static int add_edge_idx(spg_graph *g, int kind, int nv, const int32_t *vix, int6
     for (int i = 0; i < nv; i++) {
         bool dup = false;
         for (int j = 0; j < i; j++) dup |= (vix[j] == vix[i]);
-        if (!dup) g->adj[vix[i]].push_back(eid);
+        if (!dup) g->vr[vix[i]].adj.push_back(eid);
     }
     g->n_live_e++;
     return eid;
@@ -698,7 +701,7 @@ static void closed_neighbourhood(spg_graph *g, int32_t v, std::vector<int32_t> &
     out.clear();
     out.push_back(v);
     g->vstamp[v] = g->stamp;
-    for (int32_t eid : g->adj[v]) {
+    for (int32_t eid : g->vr[v].adj) {
         const GEdge &e = g->edges[eid];
         for (int i = 0; i < e.nv; i++) {
             int32_t u = edge_verts(g, e)[i];
@@ -739,7 +742,7 @@ static void collect_edges(spg_graph *g, const int32_t *verts, int nverts, const 
     out.clear();
     for (int vi_ = 0; vi_ < nverts; vi_++) {
         int32_t v = verts[vi_];
-        for (int32_t eid : g->adj[v]) {
+        for (int32_t eid : g->vr[v].adj) {
             if (g->estamp[eid] == st) continue;
             g->estamp[eid] = st;
             const GEdge &e = g->edges[eid];
@@ -811,7 +814,6 @@ static void schedule_round(spg_graph *g) {
     bt.rb.clear();
     bt.rb_verts.clear();
     bt.rb_edges.clear();
-    if (g->vowners.size() < g->vid.size()) g->vowners.resize(g->vid.size());
     // the deferred-vertex owners of the previous pass are void; blanket owners of batches still in
     // flight stay registered (their removals are not in the host graph yet, so nothing that fails to
     // commute with them may be selected now)
@@ -827,12 +829,12 @@ static void schedule_round(spg_graph *g) {
         int32_t oid = owner_acquire(g, batch, off, len);
         const uint32_t gen = g->owners[oid].gen;
         const int32_t *set = owner_set(g, g->owners[oid]);
-        for (int32_t i = 0; i < len; i++) g->vowners[set[i]].push_back({oid, gen});
+        for (int32_t i = 0; i < len; i++) g->vr[set[i]].own.push_back({oid, gen});
         return oid;
     };
     // live owners of x, dropping stale references on the way
     auto for_owners = [&](int32_t x, auto &&fn) {
-        auto &vo = g->vowners[x];
+        auto &vo = g->vr[x].own;
         for (size_t i = 0; i < vo.size();) {
             const spg_graph::OwnRef r = vo[i];
             if (g->owners[r.oid].gen != r.gen) { vo[i] = vo.back(); vo.pop_back(); continue; }
@@ -922,7 +924,7 @@ static void schedule_round(spg_graph *g) {
                 });
                 if (dense && c != v) {
                     // neighbourhood of an absorbed vertex (stamps are in use: gather without closed_neighbourhood)
-                    for (int32_t eid : g->adj[c]) {
+                    for (int32_t eid : g->vr[c].adj) {
                         const GEdge &e = g->edges[eid];
                         for (int i = 0; i < e.nv; i++) {
                             int32_t y = edge_verts(g, e)[i];
@@ -1253,7 +1255,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
             e.alive = 0;
             g->n_live_e--;
             for (int i = 0; i < e.nv; i++) {
-                auto &av = g->adj[edge_verts(g, e)[i]];
+                auto &av = g->vr[edge_verts(g, e)[i]].adj;
                 for (size_t j = 0; j < av.size(); j++) if (av[j] == eid) { av[j] = av.back(); av.pop_back(); break; }
             }
         }
@@ -1261,7 +1263,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
         for (int i = 0; i < r.n_remove; i++) {
             int32_t v = rverts[i];
             g->valive[v] = 0;
-            g->adj[v].clear();
+            g->vr[v].adj.clear();
             g->n_live_v--;
             g->stats.n_removed++;
         }
@@ -1672,7 +1674,7 @@ extern "C" int spg_graph_substitute_edge(spg_graph *g, const int32_t *marginaliz
                 int v = vix(r);
                 visited.insert(r);
                 if (v < 0) continue;
-                for (int32_t eid : g->adj[v]) {
+                for (int32_t eid : g->vr[v].adj) {
                     const GEdge &e = g->edges[eid];
                     if (e.nv != 2) continue;
                     int a = g->vid[edge_verts(g, e)[0]], b = g->vid[edge_verts(g, e)[1]];
@@ -1693,7 +1695,7 @@ extern "C" int spg_graph_substitute_edge(spg_graph *g, const int32_t *marginaliz
         frontiers.pop_back();
         int v = vix(reach);
         if (v < 0) return set_err(g->ctx, SPG_EINVAL, "substitute path broken");
-        std::vector<int32_t> es(g->adj[v].begin(), g->adj[v].end());
+        std::vector<int32_t> es(g->vr[v].adj.begin(), g->vr[v].adj.end());
         std::sort(es.begin(), es.end());
         for (int32_t eid : es) {
             const GEdge &e = g->edges[eid];
@@ -1757,7 +1759,7 @@ void build_dense_stage(spg_graph *g, DenseStage &st) {
     for (int v = 0; v < nv; v++) {
         if (g->valive[v]) {
             std::vector<int32_t> es;
-            for (int32_t e : g->adj[v]) if (remap[e] >= 0) es.push_back(remap[e]);
+            for (int32_t e : g->vr[v].adj) if (remap[e] >= 0) es.push_back(remap[e]);
             std::sort(es.begin(), es.end());
             es.erase(std::unique(es.begin(), es.end()), es.end());
             st.inc.insert(st.inc.end(), es.begin(), es.end());
