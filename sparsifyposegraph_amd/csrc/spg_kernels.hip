@@ -1136,7 +1136,9 @@ struct HipBackend {
         void *h_mail = nullptr, *d_mail = nullptr;   // pinned host mailbox the kernel writes out records into
         size_t c_mail = 0;
         void *h_stage = nullptr;                      // pinned host staging for the descriptor upload
+        void *d_stage = nullptr;                      // the same buffer in the device's address space
         size_t c_stage = 0;
+        bool busy = false;                            // work was queued on the stream since its last synchronisation
         std::vector<Timed> pending;
         // per slot, so that a submission thread working on one slot and the graph thread draining
         // another never share state
@@ -1165,6 +1167,7 @@ struct HipBackend {
         size_t nc = std::max(need, S.c_stage * 2);
         if (S.h_stage) { HIPCHK(hipStreamSynchronize(S.stream)); HIPCHK(hipHostFree(S.h_stage)); S.h_stage = nullptr; }
         HIPCHK(hipHostMalloc(&S.h_stage, nc, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer(&S.d_stage, S.h_stage, 0));
         S.c_stage = nc;
         return 0;
     }
@@ -1249,10 +1252,15 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o_blk = 0, o_vpo = o_blk + al(s_blk), o_er = o_vpo + al(s_vpo), o_ev = o_er + al(s_er), o_list = o_ev + al(s_ev);
     size_t tot = o_list + al(s_list);
-    HIPCHK(hipSetDevice(hb->device));
-    // the previous round's copy must have drained before the staging buffer is rewritten
-    HIPCHK(hipStreamSynchronize(S.stream));
+    {
+        int cur = -1;   // (a thread-local read; hipSetDevice costs a microsecond per launch)
+        if (hipGetDevice(&cur) != hipSuccess || cur != hb->device) HIPCHK(hipSetDevice(hb->device));
+    }
+    // the previous launch of this slot must have drained before its staging buffer is rewritten
+    // (already the case when the host has just harvested the slot's late results)
+    if (S.busy) { HIPCHK(hipStreamSynchronize(S.stream)); S.busy = false; }
     drain_profile(hb, S);
+    S.busy = true;
     if (int rc = hb->ensure_stage(S, tot)) return rc;
     if (int rc = hb->ensure(S, &S.d_desc, &S.c_desc, tot)) return rc;
     char *st = (char *)S.h_stage;
@@ -1271,9 +1279,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     static const int mapped_limit = [] { const char *e = getenv("SPG_MAPPED_DESC"); return e ? atoi(e) : 512; }();
     char *desc_base = (char *)S.d_desc;
     if ((long long)rd->count <= (long long)mapped_limit) {
-        void *dv = nullptr;
-        HIPCHK(hipHostGetDevicePointer(&dv, S.h_stage, 0));
-        desc_base = (char *)dv;
+        desc_base = (char *)S.d_stage;
     } else {
         HIPCHK(hipMemcpyAsync(S.d_desc, st, tot, hipMemcpyHostToDevice, S.stream));
     }
@@ -1374,6 +1380,7 @@ static int hip_sync(void *user) {
     char *err = hb->err;
     for (auto &S : hb->slots) {
         HIPCHK(hipStreamSynchronize(S.stream));
+        S.busy = false;
         drain_profile(hb, S);
     }
     return 0;
@@ -1383,6 +1390,7 @@ static int hip_sync_slot(void *user, int slot) {
     char *err = hb->err;
     HipBackend::Slot &S = hb->slots[slot & (HipBackend::NSLOT - 1)];
     HIPCHK(hipStreamSynchronize(S.stream));
+    S.busy = false;
     drain_profile(hb, S);
     return 0;
 }
