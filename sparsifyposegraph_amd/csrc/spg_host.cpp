@@ -223,6 +223,10 @@ struct spg_graph {
     int32_t stamp = 0;
     std::vector<int32_t> ocnt;
     std::vector<int32_t> lidx;
+    std::vector<int32_t> s_newpending, s_B, s_centres, s_Dv, s_tmp, s_work, s_seen, s_hit, s_vix;
+    std::vector<double> s_cost;
+    std::vector<int> s_first;
+    std::vector<int64_t> s_chunk_len;
 };
 
 static inline const int32_t *edge_verts(const spg_graph *g, const GEdge &e) {
@@ -821,8 +825,10 @@ static void schedule_round(spg_graph *g) {
     g->transient.clear();
     g->Dpool.clear();
     const int32_t my_batch = (int32_t)(&bt - g->bt);
-    std::vector<int32_t> newpending, B, centres, Dv, tmp, work, seen_owner;
-    std::vector<int32_t> hit;
+    // scratch that keeps its capacity between passes (a pass runs a thousand times per marginalisation)
+    std::vector<int32_t> &newpending = g->s_newpending, &B = g->s_B, &centres = g->s_centres, &Dv = g->s_Dv, &tmp = g->s_tmp,
+                         &work = g->s_work, &seen_owner = g->s_seen, &hit = g->s_hit;
+    newpending.clear();
     bool stop = false;
     size_t n_deferred = 0, consec = 0;
     auto reg = [&](int32_t batch, int32_t off, int32_t len) -> int32_t {
@@ -1021,7 +1027,8 @@ static int prepare_scheduled(spg_graph *g, spg_round_info *info, double t0) {
     bt.eff_rank = sharded ? g->rank : 0;
     const int d = g->d, nr = bt.eff_ranks;
     // ---- contiguous, cost-balanced slices (cost ~ n^3 + E d^3)
-    std::vector<double> cost(B);
+    std::vector<double> &cost = g->s_cost;
+    cost.assign(B, 0.0);
     double total = 0;
     for (int b = 0; b < B; b++) {
         RoundBlanket &r = bt.rb[b];
@@ -1029,7 +1036,8 @@ static int prepare_scheduled(spg_graph *g, spg_round_info *info, double t0) {
         cost[b] = nn * nn * nn + (double)r.ne * d * d * d + 1.0;
         total += cost[b];
     }
-    std::vector<int> first(nr + 1, B);
+    std::vector<int> &first = g->s_first;
+    first.assign(nr + 1, B);
     {
         double acc = 0;
         int q = 0;
@@ -1045,7 +1053,8 @@ static int prepare_scheduled(spg_graph *g, spg_round_info *info, double t0) {
     bt.h_blk.resize(B);
     bt.h_vpo.clear(); bt.h_er.clear(); bt.h_ev.clear();
     bt.chunk_hdr.assign(nr, 0);
-    std::vector<int64_t> chunk_len(nr, 0);
+    std::vector<int64_t> &chunk_len = g->s_chunk_len;
+    chunk_len.assign(nr, 0);
     if (g->lidx.size() < g->vid.size()) g->lidx.resize(g->vid.size(), -1);
     std::vector<int32_t> &lidx = g->lidx;
     for (int q = 0; q < nr; q++) {
@@ -1233,7 +1242,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
         else { g->stale_lo = std::min(g->stale_lo, lo); g->stale_hi = std::max(g->stale_hi, hi); }
     }
     // updateInputGraph (src/vertex_remover.cpp:500-546), in list order
-    std::vector<int32_t> vix;
+    std::vector<int32_t> &vix = g->s_vix;
     for (size_t b = 0; b < bt.rb.size(); b++) {
         RoundBlanket &r = bt.rb[b];
         const spg_blanket_desc &bd = r.desc;

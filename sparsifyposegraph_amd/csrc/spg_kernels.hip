@@ -1139,6 +1139,7 @@ struct HipBackend {
         void *d_stage = nullptr;                      // the same buffer in the device's address space
         size_t c_stage = 0;
         bool busy = false;                            // work was queued on the stream since its last synchronisation
+        std::vector<int32_t> bin_lists[5];            // scratch of hip_run_round
         std::vector<Timed> pending;
         // per slot, so that a submission thread working on one slot and the graph thread draining
         // another never share state
@@ -1218,10 +1219,11 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     const int D = o.pose_dim;
     if (D != 3 && D != 6) return SPG_EINVAL;
     // ---- bin this rank's blankets by the LDS their tiles need
-    struct Bin { std::vector<int32_t> list; int kmax = 0, mmax = 0, smax = 0; double bytes = 0; };
+    struct Bin { std::vector<int32_t> &list; int kmax = 0, mmax = 0, smax = 0; double bytes = 0; };
     const int NB = 5;
     const size_t lim[NB - 1] = {24 * 1024, 40 * 1024, 80 * 1024, (size_t)hb->lds_limit};
-    Bin bins[NB];
+    for (auto &v : S.bin_lists) v.clear();   // per-slot scratch: no allocation per launch
+    Bin bins[NB] = {{S.bin_lists[0]}, {S.bin_lists[1]}, {S.bin_lists[2]}, {S.bin_lists[3]}, {S.bin_lists[4]}};
     for (int b = rd->first; b < rd->first + rd->count; b++) {
         const spg_blanket_desc &bd = rd->blankets[b];
         int k = bd.n_vert - bd.n_remove, m = bd.n_remove;
@@ -1230,7 +1232,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         int bi = NB - 1;
         for (int i = 0; i < NB - 1; i++) if (need <= lim[i]) { bi = i; break; }
         bins[bi].list.push_back(b);
-        {
+        if (hb->profiling) {
             // algorithmic HBM bytes of this blanket: poses + (2 x i32 + record) per edge
             // + new records + (kld f64 + status i32)
             const int ps = (D == 6) ? 7 : 3;
