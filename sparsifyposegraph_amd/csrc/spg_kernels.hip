@@ -1140,6 +1140,8 @@ struct HipBackend {
         size_t c_stage = 0;
         bool busy = false;                            // work was queued on the stream since its last synchronisation
         std::vector<int32_t> bin_lists[5];            // scratch of hip_run_round
+        void *d_bar = nullptr;                        // fine-grained device memory the host writes through the PCIe BAR
+        size_t c_bar = 0;
         std::vector<Timed> pending;
         // per slot, so that a submission thread working on one slot and the graph thread draining
         // another never share state
@@ -1150,6 +1152,7 @@ struct HipBackend {
     static constexpr int NSLOT = 4;
     Slot slots[NSLOT];
     int lds_limit = 160 * 1024;
+    bool large_bar = false;       // the host can store straight into device memory (hipDeviceAttributeIsLargeBar)
     std::atomic<int> n_launches{0};
     bool force_one_wave = false;  // SPG_ONE_WAVE=1: never use the two-wavefront latency variant (A/B timing)
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
@@ -1263,9 +1266,29 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     if (S.busy) { HIPCHK(hipStreamSynchronize(S.stream)); S.busy = false; }
     drain_profile(hb, S);
     S.busy = true;
-    if (int rc = hb->ensure_stage(S, tot)) return rc;
-    if (int rc = hb->ensure(S, &S.d_desc, &S.c_desc, tot)) return rc;
-    char *st = (char *)S.h_stage;
+    // Where the descriptors of this launch go:
+    //  - small launch, large-BAR system: the host stores them straight into (fine-grained) device memory —
+    //    posted writes ahead of the doorbell, no copy engine hop, and the kernel reads local HBM;
+    //  - small launch otherwise: the kernel reads them from the mapped pinned staging buffer over PCIe;
+    //  - large launch: one host->device copy from the staging buffer.
+    static const int mapped_limit = [] { const char *e = getenv("SPG_MAPPED_DESC"); return e ? atoi(e) : 512; }();
+    static const bool bar_ok = [] { const char *e = getenv("SPG_BAR_DESC"); return !(e && e[0] == '0'); }();
+    const bool small = (long long)rd->count <= (long long)mapped_limit;
+    const bool via_bar = small && hb->large_bar && bar_ok;
+    char *st;
+    if (via_bar) {
+        if (tot > S.c_bar) {
+            if (S.d_bar) HIPCHK(hipFree(S.d_bar));
+            size_t nc = std::max(tot, S.c_bar * 2);
+            HIPCHK(hipExtMallocWithFlags(&S.d_bar, nc, hipDeviceMallocFinegrained));
+            S.c_bar = nc;
+        }
+        st = (char *)S.d_bar;   // write-only from the host
+    } else {
+        if (int rc = hb->ensure_stage(S, tot)) return rc;
+        if (!small) if (int rc = hb->ensure(S, &S.d_desc, &S.c_desc, tot)) return rc;
+        st = (char *)S.h_stage;
+    }
     memcpy(st + o_blk, rd->blankets, s_blk);
     memcpy(st + o_vpo, rd->vert_pose_off, s_vpo);
     memcpy(st + o_er, rd->edges, s_er);
@@ -1275,14 +1298,17 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         size_t p = 0;
         for (int i = 0; i < NB; i++) for (int32_t b : bins[i].list) lst[p++] = b;
     }
-    // Small launches read their descriptors straight from the pinned staging buffer (it is mapped into
-    // the device's address space): a copy engine hop in front of a latency-bound kernel costs more
-    // than a few scalar loads over PCIe. Large launches take one host->device copy.
-    static const int mapped_limit = [] { const char *e = getenv("SPG_MAPPED_DESC"); return e ? atoi(e) : 512; }();
-    char *desc_base = (char *)S.d_desc;
-    if ((long long)rd->count <= (long long)mapped_limit) {
+    char *desc_base;
+    if (via_bar) {
+        std::atomic_thread_fence(std::memory_order_release);
+#if defined(__x86_64__)
+        __builtin_ia32_sfence();   // write-combining buffers drained before the launch rings the doorbell
+#endif
+        desc_base = (char *)S.d_bar;
+    } else if (small) {
         desc_base = (char *)S.d_stage;
     } else {
+        desc_base = (char *)S.d_desc;
         HIPCHK(hipMemcpyAsync(S.d_desc, st, tot, hipMemcpyHostToDevice, S.stream));
     }
     double *mail_dev = nullptr;
@@ -1425,6 +1451,10 @@ int hip_backend_create(int device, spg_backend *out, char *errbuf, size_t errlen
     }
     { const char *e1 = getenv("SPG_ONE_WAVE"); hb->force_one_wave = e1 && e1[0] == '1'; }
     hb->lds_limit = (int)prop.sharedMemPerBlock > 0 ? (int)std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024) : 64 * 1024;
+    {
+        int lb = 0;
+        hb->large_bar = hipDeviceGetAttribute(&lb, hipDeviceAttributeIsLargeBar, device) == hipSuccess && lb != 0;
+    }
     out->user = hb;
     out->alloc = hip_alloc;
     out->release = hip_release;
@@ -1448,6 +1478,7 @@ void hip_backend_destroy(spg_backend *b) {
         if (S.d_gws) (void)hipFree(S.d_gws);
         if (S.h_mail) (void)hipHostFree(S.h_mail);
         if (S.h_stage) (void)hipHostFree(S.h_stage);
+        if (S.d_bar) (void)hipFree(S.d_bar);
         for (auto &t : S.pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
         for (auto &pr : S.pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         (void)hipStreamDestroy(S.stream);
