@@ -100,7 +100,8 @@ def main():
     for i in range(args.warmup):
         run(replicas[i])
     fence()
-    ctx.profile(True)
+    EVENT_STRIDE = 1   # HIP events around every launch (sampling every n-th launch made the untimed launches slower)
+    ctx.profile(EVENT_STRIDE)
     t0 = time.perf_counter()
     stats = None
     for i in range(args.steps):
@@ -142,8 +143,8 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
             if world == 1 and args.poses == 100000 and args.ring == 400:
-                # the PMC passes see the same launches; scale to this run's launch count
-                traffic = pm["traffic_bytes_total_uncorrected_per_step"] * args.steps / prof["launches"]
+                # per launch, from the PMC passes of this same command
+                traffic = pm["traffic_bytes_total_uncorrected_per_step"] / pm["launches_per_step"]
                 traffic_note = "profiles/r01_pmc_summary.json: (FETCH_SIZE + WRITE_SIZE) * 1024 per launch, separate --pmc passes, uncorrected (8 B/lane gathers are outside the guide's calibration; includes instruction fetch)"
         except Exception:
             pass
@@ -152,7 +153,7 @@ def main():
             "traffic": traffic, "traffic_note": traffic_note,
             # launches of <= 512 blankets give every blanket two wavefronts (NT = 128), larger ones one (NT = 64)
             "kernel": "blanket_kernel<6,128,false,NFR>" if prof["blankets"] / prof["launches"] <= 512 else "blanket_kernel<6,64,false,NFR>",
-            "launches": prof["launches"],
+            "launches": prof["launches"], "event_sampling": "HIP events around every launch of the timed region" if EVENT_STRIDE == 1 else f"HIP events around every {EVENT_STRIDE}-th launch",
             "avg_launch_us": 1e6 * per_launch_s, "alg_bytes_per_launch": per_launch_bytes,
             "blankets_per_launch": prof["blankets"] / prof["launches"],
             "note": "path is fp64-ALU/latency-bound on paper (SURVEY.md 8d: ~110 flop/B); fp64 vector fraction alongside",

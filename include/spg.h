@@ -127,8 +127,11 @@ const char *spg_last_error(spg_ctx *ctx);
 void *spg_ctx_stream(spg_ctx *ctx);
 int spg_ctx_synchronize(spg_ctx *ctx);
 /* per-launch timing of the blanket kernel with HIP events on the context stream (bench roofline leg):
- * enable/reset, then read the sums over every launch completed since: kernel milliseconds, algorithmic
- * HBM bytes (SURVEY.md 8d formula evaluated on the launched blankets), launches, blankets */
+ * enable/reset, then read the sums over the timed launches completed since: kernel milliseconds,
+ * algorithmic HBM bytes (SURVEY.md 8d formula evaluated on the launched blankets), launches, blankets.
+ * enable = 1 times every launch (what bench.py uses); enable = n > 1 only every n-th one; 0 switches timing
+ * off. (Sampling does not pay on ROCm 7.2: launches without the trailing event record were measured to
+ * cost more host time than the two records they save.) */
 int spg_ctx_profile(spg_ctx *ctx, int enable);
 int spg_ctx_profile_read(spg_ctx *ctx, double *kernel_ms, double *alg_bytes, int64_t *launches, int64_t *blankets);
 

@@ -22,6 +22,7 @@
 // the algorithmic minimum: every pose and edge record is read once, every new record written once.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1157,6 +1158,7 @@ struct HipBackend {
     bool force_one_wave = false;  // SPG_ONE_WAVE=1: never use the two-wavefront latency variant (A/B timing)
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
     bool profiling = false;
+    int prof_stride = 1, prof_tick = 0;   // time every prof_stride-th launch (1 = all)
 
     int ensure(Slot &S, void **p, size_t *cap, size_t need) {
         if (need <= *cap) return 0;
@@ -1184,7 +1186,8 @@ static int launch_bin(HipBackend *hb, HipBackend::Slot &S, const KArgs &ka, int 
     if (lds_bytes > 64 * 1024)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HipBackend::Timed t{};
-    if (hb->profiling) {
+    const bool timed = hb->profiling && (hb->prof_tick++ % hb->prof_stride == 0);
+    if (timed) {
         if (S.pool.empty()) {
             HIPCHK(hipEventCreate(&t.a));
             HIPCHK(hipEventCreate(&t.b));
@@ -1194,7 +1197,7 @@ static int launch_bin(HipBackend *hb, HipBackend::Slot &S, const KArgs &ka, int 
     }
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), lds_bytes, S.stream, ka);
     HIPCHK(hipGetLastError());
-    if (hb->profiling) {
+    if (timed) {
         HIPCHK(hipEventRecord(t.b, S.stream));
         S.pending.push_back(t);
     }
@@ -1213,8 +1216,17 @@ static void drain_profile(HipBackend *hb, HipBackend::Slot &S) {
     S.pending.clear();
 }
 
+#ifdef SPG_LAUNCH_PROF
+static double lp_t[6]; static long lp_n;
+#define LP(i) do { auto n_ = std::chrono::steady_clock::now(); lp_t[i] += std::chrono::duration<double, std::micro>(n_ - lp0_).count(); lp0_ = n_; } while (0)
+#define LP0 auto lp0_ = std::chrono::steady_clock::now(); lp_n++
+#else
+#define LP(i) do {} while (0)
+#define LP0 do {} while (0)
+#endif
 static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     HipBackend *hb = (HipBackend *)user;
+    LP0;
     char *err = hb->err;
     if (rd->count <= 0) return 0;
     HipBackend::Slot &S = hb->slots[rd->slot & (HipBackend::NSLOT - 1)];
@@ -1248,6 +1260,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         bins[bi].mmax = std::max(bins[bi].mmax, m);
         bins[bi].smax = std::max(bins[bi].smax, (int)bd.pad_);
     }
+    LP(0);
     // ---- upload the round's descriptors (one pinned staging buffer, async copies)
     size_t s_blk = sizeof(spg_blanket_desc) * (size_t)rd->n_blankets;
     size_t s_vpo = sizeof(int64_t) * (size_t)rd->n_vert_total;
@@ -1266,6 +1279,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     if (S.busy) { HIPCHK(hipStreamSynchronize(S.stream)); S.busy = false; }
     drain_profile(hb, S);
     S.busy = true;
+    LP(1);
     // Where the descriptors of this launch go:
     //  - small launch, large-BAR system: the host stores them straight into (fine-grained) device memory —
     //    posted writes ahead of the doorbell, no copy engine hop, and the kernel reads local HBM;
@@ -1311,6 +1325,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         desc_base = (char *)S.d_desc;
         HIPCHK(hipMemcpyAsync(S.d_desc, st, tot, hipMemcpyHostToDevice, S.stream));
     }
+    LP(2);
     double *mail_dev = nullptr;
     if (rd->mail_len > 0) {
         size_t need = (size_t)rd->mail_len * 8;
@@ -1374,6 +1389,11 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         }
         if (rc) return rc;
     }
+    LP(3);
+#ifdef SPG_LAUNCH_PROF
+    if (lp_n % 1005 == 0) fprintf(stderr, "launch prof: bins %.2f sync+drain %.2f desc write %.2f launch %.2f us (avg over %ld)\n",
+                                  lp_t[0] / lp_n, lp_t[1] / lp_n, lp_t[2] / lp_n, lp_t[3] / lp_n, lp_n);
+#endif
     return 0;
 }
 
@@ -1495,6 +1515,8 @@ void hip_backend_profile(spg_backend *b, int enable) {
     HipBackend *hb = (HipBackend *)b->user;
     if (!hb) return;
     hb->profiling = enable != 0;
+    hb->prof_stride = enable > 1 ? enable : 1;   // enable = n > 1: HIP events around every n-th launch only
+    hb->prof_tick = 0;
     for (auto &S : hb->slots) { S.prof_ms = S.prof_bytes = 0; S.prof_launches = S.prof_blankets = 0; }
 }
 void hip_backend_profile_read(spg_backend *b, double *ms, double *bytes, long long *launches, long long *blankets) {
