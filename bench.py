@@ -101,7 +101,7 @@ def main():
         run(replicas[i])
     fence()
     EVENT_STRIDE = 1   # HIP events around every launch (sampling every n-th launch made the untimed launches slower)
-    ctx.profile(EVENT_STRIDE)
+    ctx.profile(0 if os.environ.get("SPG_BENCH_NO_EVENTS") == "1" else EVENT_STRIDE)   # (=1: A/B of the event overhead; no roofline then)
     t0 = time.perf_counter()
     stats = None
     for i in range(args.steps):
