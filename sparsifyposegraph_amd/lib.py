@@ -10,7 +10,7 @@ import subprocess
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspg_hip.so")
+LIB_PATH = os.environ.get("SPG_LIB_PATH") or os.path.join(_HERE, "libspg_hip.so")   # (override: A/B of two builds)
 _lib = None
 
 _f64p, _i32p, _i64p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
