@@ -353,3 +353,29 @@ def test_global_kld_invariants_multi_tile(hip_ctx):
     assert res["nfr"] > 1e-3
     assert abs(res["nfr"] - res["glc"]) <= 1e-6 * max(1.0, res["nfr"])
     print("global KLD, 1501-pose sphere:", res, base.last_kld_terms)
+
+
+def test_global_kld_on_full_size_configs(hip_ctx):
+    """the dense global KLD on BASELINE.json configs 2-4 at full size (inputs: the full-size
+    fixtures), through invariants the oracle is too slow to replace there: Dense GLC on all of manhattan
+    reproduces the baseline marginal (KLD ~ 0 over 5 280 kept variables); on all of sphere and parking the
+    NFR Tree and the GLC Tree sparsifications are the same Chow-Liu approximation (equal KLD > 0)."""
+    g, which, opts, *_ = util.load_golden("manhattan_full_glc_dense")
+    base = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+    sp = GraphWrapperHIP.from_dict(g, ctx=hip_ctx, useGLC=True)
+    sp.marginalizeNoOptimize(which, opts)
+    kld = base.kullbackLeibler(sp)
+    t = base.last_kld_terms
+    assert t["n"] == 3 * (sp.numVertices() - 1) and abs(kld) <= 1e-6 * t["n"], (kld, t)
+    out = {"manhattan dense": kld}
+    for case in ("sphere_full_nfr_tree", "parking_full_nfr_tree"):
+        g, which, opts, *_ = util.load_golden(case)
+        base = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+        res = []
+        for alg in (abi.ALG_NFR, abi.ALG_GLC):
+            sp = GraphWrapperHIP.from_dict(g, ctx=hip_ctx, useGLC=(alg == abi.ALG_GLC))
+            sp.marginalizeNoOptimize(which, abi.make_options(6, alg, abi.TOPO_TREE))
+            res.append(base.kullbackLeibler(sp))
+        assert res[0] > 1.0 and abs(res[0] - res[1]) <= 1e-6 * res[0], res
+        out[case] = res[0]
+    print("global KLD at full size:", out)
