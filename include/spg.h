@@ -153,7 +153,8 @@ typedef struct spg_graph spg_graph;
 int spg_graph_create(spg_ctx *ctx, int pose_dim, spg_graph **out);
 void spg_graph_destroy(spg_graph *g);
 /* GraphWrapperG2O(fname, optimize=false, ...) (src/graph_wrapper_g2o.cpp:107-154), .g2o text:
- * VERTEX_SE2 / EDGE_SE2 / VERTEX_SE3:QUAT / EDGE_SE3:QUAT. No optimisation (LM is out of scope). */
+ * VERTEX_SE2 / EDGE_SE2 / VERTEX_SE3:QUAT / EDGE_SE3:QUAT and GLC_EDGE (src/glc_edge.cpp:65-93). The estimates
+ * are taken as stored (optimize=false); call spg_graph_optimize for the reference's optimize=true. */
 int spg_graph_load_g2o(spg_ctx *ctx, const char *path, spg_graph **out);
 /* GraphWrapper::write (src/graph_wrapper_g2o.cpp:467-470) incl. GLC_EDGE records (src/glc_edge.cpp:95-119) */
 int spg_graph_write_g2o(spg_graph *g, const char *path);
@@ -196,7 +197,7 @@ typedef struct {
 /* GraphWrapperG2O::marginalizeNoOptimize (src/graph_wrapper_g2o.cpp:398-453): removes `which` with
  * the sequential semantics of VertexRemover::remove (src/vertex_remover.cpp:83-140), executed as
  * conflict-free rounds of independent blankets on the device. Does NOT run optimize()
- * (src/graph_wrapper_g2o.cpp:462) — LM is outside the accelerated path. */
+ * (src/graph_wrapper_g2o.cpp:462); GraphWrapperG2O::marginalize = this + spg_graph_optimize. */
 int spg_graph_marginalize(spg_graph *g, const int32_t *which, int n, const spg_options *opts,
                           spg_marg_stats *stats);
 /* The same call for nranks cooperating processes (one per GPU), each holding an identical replica:
