@@ -658,6 +658,10 @@ inline bool local_linearization_point(const BlanketIn &in, std::vector<double> &
 
 inline BlanketOut run_blanket_at(const spg_options &o, const BlanketIn &in);
 
+// set by spg_ref.cpp: optimise the blanket's estimates in place of a closed form (returns false if it cannot)
+typedef bool (*LocalLmFn)(const BlanketIn &in, std::vector<double> &pose);
+inline LocalLmFn &local_lm_hook() { static LocalLmFn f = nullptr; return f; }
+
 // One iteration of VertexRemover::remove (src/vertex_remover.cpp:108-132) on a gathered blanket.
 inline BlanketOut run_blanket(const spg_options &o, const BlanketIn &in) {
     BlanketOut out;
@@ -665,7 +669,11 @@ inline BlanketOut run_blanket(const spg_options &o, const BlanketIn &in) {
     BlanketIn local = in;
     std::vector<double> local_pose;
     if (o.lin_point != SPG_LIN_GLOBAL) {
-        if (!local_linearization_point(in, local_pose)) { out.status = SPG_ST_NEEDS_LOCAL_OPTIMIZATION; return out; }
+        if (!local_linearization_point(in, local_pose)) {
+            // no closed-form estimate: 10 LM iterations on the subgraph with the first removed vertex fixed at
+            // its current estimate (src/vertex_remover.cpp:382-391). The LM lives with the graph code.
+            if (!local_lm_hook() || !local_lm_hook()(in, local_pose)) { out.status = SPG_ST_NEEDS_LOCAL_OPTIMIZATION; return out; }
+        }
         local.pose = local_pose.data();
     }
     return run_blanket_at(o, local);

@@ -630,6 +630,28 @@ int spgref_graph_set_estimate(void *h, int id, const double *pose) {
     return 0;
 }
 
+// buildSubgraph, Local linearisation point without a closed form (src/vertex_remover.cpp:382-391): the
+// blanket becomes a small graph (local vertex index = id), the first removed vertex is fixed, 10 LM iterations.
+static bool blanket_local_lm(const BlanketIn &in, std::vector<double> &pose) {
+    if (in.m != 1) return false;   // clusters (Dense) with a Local linearisation point: not restated
+    int ps = pose_stride(in.d);
+    RGraph g;
+    g.d = in.d;
+    for (int v = 0; v < in.nv; v++) { g.pose[v] = std::vector<double>(in.pose + (size_t)v * ps, in.pose + (size_t)(v + 1) * ps); g.adj[v]; }
+    for (const EdgeIn &e : in.edges) {
+        if (e.kind != SPG_EDGE_BINARY) return false;
+        REdge re;
+        re.kind = e.kind; re.ids.assign(e.v.begin(), e.v.end()); re.data.assign(e.data, e.data + e.len); re.alive = true;
+        g.edges.push_back(re);
+    }
+    double st[5];
+    optimize_fixed(&g, 10, std::set<int>{0}, st);
+    pose.resize((size_t)in.nv * ps);
+    for (int v = 0; v < in.nv; v++) std::memcpy(&pose[(size_t)v * ps], g.pose[v].data(), ps * sizeof(double));
+    return true;
+}
+namespace { struct HookInit { HookInit() { local_lm_hook() = blanket_local_lm; } } hook_init_; }
+
 // Batch entry spread over host threads (cpu_baseline "B": same rounds, all cores). Blankets are
 // independent; outputs are produced per thread and stitched in order.
 int spgref_marginalize_batch_mt(const spg_options *o, const spg_batch *b, spg_result *r, int nthreads) {

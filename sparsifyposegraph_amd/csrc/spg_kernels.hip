@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     };
     STAMP(0);  //
     // ---------------------------------------------------------------- gather poses, clear H
-    if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0; misc[6] = 0; misc[7] = 0; }
+    if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0; misc[6] = 0; misc[7] = 0; misc[8] = 0; misc[9] = 0; }
     for (int v = tid; v < nv; v += NT) {
         const double *p = arena + a.vpo[bd.vert_begin + v];
         if (D == 6) iso_from_tq(p, pose + v * PSZ);
@@ -227,6 +227,8 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         finish(); return;
     }
 
+    // Local linearisation point without a closed form: lm_left LM iterations on the blanket (below)
+    int lm_left = 0;
     if (a.lin_point != SPG_LIN_GLOBAL) {
         // Local linearisation point, closed-form branch of buildSubgraph (src/vertex_remover.cpp:304-381):
         // possible iff every vertex but the first removed one sits in exactly one (pose-pose) blanket edge;
@@ -237,15 +239,21 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         T.sync();
         for (int e = tid; e < bd.n_edge; e += NT) {
             const spg_edge_ref er = a.er[bd.edge_begin + e];
-            if (er.kind != SPG_EDGE_BINARY) { misc[1] = 1; continue; }
+            if (er.kind != SPG_EDGE_BINARY) { misc[8] = 1; continue; }
             int vi = a.ev[er.vbegin], vj = a.ev[er.vbegin + 1];
             if (vi != 0) atomicAdd(&cntv[vi], 1);
             if (vj != 0) atomicAdd(&cntv[vj], 1);
         }
         T.sync();
-        for (int v = 1 + tid; v < nv; v += NT) if (cntv[v] > 1) misc[1] = 1;
+        for (int v = 1 + tid; v < nv; v += NT) if (cntv[v] > 1) misc[9] = 1;
         T.sync();
-        if (misc[1] || n < nv) { status = SPG_ST_NEEDS_LOCAL_OPTIMIZATION; finish(); return; }
+        // a GLC edge cannot propagate an estimate, and clusters (m > 1) with a Local point are not built
+        if (misc[8] || n < nv || (misc[9] && m != 1)) { status = SPG_ST_NEEDS_LOCAL_OPTIMIZATION; finish(); return; }
+        if (misc[9]) {
+            // some kept vertex sits in several blanket edges: the reference fixes the removed vertex at its
+            // current estimate and runs 10 LM iterations on the subgraph (src/vertex_remover.cpp:382-391)
+            lm_left = 10;
+        } else {
         if (tid == 0) {
             if (D == 6) {
 #pragma unroll
@@ -281,6 +289,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                 }
             }
         }
+        }
         T.sync();
     }
     // ---------------------------------------------------------------- assemble H (a6)
@@ -292,6 +301,26 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             M1[(R - nm) * ld + (Cc - nm)] += val;
         }
     };
+    // LM state (uniform over the workgroup; only used when lm_left > 0). The system of an LM iteration is
+    // what the assembly produces anyway: H = M1 (kept block: the removed vertex is fixed), plus the
+    // right-hand side b = -sum J^T Omega e and chi2, which the assembly adds in LM mode. M2 / Sv keep the
+    // system of the last accepted estimates, M3 takes the factorisation, Ng the backup of the estimates.
+    double *eE = nJ;                      // errors of the staged edges (EC x D)
+    double *bnew = ev, *bcur = Sv, *xs = cs, *pbak = smem + L.o_Ng;
+    double lm_lambda = 0, lm_ni = 2, lm_chi = 0, lm_scale = 0;
+    int lm_it = 0, lm_q = 0, lm_phase = 0;
+    bool lm_redo = false;                 // the tiles hold a rejected trial: assemble once more, then go on
+    for (;;) {
+    if (lm_left > 0 || lm_redo) {
+        if (lm_phase > 0 || lm_redo) {
+            for (int i = tid; i < n * ld; i += NT) M1[i] = 0.0;
+            for (int i = tid; i < nm * ldm; i += NT) Hmm[i] = 0.0;
+            for (int i = tid; i < nm * ld; i += NT) Hmk[i] = 0.0;
+        }
+        for (int i = tid; i < n; i += NT) bnew[i] = 0.0;
+        if (tid == 0) xch[0] = 0.0;
+        T.sync();
+    }
     for (int base = 0; base < bd.n_edge; base += EC) {
         int cnt = min(EC, bd.n_edge - base);
         if (tid < cnt) {
@@ -303,9 +332,9 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                 if (D == 6) {
                     double Z[kIso];
                     iso_from_tq(rec, Z);
-                    se3_edge_jac(pose + vi * PSZ, pose + vj * PSZ, Z, eJ + tid * 2 * DD, eJ + tid * 2 * DD + DD, nullptr);
+                    se3_edge_jac(pose + vi * PSZ, pose + vj * PSZ, Z, eJ + tid * 2 * DD, eJ + tid * 2 * DD + DD, lm_left > 0 ? eE + tid * D : nullptr);
                 } else {
-                    se2_edge_jac(pose + vi * PSZ, pose + vj * PSZ, rec, eJ + tid * 2 * DD, eJ + tid * 2 * DD + DD, nullptr);
+                    se2_edge_jac(pose + vi * PSZ, pose + vj * PSZ, rec, eJ + tid * 2 * DD, eJ + tid * 2 * DD + DD, lm_left > 0 ? eE + tid * D : nullptr);
                 }
             } else {
                 if (!is_glc) misc[1] = 1;  // GLC edge inside an NFR blanket: no provider applies
@@ -332,6 +361,33 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         }
         T.sync();
         STAMP(25);  // T = Omega J
+        if (lm_left > 0) {
+            // LM mode: b_v -= (Omega J_v)^T e and chi2 += e^T Omega e (one lane: this path is rare and short)
+            if (tid == 0) {
+                double c2 = 0;
+                for (int e = 0; e < cnt; e++) {
+                    if (echv[2 * e] < 0) continue;
+                    const double *Om = eO + e * DD, *er_ = eE + e * D;
+                    for (int p = 0; p < D; p++) {
+                        double sacc = 0;
+                        for (int q = 0; q < D; q++) sacc += Om[p * D + q] * er_[q];
+                        c2 += er_[p] * sacc;
+                    }
+                    for (int side = 0; side < 2; side++) {
+                        int v = echv[2 * e + side];
+                        if (v < 1) continue;   // the removed vertex (local index 0, m == 1) is fixed
+                        const double *Te = eT + e * 2 * DD + side * DD;
+                        for (int r = 0; r < D; r++) {
+                            double sacc = 0;
+                            for (int p = 0; p < D; p++) sacc += Te[p * D + r] * er_[p];
+                            bnew[(v - 1) * D + r] -= sacc;
+                        }
+                    }
+                }
+                xch[0] += c2;
+            }
+            T.sync();
+        }
         if (NT == 64) {
             // One wavefront: LDS atomics retire in program order and every ds_add_f64 below carries the
             // items of a single edge (128-slot stride, 108 used), so no two lanes of one instruction hit
@@ -384,6 +440,113 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         }
         }
     }
+    if (lm_redo || lm_left <= 0) break;   // ordinary case: one assembly
+    // ---- g2o Levenberg-Marquardt on the blanket, removed vertex fixed (OptimizationAlgorithmLevenberg:
+    //      lambda_0 = 1e-5 max diag, <= 10 trials per iteration, rho = (chi2 - chi2') / (x.(lambda x + b) + 1e-3),
+    //      good step: lambda *= clamp(1 - (2 rho - 1)^3, 1/3, 2/3); bad step: lambda *= ni, ni *= 2)
+    {
+        const double chi_new = xch[0];
+        bool next_trial = false, done = false;
+        if (lm_phase == 0) {
+            // first system: the current estimates
+            lm_chi = chi_new;
+            if (tid == 0) { double md = 0; for (int i = 0; i < n; i++) md = fmax(md, fabs(M1[i * ld + i])); xch[1] = md; }
+            T.sync();
+            lm_lambda = 1e-5 * xch[1];
+            lm_ni = 2; lm_it = 0; lm_q = 0;
+            for (int i = tid; i < n * ld; i += NT) M2[i] = M1[i];
+            for (int i = tid; i < n; i += NT) bcur[i] = bnew[i];
+            T.sync();
+            lm_phase = 1;
+            next_trial = true;
+        } else {
+            const double rho = (lm_chi - chi_new) / (lm_scale + 1e-3);
+            if (rho > 0 && isfinite(chi_new)) {
+                double alpha = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+                alpha = fmin(alpha, 2.0 / 3.0);
+                lm_lambda *= fmax(1.0 / 3.0, alpha);
+                lm_ni = 2;
+                lm_chi = chi_new;
+                for (int i = tid; i < n * ld; i += NT) M2[i] = M1[i];
+                for (int i = tid; i < n; i += NT) bcur[i] = bnew[i];
+                T.sync();
+                lm_it++; lm_q = 0;
+                if (lm_it >= lm_left) done = true;          // the tiles hold the system of the accepted estimates
+                else next_trial = true;
+            } else {
+                lm_lambda *= lm_ni;
+                lm_ni *= 2;
+                for (int i = tid; i < nv * PSZ; i += NT) pose[i] = pbak[i];   // pop()
+                T.sync();
+                lm_q++;
+                if (rho < 0 && lm_q < 10 && isfinite(lm_lambda)) next_trial = true;
+                else { lm_redo = true; }                     // terminate: re-assemble at the restored estimates
+            }
+        }
+        if (done) { lm_left = 0; break; }
+        if (lm_redo) { lm_left = 0; continue; }
+        if (next_trial) {
+            // solve (H + lambda I) x = b with the system of the accepted estimates, then x -> estimates
+            bool ok2 = true;
+            for (;;) {
+                for (int i = tid; i < nv * PSZ; i += NT) pbak[i] = pose[i];   // push()
+                for (int i = tid; i < n * ld; i += NT) { int r = i / ld, c = i - r * ld; M3[i] = M2[i] + ((r == c && c < n) ? lm_lambda : 0.0); }
+                if (tid == 0) *T.flag = 0;
+                T.sync();
+                chol_lower<NT>(T, M3, n, ld);
+                ok2 = (*T.flag == 0);
+                T.sync();
+                if (tid == 0) *T.flag = 0;
+                if (ok2) break;
+                // the factorisation failed: g2o rejects the step (chi2 = max) without looking at the estimates
+                lm_lambda *= lm_ni; lm_ni *= 2; lm_q++;
+                if (!(lm_q < 10 && isfinite(lm_lambda))) break;
+                T.sync();
+            }
+            if (!ok2) { lm_redo = true; lm_left = 0; T.sync(); continue; }
+            if (tid == 0) {
+                for (int i = 0; i < n; i++) {
+                    double sacc = bcur[i];
+                    for (int kk = 0; kk < i; kk++) sacc -= M3[i * ld + kk] * xs[kk];
+                    xs[i] = sacc / M3[i * ld + i];
+                }
+                for (int i = n - 1; i >= 0; i--) {
+                    double sacc = xs[i];
+                    for (int kk = i + 1; kk < n; kk++) sacc -= M3[kk * ld + i] * xs[kk];
+                    xs[i] = sacc / M3[i * ld + i];
+                }
+                double sc = 0;
+                for (int i = 0; i < n; i++) sc += xs[i] * (lm_lambda * xs[i] + bcur[i]);
+                xch[2] = sc;
+            }
+            T.sync();
+            lm_scale = xch[2];
+            for (int v = 1 + tid; v < nv; v += NT) {
+                const double *dx = xs + (v - 1) * D;
+                double *pv = pose + v * PSZ;
+                if (D == 6) {
+                    // X <- X * fromVectorMQT(dx), renormalised through the quaternion (the estimates are stored as t + q)
+                    double Dl[kIso], R[9], q[4];
+                    iso_from_mqt(dx, Dl);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) R[i * 3 + c] = pv[i * 3] * Dl[c] + pv[i * 3 + 1] * Dl[3 + c] + pv[i * 3 + 2] * Dl[6 + c];
+                    }
+                    double tn[3];
+#pragma unroll
+                    for (int i = 0; i < 3; i++) tn[i] = pv[9 + i] + pv[i * 3] * Dl[9] + pv[i * 3 + 1] * Dl[10] + pv[i * 3 + 2] * Dl[11];
+                    R_to_quat(R, q);
+                    quat_to_R(q, pv);
+                    pv[9] = tn[0]; pv[10] = tn[1]; pv[11] = tn[2];
+                } else {
+                    pv[0] += dx[0]; pv[1] += dx[1]; pv[2] = normalize_theta(pv[2] + dx[2]);
+                }
+            }
+            T.sync();
+        }
+    }
+    }   // LM wrapper
     if (misc[1]) { status = SPG_ST_UNSUPPORTED; finish(); return; }
     if constexpr (is_glc) {
         // n-ary GLC edges already in the blanket (a14): H += (W Jr)^T (W Jr), Jr = reparametrisation
