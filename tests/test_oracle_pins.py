@@ -315,4 +315,13 @@ def test_local_linearization_point_chain(oracle):
     batch2["edge_data_off"] = np.array([0, 28, 56, 84], np.int64)
     batch2["edge_data"] = np.concatenate([z01, info, z12, info, z12, info])
     out2 = abi.marginalize_batch(oracle, None, opts, batch2)
-    assert out2["status"][0] == abi.ST_NEEDS_LOCAL_OPTIMIZATION
+    # ... which the oracle restates (10 LM iterations on the blanket, removed vertex fixed): the estimate of
+    # vertex 2 is now a compromise between the chain 1-0-2 and the direct edge 1-2, so the recovered
+    # measurement 0->2 moves away from the pure composition
+    assert out2["status"][0] == 0 and list(out2["new_edge_vert"]) == [0, 2]
+    assert not np.allclose(out2["new_edge_data"][:3], t, atol=1e-3)
+    # a cluster of two removed vertices under Local is not restated (and not built): status 11
+    batch3 = dict(batch2)
+    batch3["n_remove"] = np.array([2], np.int32)
+    out3 = abi.marginalize_batch(oracle, None, opts, batch3)
+    assert out3["status"][0] == abi.ST_NEEDS_LOCAL_OPTIMIZATION
