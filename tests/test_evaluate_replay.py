@@ -63,14 +63,16 @@ def test_evaluate_loop_on_the_oracle_alone():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("profile,alg", [("online", "nfr"), ("cluster", "nfr"), ("online", "glc"), ("cluster", "nfr-chi2")])
+@pytest.mark.parametrize("profile,alg", [("online", "nfr"), ("cluster", "nfr"), ("online", "glc"), ("cluster", "nfr-chi2"),
+                                         ("cluster", "nfr-local")])
 def test_replay_matches_oracle(profile, alg, hip_ctx):
     use_chi2 = alg.endswith("-chi2")
+    local = alg.endswith("-local")    # the reference's default linearisation point (LM on the blankets)
     alg = alg.split("-")[0]
     g, which, opts, *_ = util.load_golden("manhattan_nfr_tree" if alg == "nfr" else "manhattan_glc_tree")
     sub, _ = util.prefix_graph(g, which, 70)
     dec = {"online": (onlineDecimate, DecimateOptions(2)), "cluster": (clusterDecimate, DecimateOptions(2, 10))}[profile]
-    so = SparsityOptions(SparsityOptions.Tree, linPoint=SparsityOptions.Global)
+    so = SparsityOptions(SparsityOptions.Tree, linPoint=SparsityOptions.Local if local else SparsityOptions.Global)
     info = EvaluateInfo(dec[0], dec[1], so, alg, kldPeriod=10, useChi2=use_chi2)
     full = GraphWrapperHIP.from_dict(sub, ctx=hip_ctx)     # computeSubstituteEdge walks the full graph (host side)
     got, inc_h, base_h = evaluate(sub, info, lambda glc: GraphWrapperHIP(ctx=hip_ctx, pose_dim=3, useGLC=glc), full)
