@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--poses", type=int, default=100000)
     ap.add_argument("--ring", type=int, default=400)
     ap.add_argument("--sparsity", type=int, default=2)
+    ap.add_argument("--lin-point", choices=["global", "local"], default="global",
+                    help="linearisation point (BASELINE config 5 is Global; local = the reference's default, LM on the blankets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-poses", type=int, default=0, help="0 = full workload")
     args = ap.parse_args()
@@ -76,7 +78,7 @@ def main():
     g = g2o_io.synth_sphere(n_poses=args.poses, ring=args.ring)
     last = int(g["ids"][-1])
     which = np.array(globalDecimate(last, last, DecimateOptions(args.sparsity)), np.int32)
-    opts = abi.make_options(6, abi.ALG_NFR, abi.TOPO_TREE, abi.LIN_GLOBAL)
+    opts = abi.make_options(6, abi.ALG_NFR, abi.TOPO_TREE, abi.LIN_GLOBAL if args.lin_point == "global" else abi.LIN_LOCAL)
 
     n_rep = args.warmup + args.steps
     arena_need = int(len(g["ids"]) * 7 + len(g["edge_ij"]) * 28) * 3
@@ -123,7 +125,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": f"synthetic SE3 sphere-spiral pose graph, {args.poses} poses ({args.poses // args.ring} rings x {args.ring}), "
-                        f"{len(g['edge_ij'])} edges, NFR Tree, Global linearisation point = stored estimates, "
+                        f"{len(g['edge_ij'])} edges, NFR Tree, " + ("Global linearisation point = stored estimates, " if args.lin_point == "global" else "Local linearisation point (10 LM iterations per blanket), ") +
                         f"globalDecimate sparsity {args.sparsity} ({len(which)} removals), marginalizeNoOptimize only",
             "parallelism": "single GPU" if world == 1 else f"replicated graph on {world} GPUs; batches of >= 2048 blankets sharded + one all-gather, narrower batches computed by every rank",
             "rounds": stats["n_rounds"], "removed": removed, "max_blanket": stats["max_blanket"],

@@ -362,29 +362,35 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         T.sync();
         STAMP(25);  // T = Omega J
         if (lm_left > 0) {
-            // LM mode: b_v -= (Omega J_v)^T e and chi2 += e^T Omega e (one lane: this path is rare and short)
-            if (tid == 0) {
+            // LM mode: b_v -= (Omega J_v)^T e and chi2 += e^T Omega e. Lanes own (edge, side, row); the edges
+            // of the chunk are folded in serially so that the sums keep a fixed order.
+            {
                 double c2 = 0;
-                for (int e = 0; e < cnt; e++) {
+                for (int it = tid; it < cnt * D; it += NT) {
+                    int e = it / D, p = it - e * D;
                     if (echv[2 * e] < 0) continue;
                     const double *Om = eO + e * DD, *er_ = eE + e * D;
-                    for (int p = 0; p < D; p++) {
-                        double sacc = 0;
-                        for (int q = 0; q < D; q++) sacc += Om[p * D + q] * er_[q];
-                        c2 += er_[p] * sacc;
-                    }
+                    double sacc = 0;
+#pragma unroll
+                    for (int q = 0; q < D; q++) sacc += Om[p * D + q] * er_[q];
+                    c2 += er_[p] * sacc;
+                }
+                c2 = T.sum(c2);
+                if (tid == 0) xch[0] += c2;
+                for (int e = 0; e < cnt; e++) {
+                    if (echv[2 * e] < 0) continue;   // (uniform: echv is shared)
                     for (int side = 0; side < 2; side++) {
-                        int v = echv[2 * e + side];
-                        if (v < 1) continue;   // the removed vertex (local index 0, m == 1) is fixed
-                        const double *Te = eT + e * 2 * DD + side * DD;
-                        for (int r = 0; r < D; r++) {
+                        const int v = echv[2 * e + side];
+                        if (tid < D && v >= 1) {     // the removed vertex (local 0, m == 1) is fixed
+                            const double *Te = eT + e * 2 * DD + side * DD, *er_ = eE + e * D;
                             double sacc = 0;
-                            for (int p = 0; p < D; p++) sacc += Te[p * D + r] * er_[p];
-                            bnew[(v - 1) * D + r] -= sacc;
+#pragma unroll
+                            for (int p = 0; p < D; p++) sacc += Te[p * D + tid] * er_[p];
+                            bnew[(v - 1) * D + tid] -= sacc;
                         }
+                        T.sync();
                     }
                 }
-                xch[0] += c2;
             }
             T.sync();
         }
@@ -490,10 +496,21 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             bool ok2 = true;
             for (;;) {
                 for (int i = tid; i < nv * PSZ; i += NT) pbak[i] = pose[i];   // push()
-                for (int i = tid; i < n * ld; i += NT) { int r = i / ld, c = i - r * ld; M3[i] = M2[i] + ((r == c && c < n) ? lm_lambda : 0.0); }
                 if (tid == 0) *T.flag = 0;
-                T.sync();
-                chol_lower<NT>(T, M3, n, ld);
+                if (use_wave_hw) {
+                    // small system: (H + lambda I)^-1 by the register-resident Gauss-Jordan of one wavefront
+                    T.sync();
+                    if (tid < 64) {
+                        double ldt_, tri_;
+                        bool okw = wave_spd_inverse(M2, ld, n, tid, lm_lambda, M3, ldt_, tri_);
+                        if (!okw && tid == 0) *T.flag = 1;
+                    }
+                    T.sync();
+                } else {
+                    for (int i = tid; i < n * ld; i += NT) { int r = i / ld, c = i - r * ld; M3[i] = M2[i] + ((r == c && c < n) ? lm_lambda : 0.0); }
+                    T.sync();
+                    chol_lower<NT>(T, M3, n, ld);
+                }
                 ok2 = (*T.flag == 0);
                 T.sync();
                 if (tid == 0) *T.flag = 0;
@@ -504,7 +521,18 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                 T.sync();
             }
             if (!ok2) { lm_redo = true; lm_left = 0; T.sync(); continue; }
-            if (tid == 0) {
+            if (use_wave_hw) {
+                for (int i = tid; i < n; i += NT) {
+                    double sacc = 0;
+                    for (int j = 0; j < n; j++) sacc += M3[i * ld + j] * bcur[j];
+                    xs[i] = sacc;
+                }
+                T.sync();
+                double sc = 0;
+                for (int i = tid; i < n; i += NT) sc += xs[i] * (lm_lambda * xs[i] + bcur[i]);
+                sc = T.sum(sc);
+                if (tid == 0) xch[2] = sc;
+            } else if (tid == 0) {
                 for (int i = 0; i < n; i++) {
                     double sacc = bcur[i];
                     for (int kk = 0; kk < i; kk++) sacc -= M3[i * ld + kk] * xs[kk];
