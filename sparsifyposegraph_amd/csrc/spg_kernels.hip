@@ -1493,15 +1493,15 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     static const int mapped_limit = [] { const char *e = getenv("SPG_MAPPED_DESC"); return e ? atoi(e) : 512; }();
     static const bool bar_ok = [] { const char *e = getenv("SPG_BAR_DESC"); return !(e && e[0] == '0'); }();
     const bool small = (long long)rd->count <= (long long)mapped_limit;
-    const bool via_bar = small && hb->large_bar && bar_ok;
+    bool via_bar = small && hb->large_bar && bar_ok;
     char *st;
+    if (via_bar && tot > S.c_bar) {
+        if (S.d_bar) { HIPCHK(hipFree(S.d_bar)); S.d_bar = nullptr; S.c_bar = 0; }
+        size_t nc = std::max(tot, (size_t)1 << 16);
+        if (hipExtMallocWithFlags(&S.d_bar, nc, hipDeviceMallocFinegrained) == hipSuccess) S.c_bar = nc;
+        else { (void)hipGetLastError(); S.d_bar = nullptr; hb->large_bar = false; via_bar = false; }   // fall back to the mapped staging buffer
+    }
     if (via_bar) {
-        if (tot > S.c_bar) {
-            if (S.d_bar) HIPCHK(hipFree(S.d_bar));
-            size_t nc = std::max(tot, S.c_bar * 2);
-            HIPCHK(hipExtMallocWithFlags(&S.d_bar, nc, hipDeviceMallocFinegrained));
-            S.c_bar = nc;
-        }
         st = (char *)S.d_bar;   // write-only from the host
     } else {
         if (int rc = hb->ensure_stage(S, tot)) return rc;
