@@ -117,6 +117,48 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # N > 1 only, outside the timed region of `value`: two more views of the same machine, each guarded so
+    # that a failure costs a field, not the bench line.
+    multi = {}
+    if world > 1:
+        def timed(fn, reps):
+            fence()
+            t1 = time.perf_counter()
+            res = None
+            for _ in range(reps):
+                res = fn()
+            fence()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cpu" if rehearse else device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()), res
+        try:
+            # (1) one independent 100k-pose graph per GPU, no collective (the reference's job farm runs one
+            #     graph per thread): aggregate nodes/s over all ranks
+            reps = [GraphWrapperHIP.from_dict(g, ctx=ctx) for _ in range(2)]
+            for hg in reps:
+                hg.reserve(arena_need)
+            it = iter(reps)
+            secs, st1 = timed(lambda: next(it).marginalizeNoOptimize(which, opts), len(reps))
+            multi["independent_graphs"] = {"value": world * st1["n_removed"] * len(reps) / secs, "unit": "nodes/s", "scaling": "weak",
+                                           "what": f"{world} x the same workload, one graph per GPU, no collective"}
+        except Exception as e:
+            multi["independent_graphs"] = {"error": str(e)[:200]}
+        try:
+            # (2) a graph whose rounds are wide (2 rings of 100 000 poses: ~50k independent blankets per
+            #     batch), so that every batch IS sharded over the ranks and all-gathered (RCCL over xGMI)
+            gw = g2o_io.synth_sphere(n_poses=200000, ring=100000)
+            ww = np.array([i for i in range(4, 200000) if i % 2], np.int32)
+            hw = [GraphWrapperHIP.from_dict(gw, ctx=ctx) for _ in range(2)]
+            for hg in hw:
+                hg.reserve(int(len(gw["ids"]) * 7 + len(gw["edge_ij"]) * 28) * 3)
+            itw = iter(hw)
+            secs, stw = timed(lambda: marginalize_sharded(next(itw), ww, opts, device=device), len(hw))
+            multi["wide_rounds"] = {"value": stw["n_removed"] * len(hw) / secs, "unit": "nodes/s", "scaling": "strong",
+                                    "removed": stw["n_removed"], "batches": stw["n_rounds"], "kld_sum": stw["kld_sum"],
+                                    "what": "synthetic SE3 graph of 2 rings x 100 000 poses: every batch (~50k blankets) sharded over the ranks + one all-gather"}
+        except Exception as e:
+            multi["wide_rounds"] = {"error": str(e)[:200]}
+
     removed = stats["n_removed"]
     value = removed * args.steps / dt
     out = {
@@ -161,6 +203,8 @@ def main():
             "note": "path is fp64-ALU/latency-bound on paper (SURVEY.md 8d: ~110 flop/B); fp64 vector fraction alongside",
             "fp64_vector_tflops_est": flops, "fp64_vector_frac_est": flops / FP64_VECTOR_PEAK_TFLOPS,
         }
+    if multi:
+        out["multi_gpu"] = multi
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from tests import oracle_lib, util
         gs = g

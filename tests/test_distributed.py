@@ -100,10 +100,12 @@ for case in sys.argv[2:]:
     for thr, stepwise in ((0, True), (0, False)):   # every batch sharded over the two ranks + exchanged
         st = check(g, which, opts, bool(opts.algorithm), thr, stepwise)
     print(f"rank {rank} {case} ok rounds={st['n_rounds']}")
-# default threshold on a graph whose first round is wide enough to be sharded (> 2048 blankets)
-g = g2o_io.synth_sphere(12000, 400)
+# default threshold (2048) on a graph whose rounds are wide enough to be sharded: 2 rings of 6000 poses
+# give batches of ~3000 independent blankets, each split over the two ranks and all-gathered
+g = g2o_io.synth_sphere(12000, 6000)
 which = np.array([i for i in range(4, 12000) if i % 2], np.int32)
 st = check(g, which, abi.make_options(6), False, None, False)
+assert st["n_rounds"] <= 8, st["n_rounds"]
 print(f"rank {rank} synthetic ok rounds={st['n_rounds']}")
 dist.destroy_process_group()
 '''
