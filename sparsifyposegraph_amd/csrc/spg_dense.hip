@@ -68,7 +68,7 @@ struct TileOp {
     int P64, Q64;  // extent in 64-tiles (rows of A / rows of B)
     int tri;       // 1: blockIdx.x enumerates the 128-tile pairs q <= p of a triangle
     int subtract;  // 1: C -= A B^T; 0: C = A B^T (C may alias A: A is consumed before C is written)
-    int kchunks;   // K = 32 * kchunks (2 for a 64-wide panel; 8 for the 256-wide outer block)
+    int kchunks;   // K = 32 * kchunks (2 for a 64-wide panel; 16 for the 512-wide outer block)
 };
 
 constexpr int KC = 32, LDK = 34;
@@ -692,11 +692,11 @@ void launch_tiles(const TileOp &op, hipStream_t s) {
 }
 
 // Blocked right-looking lower Cholesky of the N x N matrix M (N a multiple of 64), in place.
-// Two levels: a 256-wide outer block is factorised as four 64-wide panels (diagonal block in one
+// Two levels: a 512-wide outer block is factorised as eight 64-wide panels (diagonal block in one
 // wavefront, panel solve = product with L_jj^-T, update of the remaining columns of the outer block),
-// then the whole trailing matrix is updated ONCE with K = 256 — the trailing read-modify-write of C is
+// then the whole trailing matrix is updated ONCE with K = 512 — the trailing read-modify-write of C is
 // what bounds a K = 64 update (10 flop/B), and it shrinks with the outer width.
-constexpr int OUTER = 4;   // 64-tiles per outer block
+constexpr int OUTER = 8;   // 64-tiles per outer block
 void potrf_lower(double *M, int N, double *linv /*64*64*/, int *bad, hipStream_t s) {
     const int nt = N / TB;
     const long long ld = N;
