@@ -730,19 +730,32 @@ void potrf_lower(double *M, int N, double *linv /*64*64*/, int *bad, hipStream_t
 }
 
 // Y <- Y * Ls^-T for upper-triangular Y (Ng x Ng, ldy) and lower-triangular Ls (ld), tile-aligned.
+// Same two levels as the factorisation: inside an outer block of OUTER column tiles the columns are
+// scaled (product with L_cc^-T) and the later columns of the block updated with K = 64; the columns to
+// the right of the block take ONE update with K = 64 * OUTER.
 void rsolve_lower_transposed(double *Y, int ldy, const double *Ls, int ld, int Ng, double *linv_all, int *bad, hipStream_t s) {
     const int nt = Ng / TB;
     hipLaunchKernelGGL(diag_potrf_kernel, dim3(nt), dim3(64), 0, s, const_cast<double *>(Ls), ld, linv_all, bad, 0);
-    for (int c = 0; c < nt; c++) {
-        double *col = Y + (long long)c * TB;
-        // rows 0..c of block column c: Y[:, c] <- Y[:, c] * L_cc^-T
-        TileOp scale{col, col, linv_all + (long long)c * TB * TB, (long long)TB * ldy, 0, (long long)TB * ldy, 0, ldy, ldy, TB, c + 1, 1, 0, 0, 2};
-        launch_tiles(scale, s);
-        const int rem = nt - c - 1;
-        if (rem == 0) break;
-        // Y[0..c, c'] -= Y[0..c, c] * Ls[c', c]^T for the block columns c' > c
-        const double *lpanel = Ls + ((long long)(c + 1) * TB * ld + (long long)c * TB);
-        TileOp upd{Y + (long long)(c + 1) * TB, col, lpanel, (long long)TB * ldy, TB, (long long)TB * ldy, (long long)TB * ld, ldy, ldy, ld, c + 1, rem, 0, 1, 2};
+    for (int C0 = 0; C0 < nt; C0 += OUTER) {
+        const int C1 = std::min(nt, C0 + OUTER);
+        for (int c = C0; c < C1; c++) {
+            double *col = Y + (long long)c * TB;
+            // rows 0..c of block column c: Y[:, c] <- Y[:, c] * L_cc^-T
+            TileOp scale{col, col, linv_all + (long long)c * TB * TB, (long long)TB * ldy, 0, (long long)TB * ldy, 0, ldy, ldy, TB, c + 1, 1, 0, 0, 2};
+            launch_tiles(scale, s);
+            const int inner = C1 - c - 1;
+            if (inner > 0) {
+                // Y[0..c, c'] -= Y[0..c, c] * Ls[c', c]^T for the remaining columns c' of the outer block
+                const double *lpanel = Ls + ((long long)(c + 1) * TB * ld + (long long)c * TB);
+                TileOp upd{Y + (long long)(c + 1) * TB, col, lpanel, (long long)TB * ldy, TB, (long long)TB * ldy, (long long)TB * ld, ldy, ldy, ld, c + 1, inner, 0, 1, 2};
+                launch_tiles(upd, s);
+            }
+        }
+        const int rem = nt - C1;
+        if (rem <= 0) break;
+        // Y[0..C1-1, c' >= C1] -= Y[0..C1-1, C0..C1-1] * Ls[c', C0..C1-1]^T   (K = 64 * (C1 - C0))
+        const double *lblock = Ls + ((long long)C1 * TB * ld + (long long)C0 * TB);
+        TileOp upd{Y + (long long)C1 * TB, Y + (long long)C0 * TB, lblock, (long long)TB * ldy, TB, (long long)TB * ldy, (long long)TB * ld, ldy, ldy, ld, C1, rem, 0, 1, 2 * (C1 - C0)};
         launch_tiles(upd, s);
     }
 }
