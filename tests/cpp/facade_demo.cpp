@@ -44,6 +44,27 @@ int main(int argc, char **argv) {
     std::printf("\nedges=%zu kld=%.3e\n", es.size(), w.lastKullbackLeiblerSum());
     // k = 2: a single new edge 0-2 that reproduces the target exactly
     if (es.size() != 1 || es[0].vertices != std::vector<int>({0, 2}) || std::fabs(w.lastKullbackLeiblerSum()) > 1e-9) return 2;
+    // the reference's evaluation flow on a longer chain with a loop closure: optimize() the baseline,
+    // marginalize() a copy (= marginalizeNoOptimize + optimize), global KLD between the two
+    // (GraphWrapperG2O::optimize / ::marginalize / ::kullbackLeibler, src/graph_wrapper_g2o.cpp:250-269,455-463,531-548)
+    spg::GraphWrapperHIP base(6), sparse(6);
+    spg::IsometryXd step(std::vector<double>{0.5, 0.0, 0.0, 0, 0, 0, 1}), closure(std::vector<double>{2.5, 0.05, 0.0, 0, 0, 0, 1});
+    for (spg::GraphWrapperHIP *gw : {&base, &sparse}) {
+        for (int i = 0; i < 6; i++) gw->addVertex(i, spg::IsometryXd(std::vector<double>{0.5 * i + 0.01 * (i % 3), 0.02 * i, 0.0, 0, 0, 0, 1}));
+        for (int i = 0; i + 1 < 6; i++) gw->addEdge(i, i + 1, step, I);
+        gw->addEdge(0, 5, closure, I);
+    }
+    spg_optimize_stats ob = base.optimize();
+    sparse.optimize();
+    sparse.marginalize({2, 4}, opts);
+    spg_kld_terms terms;
+    double kld = base.kullbackLeibler(&sparse, &terms);
+    if (!(ob.chi2_final <= ob.chi2_initial) || sparse.vertices().size() != 4 || !(kld > -1e-9) || terms.n != 6 * 3) {
+        std::printf("pipeline mismatch: chi2 %g -> %g, V = %zu, kld %g, n %lld\n", ob.chi2_initial, ob.chi2_final, sparse.vertices().size(), kld, (long long)terms.n);
+        return 3;
+    }
+    std::printf("optimize chi2 %.4g -> %.4g in %d iterations; marginalize + optimize; global KLD %.4g over %lld variables\n",
+                ob.chi2_initial, ob.chi2_final, ob.iterations, kld, (long long)terms.n);
     std::printf("gpu ok\n");
     return 0;
 }
