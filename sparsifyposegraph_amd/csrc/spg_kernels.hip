@@ -39,6 +39,9 @@ using namespace spgdev;
 namespace {
 
 constexpr int EC = 8;  // edges whose Jacobians are staged per chunk
+// kernel-internal third value of the ALG template parameter: NFR with the blanket-level LM of the Local
+// linearisation point compiled in (its pose-update arithmetic costs ~160 VGPRs; the plain NFR kernel has 84)
+constexpr int SPG_ALG_NFR_LM = 2;
 
 // LDS / workspace carve-up for one blanket (all offsets in doubles). Monotone in k and m, so the
 // layout of the largest blanket of a launch bounds every blanket in it.
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     const bool use_wave_hw = !GWS && (n <= kWaveMax) && !((a.flags >> 17) & 1);
     const bool use_wave = use_wave_hw && (NT == 64);
     // two wavefronts per blanket: the Chow-Liu chain and the gauge chain run side by side (NFR only)
-    const bool split = (NT == 128) && (ALG == SPG_ALG_NFR) && use_wave_hw && !(a.flags & SPG_FLAG_FORCE_EIG);
+    const bool split = (NT == 128) && (ALG != SPG_ALG_GLC) && use_wave_hw && !(a.flags & SPG_FLAG_FORCE_EIG);
     double *xch = smem + L.o_xch;
     double *arena = a.arena;
     double *orec = a.mail ? (a.mail + (bd.out_off - a.mail_base)) : (arena + bd.out_off);
@@ -222,6 +225,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     STAMP(23);  // gathered + cleared
     if (bd.n_edge == 0 || m < 1) { status = SPG_ST_EMPTY_BLANKET; finish(); return; }
     constexpr bool is_glc = (ALG == SPG_ALG_GLC);  // compile-time: the NFR instantiation carries no GLC code
+    constexpr bool has_lm = (ALG == SPG_ALG_NFR_LM);
     if (is_glc && !(a.topology == SPG_TOPO_DENSE || a.topology == SPG_TOPO_TREE)) {
         status = SPG_ST_UNSUPPORTED;  // asserts at src/topology_provider_glc.cpp:107-111
         finish(); return;
@@ -252,7 +256,8 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         if (misc[9]) {
             // some kept vertex sits in several blanket edges: the reference fixes the removed vertex at its
             // current estimate and runs 10 LM iterations on the subgraph (src/vertex_remover.cpp:382-391)
-            lm_left = 10;
+            if constexpr (has_lm) lm_left = 10;
+            else { status = SPG_ST_NEEDS_LOCAL_OPTIMIZATION; finish(); return; }   // (the host launches the LM variant for Local)
         } else {
         if (tid == 0) {
             if (D == 6) {
@@ -311,7 +316,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     int lm_it = 0, lm_q = 0, lm_phase = 0;
     bool lm_redo = false;                 // the tiles hold a rejected trial: assemble once more, then go on
     for (;;) {
-    if (lm_left > 0 || lm_redo) {
+    if (has_lm && (lm_left > 0 || lm_redo)) {
         if (lm_phase > 0 || lm_redo) {
             for (int i = tid; i < n * ld; i += NT) M1[i] = 0.0;
             for (int i = tid; i < nm * ldm; i += NT) Hmm[i] = 0.0;
@@ -332,9 +337,9 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                 if (D == 6) {
                     double Z[kIso];
                     iso_from_tq(rec, Z);
-                    se3_edge_jac(pose + vi * PSZ, pose + vj * PSZ, Z, eJ + tid * 2 * DD, eJ + tid * 2 * DD + DD, lm_left > 0 ? eE + tid * D : nullptr);
+                    se3_edge_jac(pose + vi * PSZ, pose + vj * PSZ, Z, eJ + tid * 2 * DD, eJ + tid * 2 * DD + DD, (has_lm && lm_left > 0) ? eE + tid * D : nullptr);
                 } else {
-                    se2_edge_jac(pose + vi * PSZ, pose + vj * PSZ, rec, eJ + tid * 2 * DD, eJ + tid * 2 * DD + DD, lm_left > 0 ? eE + tid * D : nullptr);
+                    se2_edge_jac(pose + vi * PSZ, pose + vj * PSZ, rec, eJ + tid * 2 * DD, eJ + tid * 2 * DD + DD, (has_lm && lm_left > 0) ? eE + tid * D : nullptr);
                 }
             } else {
                 if (!is_glc) misc[1] = 1;  // GLC edge inside an NFR blanket: no provider applies
@@ -361,7 +366,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         }
         T.sync();
         STAMP(25);  // T = Omega J
-        if (lm_left > 0) {
+        if (has_lm && lm_left > 0) {
             // LM mode: b_v -= (Omega J_v)^T e and chi2 += e^T Omega e. Lanes own (edge, side, row); the edges
             // of the chunk are folded in serially so that the sums keep a fixed order.
             {
@@ -446,7 +451,8 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         }
         }
     }
-    if (lm_redo || lm_left <= 0) break;   // ordinary case: one assembly
+    if (!has_lm || lm_redo || lm_left <= 0) break;   // ordinary case: one assembly
+    if constexpr (has_lm)
     // ---- g2o Levenberg-Marquardt on the blanket, removed vertex fixed (OptimizationAlgorithmLevenberg:
     //      lambda_0 = 1e-5 max diag, <= 10 trials per iteration, rho = (chi2 - chi2') / (x.(lambda x + b) + 1e-3),
     //      good step: lambda *= clamp(1 - (2 rho - 1)^3, 1/3, 2/3); bad step: lambda *= ni, ni *= 2)
@@ -1555,6 +1561,8 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     ka.mail_base = rd->mail_base;
     ka.gws = nullptr; ka.gws_stride = 0;
     ka.topology = o.topology; ka.algorithm = o.algorithm; ka.flags = o.flags; ka.chord_ratio = o.chord_ratio; ka.lin_point = o.lin_point; ka.tag = rd->tag;
+    // Local linearisation point: the kernel variant that carries the blanket-level LM
+    const bool lm = (o.algorithm == SPG_ALG_NFR) && (o.lin_point != SPG_LIN_GLOBAL);
     size_t list_off = 0;
     for (int i = 0; i < NB; i++) {
         int nb = (int)bins[i].list.size();
@@ -1574,9 +1582,12 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
             if (two_waves) {
                 Layout L2 = make_layout(D, 128, bins[i].kmax, bins[i].mmax, o.algorithm, o.topology, bins[i].smax);
                 size_t lds2 = std::min((size_t)(L2.small_doubles + L2.mat_doubles) * 8, (size_t)hb->lds_limit);
-                rc = (D == 6) ? launch_bin<6, 128, false, SPG_ALG_NFR>(hb, S, ka, nb, lds2, bins[i].bytes) : launch_bin<3, 128, false, SPG_ALG_NFR>(hb, S, ka, nb, lds2, bins[i].bytes);
+                if (lm) rc = (D == 6) ? launch_bin<6, 128, false, SPG_ALG_NFR_LM>(hb, S, ka, nb, lds2, bins[i].bytes) : launch_bin<3, 128, false, SPG_ALG_NFR_LM>(hb, S, ka, nb, lds2, bins[i].bytes);
+                else rc = (D == 6) ? launch_bin<6, 128, false, SPG_ALG_NFR>(hb, S, ka, nb, lds2, bins[i].bytes) : launch_bin<3, 128, false, SPG_ALG_NFR>(hb, S, ka, nb, lds2, bins[i].bytes);
             } else if (o.algorithm == SPG_ALG_GLC)
                 rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_GLC>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_GLC>(hb, S, ka, nb, lds, bins[i].bytes);
+            else if (lm)
+                rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_NFR_LM>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_NFR_LM>(hb, S, ka, nb, lds, bins[i].bytes);
             else
                 rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes);
         } else {
@@ -1589,6 +1600,8 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
             ka.gws_stride = (int64_t)stride;
             if (o.algorithm == SPG_ALG_GLC)
                 rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_GLC>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_GLC>(hb, S, ka, nb, lds, bins[i].bytes);
+            else if (lm)
+                rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_NFR_LM>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_NFR_LM>(hb, S, ka, nb, lds, bins[i].bytes);
             else
                 rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes);
         }
