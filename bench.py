@@ -99,6 +99,15 @@ def main():
     from sparsifyposegraph_amd.parallel import marginalize_sharded
 
     ctx = Context(local_rank)  # raises without a gfx950 device: no CPU fallback
+    if numa_note and os.environ.get("SPG_BENCH_PIN_CORE", "0") == "1":
+        # optional (measured inconclusive on shared hosts, hence off): the runtime's helper threads exist now and
+        # keep the whole node; the graph thread itself stays on one core of it (rank-dependent)
+        try:
+            node_cpus = sorted(os.sched_getaffinity(0))
+            os.sched_setaffinity(0, {node_cpus[(2 * local_rank + 1) % len(node_cpus)]})
+            numa_note += ", graph thread on one core"
+        except Exception:
+            pass
     g = g2o_io.synth_sphere(n_poses=args.poses, ring=args.ring)
     last = int(g["ids"][-1])
     which = np.array(globalDecimate(last, last, DecimateOptions(args.sparsity)), np.int32)
