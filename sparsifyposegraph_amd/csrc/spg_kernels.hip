@@ -21,6 +21,7 @@
 // 3x3 / 6x6 information blocks, Jacobians and the n x n tiles (n = d*k) live in LDS; HBM traffic is
 // the algorithmic minimum: every pose and edge record is read once, every new record written once.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -1400,15 +1401,14 @@ static int launch_bin(HipBackend *hb, HipBackend::Slot &S, const KArgs &ka, int 
             HIPCHK(hipEventCreate(&t.b));
         } else { t.a = S.pool.back().first; t.b = S.pool.back().second; S.pool.pop_back(); }
         t.bytes = alg_bytes; t.blankets = nblocks;
-        HIPCHK(hipEventRecord(t.a, S.stream));
-    }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), lds_bytes, S.stream, ka);
-    HIPCHK(hipGetLastError());
-    if (timed) {
-        HIPCHK(hipEventRecord(t.b, S.stream));
+        // one runtime call: the dispatch itself carries the two events (start / stop of this kernel)
+        hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), (uint32_t)lds_bytes, S.stream, t.a, t.b, 0, ka);
+        HIPCHK(hipGetLastError());
         S.pending.push_back(t);
         S.wait_ev = t.b;
     } else {
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), lds_bytes, S.stream, ka);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(S.done, S.stream));
         S.wait_ev = S.done;
     }
