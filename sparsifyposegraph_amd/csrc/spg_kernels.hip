@@ -1407,9 +1407,8 @@ static int launch_bin(HipBackend *hb, HipBackend::Slot &S, const KArgs &ka, int 
         S.pending.push_back(t);
         S.wait_ev = t.b;
     } else {
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), lds_bytes, S.stream, ka);
+        hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), (uint32_t)lds_bytes, S.stream, nullptr, S.done, 0, ka);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(S.done, S.stream));
         S.wait_ev = S.done;
     }
     hb->n_launches++;
