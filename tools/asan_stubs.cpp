@@ -1,0 +1,15 @@
+// stubs of the HIP translation units for a sanitizer build of the host code (CPU only, injected backend)
+#include "spg_internal.h"
+namespace spg {
+int hip_backend_create(int, spg_backend *, char *, size_t) { return SPG_ENODEV; }
+void hip_backend_destroy(spg_backend *) {}
+void *hip_backend_stream(spg_backend *) { return nullptr; }
+const char *hip_backend_error(spg_backend *) { return ""; }
+int hip_backend_launches(spg_backend *) { return 0; }
+int hip_backend_device(spg_backend *) { return -1; }
+void hip_backend_profile(spg_backend *, int) {}
+void hip_backend_profile_read(spg_backend *, double *, double *, long long *, long long *) {}
+int hip_dense_information(void *, const DenseGraphIn &, int, double *, char *, size_t) { return SPG_ENODEV; }
+int hip_dense_kld(void *, const DenseGraphIn &, const DenseGraphIn &, int, int, const int64_t *, const int64_t *, double *, double *, char *, size_t) { return SPG_ENODEV; }
+int hip_dense_optimize(void *, const DenseGraphIn &, int, int, double *, double *, char *, size_t) { return SPG_ENODEV; }
+}
