@@ -13,6 +13,7 @@
 #ifndef SPG_H_
 #define SPG_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -123,6 +124,21 @@ typedef struct spg_ctx spg_ctx;
 /* one context per (host thread, device); owns a HIP stream and scratch. device = HIP ordinal.
  * Fails with SPG_ENODEV when no gfx950 device / code object is available: there is no CPU fallback. */
 int spg_ctx_create(spg_ctx **out, int device);
+/* Multi-GPU form (the reference has no counterpart: one process, no collective): one process per
+ * GPU, rank r of nranks. nccl_unique_id = the SPG_UNIQUE_ID_BYTES bytes rank 0 obtained from spg_get_unique_id and
+ * handed to every rank (any out-of-band channel: a file, MPI, torch.distributed's store); the call runs
+ * ncclCommInitRank (RCCL, bound from librccl.so.1 at this call — single-GPU users never load it) and is
+ * collective over the ranks. NULL id: no communicator (exchange through the caller's callback, or a single rank). */
+#define SPG_UNIQUE_ID_BYTES 128
+int spg_get_unique_id(void *id_out /* SPG_UNIQUE_ID_BYTES */);
+int spg_ctx_create_ranks(spg_ctx **out, int device, int rank, int nranks, const void *nccl_unique_id);
+int spg_ctx_rank(const spg_ctx *ctx);
+int spg_ctx_nranks(const spg_ctx *ctx);
+/* The built-in exchange of one sharded round: in-place ncclAllGather of the nranks equal chunks of
+ * arena[region_off, region_off + nranks*chunk_len) (doubles; rank r owns chunk r) over RCCL / xGMI, on the
+ * context's stream, then a stream synchronisation. What spg_graph_marginalize_ranks does per exchanged batch when
+ * no callback is given. No-op for a context without a communicator. */
+int spg_allgather_region(spg_ctx *ctx, void *arena, int64_t region_off, int64_t chunk_len);
 void spg_ctx_destroy(spg_ctx *ctx);
 const char *spg_last_error(spg_ctx *ctx);
 /* HIP stream the context launches on (hipStream_t as void*), for event timing by the caller */
@@ -160,6 +176,21 @@ void spg_graph_destroy(spg_graph *g);
 int spg_graph_load_g2o(spg_ctx *ctx, const char *path, spg_graph **out);
 /* GraphWrapper::write (src/graph_wrapper_g2o.cpp:467-470) incl. GLC_EDGE records (src/glc_edge.cpp:95-119) */
 int spg_graph_write_g2o(spg_graph *g, const char *path);
+/* GraphWrapper::write(std::ofstream &) (src/graph_wrapper.h:62): the same text into a malloc'ed buffer
+ * (*text, *len bytes, NUL-terminated); release it with spg_free. */
+int spg_graph_write_g2o_mem(spg_graph *g, char **text, size_t *len);
+void spg_free(void *p);
+/* GraphWrapperG2O::clonePortion(maxid) (src/graph_wrapper_g2o.cpp:334-356): a new graph on the same context with
+ * the vertices of id <= maxid (estimates copied) and the edges whose endpoints all satisfy it. The reference then
+ * calls optimize() on the clone; here that is the caller's next call (spg_graph_optimize). */
+int spg_graph_clone_portion(spg_graph *g, int maxid, spg_graph **out);
+/* GraphWrapperG2O::covariance() (src/graph_wrapper_g2o.cpp:368-373): inverse of spg_graph_information, dense on
+ * the device (blocked fp64-MFMA Cholesky, triangular inverse, L^-T L^-1). Same conventions as
+ * spg_graph_information: returns n; the n x n row-major matrix is written if cap >= n*n. */
+int64_t spg_graph_covariance(spg_graph *g, int32_t fixed_id, double *out, int64_t cap);
+/* GraphWrapper::Vertex::edges() (src/graph_wrapper.h:26): indices (into the order of spg_graph_get_edges) of the
+ * live edges incident to vertex id, ascending. Returns the count (writes at most cap). */
+int spg_graph_vertex_edges(spg_graph *g, int id, int32_t *edge_index, int cap);
 /* addVertex / addEdge (src/graph_wrapper_g2o.cpp:214-247). pose/meas as in spg_batch; info = upper triangle */
 int spg_graph_add_vertex(spg_graph *g, int id, const double *pose);
 int spg_graph_add_edge(spg_graph *g, int from, int to, const double *meas, const double *info_upper);
@@ -194,6 +225,10 @@ typedef struct {
     double schedule_seconds; /* part of host_seconds: conflict-free round selection */
     double commit_seconds;   /* part of host_seconds: graph update */
     double launch_seconds;   /* part of device_seconds: descriptor upload + kernel launch calls */
+    int32_t n_batches;         /* batches of blankets handed to the device (a round may be cut into several) */
+    int32_t n_exchanged;       /* batches that were sharded over the ranks and all-gathered */
+    double exchange_seconds;   /* time inside the exchange (collective + its synchronisation) */
+    double exchanged_bytes;    /* bytes all-gathered (whole regions, all ranks' chunks) */
 } spg_marg_stats;
 
 /* GraphWrapperG2O::marginalizeNoOptimize (src/graph_wrapper_g2o.cpp:398-453): removes `which` with
@@ -208,8 +243,15 @@ int spg_graph_marginalize(spg_graph *g, const int32_t *which, int n, const spg_o
  * nranks equal chunks of arena[region_off, region_off + nranks*chunk_len) in place (rank r owns
  * chunk r), e.g. ncclAllGather / torch.distributed.all_gather_into_tensor, and return 0. */
 typedef int (*spg_exchange_fn)(void *user, void *arena, int64_t region_off, int64_t chunk_len, int nranks, int rank);
+/* exchange == NULL with nranks > 1: the built-in RCCL all-gather of the graph's context (spg_ctx_create_ranks with
+ * the same rank / nranks); a callback overrides it (tests: gloo, host staging). */
 int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, int n, const spg_options *opts, int rank, int nranks,
                                 spg_exchange_fn exchange, void *exchange_user, spg_marg_stats *stats);
+/* Which batches are sharded. Default policy (threshold < 0): a cost model — a batch is sharded when the modelled
+ * device time of this rank's slice plus one exchange is below the modelled time of the whole batch on one GPU
+ * (per-blanket chain latency ~ n^2.5, blankets resident per GPU from the LDS carve-up, exchange = latency + bytes /
+ * link rate; constants in csrc/spg_host.cpp). spg_graph_set_shard_threshold(g, n >= 0) replaces it by "at least n
+ * blankets" (0 = always; used by tests). */
 /* per-removed-vertex diagnostics of the last marginalize call, in processing order */
 int spg_graph_last_blanket_count(const spg_graph *g);
 int spg_graph_last_blankets(const spg_graph *g, int32_t *root_id, int32_t *round, int32_t *status,
@@ -278,8 +320,8 @@ typedef struct {
 } spg_round_info;
 int spg_graph_marginalize_begin(spg_graph *g, const int32_t *which, int n, const spg_options *opts,
                                 int rank, int nranks);
-/* rounds with fewer blankets than this are computed redundantly on every rank instead of being
- * sharded + exchanged (default 2048; 0 = always shard) */
+/* n >= 0: rounds with fewer blankets than n are computed redundantly on every rank instead of being sharded +
+ * exchanged (0 = always shard); n < 0 (default): the cost model described at spg_graph_marginalize_ranks */
 int spg_graph_set_shard_threshold(spg_graph *g, int min_blankets);
 /* returns 1 if a round was prepared (info filled), 0 when the removal list is exhausted */
 int spg_graph_round_prepare(spg_graph *g, spg_round_info *info);

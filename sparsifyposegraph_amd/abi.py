@@ -55,7 +55,9 @@ class MargStats(C.Structure):
     _fields_ = [("n_removed", C.c_int32), ("n_rounds", C.c_int32), ("n_new_edges", C.c_int32),
                 ("n_bad_status", C.c_int32), ("max_blanket", C.c_int32), ("n_launches", C.c_int32),
                 ("kld_sum", C.c_double), ("host_seconds", C.c_double), ("device_seconds", C.c_double),
-                ("schedule_seconds", C.c_double), ("commit_seconds", C.c_double), ("launch_seconds", C.c_double)]
+                ("schedule_seconds", C.c_double), ("commit_seconds", C.c_double), ("launch_seconds", C.c_double),
+                ("n_batches", C.c_int32), ("n_exchanged", C.c_int32), ("exchange_seconds", C.c_double),
+                ("exchanged_bytes", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -790,6 +790,53 @@ done:
     return rc;
 }
 
+// GraphWrapperG2O::covariance() (src/graph_wrapper_g2o.cpp:368-373): info.llt().solve(I). Dense on the device:
+// H = L L^T (blocked fp64-MFMA Cholesky), Y = L^-T by the blocked triangular solve on the identity, then
+// Sigma = Y Y^T with one triangular sweep of the tile kernel (K = N). Host output n x n row-major, full symmetric.
+int hip_dense_covariance(void *stream, const DenseGraphIn &in, int n, double *out, char *err, size_t errlen) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = 0;
+    const int N = round_up(std::max(n, 1)), nt = N / TB;
+    GraphBufs gb;
+    DevBuf M, Y, C, linv, linv_all, bad;
+    std::vector<double> h;
+    int h_bad = 0;
+    if (hipMalloc(&M.p, (size_t)N * N * 8) != hipSuccess || hipMalloc(&Y.p, (size_t)N * N * 8) != hipSuccess ||
+        hipMalloc(&C.p, (size_t)N * N * 8) != hipSuccess) {
+        snprintf(err, errlen, "hipMalloc of three %d x %d matrices failed", N, N);
+        return SPG_ENOMEM;
+    }
+    HIPCHK(hipMalloc(&linv.p, TB * TB * 8));
+    HIPCHK(hipMalloc(&linv_all.p, (size_t)nt * TB * TB * 8));
+    HIPCHK(hipMalloc(&bad.p, sizeof(int)));
+    HIPCHK(hipMemsetAsync(M.p, 0, (size_t)N * N * 8, s));
+    HIPCHK(hipMemsetAsync(Y.p, 0, (size_t)N * N * 8, s));
+    HIPCHK(hipMemsetAsync(C.p, 0, (size_t)N * N * 8, s));
+    HIPCHK(hipMemsetAsync(bad.p, 0, sizeof(int), s));
+    if ((rc = stage_graph(in, gb, s))) { snprintf(err, errlen, "staging the graph for dense assembly failed (%d)", rc); goto done; }
+    if (in.D == 6) launch_assemble<6>(gb, (double *)M.p, N, s);
+    else launch_assemble<3>(gb, (double *)M.p, N, s);
+    if (N > n) hipLaunchKernelGGL(pad_identity_kernel, dim3((N - n + 255) / 256), dim3(256), 0, s, (double *)M.p, N, n, N);
+    hipLaunchKernelGGL(pad_identity_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (double *)Y.p, N, 0, N);
+    potrf_lower((double *)M.p, N, (double *)linv.p, (int *)bad.p, s);
+    rsolve_lower_transposed((double *)Y.p, N, (const double *)M.p, N, N, (double *)linv_all.p, (int *)bad.p, s);
+    {
+        TileOp yyt{(double *)C.p, (const double *)Y.p, (const double *)Y.p, (long long)TB * N, TB, (long long)TB * N, (long long)TB * N,
+                   N, N, N, nt, nt, 1, 0, N / KC};
+        launch_tiles(yyt, s);
+    }
+    HIPCHK(hipGetLastError());
+    h.resize((size_t)N * N);
+    HIPCHK(hipMemcpyAsync(h.data(), C.p, (size_t)N * N * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&h_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (h_bad) { snprintf(err, errlen, "covariance: the information matrix is not positive definite"); rc = SPG_ENOTPD; goto done; }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) out[(size_t)i * n + j] = (j <= i) ? h[(size_t)i * N + j] : h[(size_t)j * N + i];
+done:
+    return rc;
+}
+
 // Global KLD. base.pos orders the baseline's variables [marginalised | pad | kept | pad] with the
 // kept block starting at Nm (multiple of 64); other.pos orders other's variables [kept | pad].
 // kept_vpo_*: pose offsets of the kept vertices in both arenas, in kept order.

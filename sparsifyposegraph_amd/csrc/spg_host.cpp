@@ -118,6 +118,8 @@ struct InlVec {
 struct spg_ctx {
     spg_backend be{};
     bool is_hip = false;
+    int rank = 0, nranks = 1;
+    void *rccl = nullptr;         // communicator handle of csrc/spg_rccl.cpp (nullptr: single rank / no id given)
     int tag_counter = 0;          // ready tags are unique per context (its mailboxes are shared by all graphs)
     char err[768] = {0};
 };
@@ -211,13 +213,15 @@ struct spg_graph {
     std::vector<Owner> owners;
     std::vector<int32_t> owner_free, transient;       // free ids; deferred-vertex owners of the last pass
     std::vector<int32_t> Dpool;                       // sets of the deferred-vertex owners, flat
-    int shard_threshold = 2048;
+    int shard_threshold = -1;                         // < 0: cost model (shard_pays); >= 0: minimum blankets
     int round_no = 0, launch_seq = 0;
     bool pipelined = false;                           // two batches in flight (single rank, backend with slots)
     spg_marg_stats stats{};
     double tr_age = 0, tr_wait = 0; long tr_n = 0;   // SPG_TRACE=1: launch->commit-start, wait inside commit
     std::vector<BlanketLog> log;
     std::vector<double> hdr_buf;
+    std::vector<int32_t> live_rank;                   // edge id -> index among live edges (spg_graph_vertex_edges)
+    long n_mutations = 0, live_rank_stamp = -1;       // bumped whenever an edge is added or dies
     // scheduler scratch
     std::vector<int32_t> vstamp, estamp;
     int32_t stamp = 0;
@@ -263,11 +267,47 @@ extern "C" int spg_ctx_create_injected(spg_ctx **out, const spg_backend *backend
     return 0;
 }
 
+extern "C" int spg_get_unique_id(void *id_out) {
+    if (!id_out) return SPG_EINVAL;
+    char err[256];
+    int rc = spg::rccl_get_unique_id(id_out, err, sizeof err);
+    if (rc) fprintf(stderr, "libspg_hip: %s\n", err);
+    return rc;
+}
+
+extern "C" int spg_ctx_create_ranks(spg_ctx **out, int device, int rank, int nranks, const void *nccl_unique_id) {
+    if (!out || nranks < 1 || rank < 0 || rank >= nranks) return SPG_EINVAL;
+    int rc = spg_ctx_create(out, device);
+    if (rc) return rc;
+    spg_ctx *c = *out;
+    c->rank = rank; c->nranks = nranks;
+    if (nccl_unique_id) {
+        rc = spg::rccl_comm_create(device, rank, nranks, nccl_unique_id, &c->rccl, c->err, sizeof c->err);
+        if (rc) {
+            fprintf(stderr, "libspg_hip: %s\n", c->err);
+            spg_ctx_destroy(c);
+            *out = nullptr;
+            return rc;
+        }
+    }
+    return 0;
+}
+extern "C" int spg_ctx_rank(const spg_ctx *c) { return c ? c->rank : 0; }
+extern "C" int spg_ctx_nranks(const spg_ctx *c) { return c ? c->nranks : 0; }
+
+extern "C" int spg_allgather_region(spg_ctx *c, void *arena, int64_t region_off, int64_t chunk_len) {
+    if (!c || !arena || region_off < 0 || chunk_len < 0) return SPG_EINVAL;
+    if (!c->rccl) return 0;
+    return spg::rccl_allgather_f64(c->rccl, arena, region_off, chunk_len, spg::hip_backend_stream(&c->be), c->err, sizeof c->err);
+}
+
 extern "C" void spg_ctx_destroy(spg_ctx *c) {
     if (!c) return;
+    if (c->rccl) spg::rccl_comm_destroy(c->rccl);
     if (c->is_hip) spg::hip_backend_destroy(&c->be);
     delete c;
 }
+extern "C" void spg_free(void *p) { free(p); }
 
 extern "C" const char *spg_last_error(spg_ctx *c) {
     if (!c) return "";
@@ -405,6 +445,7 @@ static int add_edge_idx(spg_graph *g, int kind, int nv, const int32_t *vix, int6
     int32_t eid = (int32_t)g->edges.size();
     if (nv != 2) for (int i = 0; i < nv; i++) g->everts.push_back(vix[i]);
     g->edges.push_back(e);
+    g->n_mutations++;
     for (int i = 0; i < nv; i++) {
         bool dup = false;
         for (int j = 0; j < i; j++) dup |= (vix[j] == vix[i]);
@@ -658,11 +699,27 @@ extern "C" int spg_graph_load_g2o(spg_ctx *ctx, const char *path, spg_graph **ou
     return 0;
 }
 
+static void write_g2o_stream(spg_graph *g, FILE *f);
 extern "C" int spg_graph_write_g2o(spg_graph *g, const char *path) {
     if (!g || !path) return SPG_EINVAL;
     if (int rc = sync_host(g)) return rc;
     FILE *f = fopen(path, "w");
     if (!f) return set_err(g->ctx, SPG_EIO, "cannot open %s for writing", path);
+    write_g2o_stream(g, f);
+    fclose(f);
+    return 0;
+}
+extern "C" int spg_graph_write_g2o_mem(spg_graph *g, char **text, size_t *len) {
+    if (!g || !text || !len) return SPG_EINVAL;
+    if (int rc = sync_host(g)) return rc;
+    *text = nullptr; *len = 0;
+    FILE *f = open_memstream(text, len);
+    if (!f) return set_err(g->ctx, SPG_ENOMEM, "open_memstream failed");
+    write_g2o_stream(g, f);
+    fclose(f);   // finalises *text / *len (NUL-terminated)
+    return 0;
+}
+static void write_g2o_stream(spg_graph *g, FILE *f) {
     std::vector<std::pair<int32_t, int32_t>> order;
     for (size_t i = 0; i < g->vid.size(); i++) if (g->valive[i]) order.push_back({g->vid[i], (int32_t)i});
     std::sort(order.begin(), order.end());
@@ -688,8 +745,53 @@ extern "C" int spg_graph_write_g2o(spg_graph *g, const char *path) {
         }
         fputc('\n', f);
     }
-    fclose(f);
+}
+
+// GraphWrapperG2O::clonePortion (src/graph_wrapper_g2o.cpp:334-356)
+extern "C" int spg_graph_clone_portion(spg_graph *g, int maxid, spg_graph **out) {
+    if (!g || !out || g->active) return SPG_EINVAL;
+    if (int rc = sync_host(g)) return rc;
+    spg_graph *c;
+    if (int rc = spg_graph_create(g->ctx, g->d, &c)) return rc;
+    std::vector<std::pair<int32_t, int32_t>> order;
+    for (size_t i = 0; i < g->vid.size(); i++) if (g->valive[i] && g->vid[i] <= maxid) order.push_back({g->vid[i], (int32_t)i});
+    std::sort(order.begin(), order.end());
+    int rc = 0;
+    for (auto &o : order) if ((rc = spg_graph_add_vertex(c, o.first, g->host.data() + g->vpose[o.second]))) break;
+    std::vector<int32_t> ids;
+    for (size_t ei = 0; ei < g->edges.size() && !rc; ei++) {
+        const GEdge &e = g->edges[ei];
+        if (!e.alive) continue;
+        bool in = true;
+        ids.clear();
+        for (int i = 0; i < e.nv; i++) { int32_t id = g->vid[edge_verts(g, e)[i]]; in &= (id <= maxid); ids.push_back(id); }
+        if (!in) continue;
+        const double *rec = g->host.data() + e.off;
+        if (e.kind == SPG_EDGE_BINARY) rc = spg_graph_add_edge(c, ids[0], ids[1], rec, rec + g->ps);
+        else { int n = g->d * e.nv; rc = spg_graph_add_glc_edge(c, e.nv, ids.data(), (e.len - n) / n, rec, rec + n); }
+    }
+    if (rc) { spg_graph_destroy(c); return rc; }
+    *out = c;
     return 0;
+}
+
+// GraphWrapper::Vertex::edges() (src/graph_wrapper.h:26)
+extern "C" int spg_graph_vertex_edges(spg_graph *g, int id, int32_t *edge_index, int cap) {
+    if (!g || (cap > 0 && !edge_index)) return SPG_EINVAL;
+    auto it = g->vidx.find(id);
+    if (it == g->vidx.end() || !g->valive[it->second]) return set_err(g->ctx, SPG_EINVAL, "no such vertex");
+    std::vector<int32_t> es(g->vr[it->second].adj.begin(), g->vr[it->second].adj.end());
+    std::sort(es.begin(), es.end());
+    // position of an edge in spg_graph_get_edges order = number of live edges before it
+    if (g->live_rank_stamp != g->n_mutations || g->live_rank.size() != g->edges.size()) {
+        g->live_rank.resize(g->edges.size());
+        int32_t r = 0;
+        for (size_t e = 0; e < g->edges.size(); e++) { g->live_rank[e] = r; r += g->edges[e].alive ? 1 : 0; }
+        g->live_rank_stamp = g->n_mutations;
+    }
+    int n = 0;
+    for (int32_t e : es) { if (n < cap) edge_index[n] = g->live_rank[e]; n++; }
+    return n;
 }
 
 // ================================================================================= scheduler
@@ -1000,9 +1102,41 @@ extern "C" int spg_graph_marginalize_begin(spg_graph *g, const int32_t *which, i
 static int prepare_scheduled(spg_graph *g, spg_round_info *info, double t0);
 
 extern "C" int spg_graph_set_shard_threshold(spg_graph *g, int min_blankets) {
-    if (!g || min_blankets < 0) return SPG_EINVAL;
-    g->shard_threshold = min_blankets;
+    if (!g) return SPG_EINVAL;
+    g->shard_threshold = min_blankets < 0 ? -1 : min_blankets;
     return 0;
+}
+
+// Sharding policy for one batch of mutually independent blankets (all ranks evaluate it on identical data, so
+// they agree). Model, per GPU: a blanket of n = d*k target variables is one dependent chain of
+//     t_b = T24 * max(1, n/24)^2.5     (T24 = 45 us: measured chain of a 24 x 24 blanket)
+// and `cap` of them are resident at a time (LDS carve-up: floor(160 KB / tiles) workgroups per CU, at most 6, on
+// 256 CUs; blankets whose tiles live in the L2 workspace: one per CU), so a batch takes
+//     t_local = max(max_b t_b, sum_b t_b / cap_b),
+// and sharded over nr ranks  t_shard = max(max_b t_b, sum_b t_b / (nr cap_b)) + T_x + bytes / BW_x
+// with one all-gather of T_x = 30 us (small-message RCCL latency over xGMI) and BW_x = 100 GB/s towards each rank.
+// Sharding pays iff t_shard < t_local: wide batches of many blankets; narrow ones (a few hundred blankets finish in
+// one chain latency however they are split) are computed redundantly by every rank.
+static bool shard_pays(const spg_graph *g, const Batch &bt) {
+    const int B = (int)bt.rb.size(), nr = g->nranks;
+    if (nr <= 1 || B == 0) return false;
+    if (g->shard_threshold >= 0) return B >= g->shard_threshold;
+    const int d = g->d;
+    double t_sum = 0, t_max = 0, bytes = 0;
+    for (const RoundBlanket &r : bt.rb) {
+        const double n = (double)d * (r.nv - r.n_remove), nm = (double)d * r.n_remove;
+        const double tb = 45e-6 * std::pow(std::max(1.0, n / 24.0), 2.5);
+        const double lds = 8.0 * (3 * n * n + nm * nm + nm * n) + 4096.0;
+        const double per_cu = lds > 160.0 * 1024 ? 1.0 : std::min(6.0, std::floor(160.0 * 1024 / lds));
+        t_sum += tb / (256.0 * per_cu);
+        t_max = std::max(t_max, tb);
+        int32_t nn, nvv; int64_t nl;
+        new_edge_budget(g->opts, d, r.nv - r.n_remove, nn, nvv, nl);
+        bytes += 8.0 * (double)(SPG_OUT_LEN(nn, nvv) + nl);
+    }
+    const double t_local = std::max(t_max, t_sum);
+    const double t_shard = std::max(t_max, t_sum / nr) + 30e-6 + bytes / 100e9;
+    return t_shard < t_local;
 }
 
 extern "C" int spg_graph_round_prepare(spg_graph *g, spg_round_info *info) {
@@ -1022,7 +1156,7 @@ static int prepare_scheduled(spg_graph *g, spg_round_info *info, double t0) {
     if (B == 0) { g->stats.host_seconds += now_s() - t0; return 0; }
     const spg_options &o = g->opts;
     // small rounds are latency-bound: every rank computes them whole, nothing is exchanged
-    const bool sharded = g->nranks > 1 && B >= g->shard_threshold;
+    const bool sharded = shard_pays(g, bt);
     bt.eff_ranks = sharded ? g->nranks : 1;
     bt.eff_rank = sharded ? g->rank : 0;
     const int d = g->d, nr = bt.eff_ranks;
@@ -1127,6 +1261,7 @@ static int prepare_scheduled(spg_graph *g, spg_round_info *info, double t0) {
     bt.rinfo.pad_ = 0;
     if (info) *info = bt.rinfo;
     bt.round_open = true;
+    g->stats.n_batches++;
     g->round_no++;
     bt.round_no = g->round_no;
     bt.seq = g->launch_seq++;
@@ -1262,6 +1397,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
             int32_t eid = redges[ei_];
             GEdge &e = g->edges[eid];
             e.alive = 0;
+            g->n_mutations++;
             g->n_live_e--;
             for (int i = 0; i < e.nv; i++) {
                 auto &av = g->vr[edge_verts(g, e)[i]].adj;
@@ -1344,7 +1480,11 @@ extern "C" int spg_graph_marginalize(spg_graph *g, const int32_t *which, int n, 
 
 extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, int n, const spg_options *opts, int rank, int nranks,
                                            spg_exchange_fn exchange, void *exchange_user, spg_marg_stats *stats) {
-    if (nranks > 1 && !exchange) return SPG_EINVAL;
+    if (!g) return SPG_EINVAL;
+    // no callback: the built-in RCCL all-gather of the context (spg_ctx_create_ranks with the same rank / nranks)
+    const bool builtin = nranks > 1 && !exchange;
+    if (builtin && (!g->ctx->rccl || g->ctx->nranks != nranks || g->ctx->rank != rank))
+        return set_err(g->ctx, SPG_EINVAL, "spg_graph_marginalize_ranks: no exchange callback and the context has no matching RCCL communicator (spg_ctx_create_ranks)");
     int launches0 = (g && g->ctx->is_hip) ? spg::hip_backend_launches(&g->ctx->be) : 0;
     int rc = spg_graph_marginalize_begin(g, which, n, opts, rank, nranks);
     if (rc) return rc;
@@ -1352,9 +1492,15 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
     g->pipelined = g->ctx->be.synchronize_slot && g->ctx->be.mailbox_slot && !(env && env[0] == '1');
     auto do_exchange = [&](Batch &b) -> int {
         if (!b.rinfo.exchange) return 0;
+        double tx = now_s();
         int erc = g->ctx->be.synchronize(g->ctx->be.user);  // this rank's chunk is complete in memory
         if (erc) return erc;
-        return exchange(exchange_user, g->dev, b.rinfo.region_off, b.rinfo.chunk_len, g->nranks, g->rank);
+        erc = builtin ? spg_allgather_region(g->ctx, g->dev, b.rinfo.region_off, b.rinfo.chunk_len)
+                      : exchange(exchange_user, g->dev, b.rinfo.region_off, b.rinfo.chunk_len, g->nranks, g->rank);
+        g->stats.n_exchanged++;
+        g->stats.exchanged_bytes += 8.0 * (double)b.rinfo.chunk_len * g->nranks;
+        g->stats.exchange_seconds += now_s() - tx;
+        return erc;
     };
     if (!g->pipelined) {
         for (;;) {
@@ -1410,7 +1556,7 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
                 g->stats.schedule_seconds += now_s() - t0;
                 if (bt.rb.empty()) {
                     g->stats.host_seconds += now_s() - t0;
-                } else if (g->nranks > 1 && (int)bt.rb.size() >= g->shard_threshold) {
+                } else if (shard_pays(g, bt)) {
                     // a wide batch: worth sharding over the ranks. Finish what is in flight, then run it
                     // as one exchanged round (compute own slice, all-gather, commit).
                     if ((rc = commit_all()) != 0) break;
@@ -1661,79 +1807,96 @@ extern "C" int spg_graph_substitute_edge(spg_graph *g, const int32_t *marginaliz
     if (!g || !from || !to || !meas || !info_upper || (n_marg > 0 && !marginalized)) return SPG_EINVAL;
     if (int rc = sync_host(g)) return rc;
     const int d = g->d, ps = g->ps;
-    std::set<int> marg(marginalized, marginalized + n_marg), visited;
-    std::vector<std::set<int>> frontiers;  // used as a deque: front = index 0
-    std::set<int> newFrontier;
-    const int NONE = 0x7fffffff;
-    int minid = NONE;
-    int toConnect = std::max(*from, *to), toReplace = std::min(*from, *to);
-    auto vix = [&](int id) -> int { auto it = g->vidx.find(id); return (it == g->vidx.end() || !g->valive[it->second]) ? -1 : it->second; };
-    if (vix(toConnect) < 0 || vix(toReplace) < 0) return set_err(g->ctx, SPG_EINVAL, "substitute edge endpoint does not exist");
-    newFrontier.insert(toReplace);
-    visited.insert(toConnect);
-    visited.insert(toReplace);
-    do {
-        if (newFrontier.empty()) return set_err(g->ctx, SPG_EINVAL, "no surviving vertex reachable");
-        frontiers.push_back(newFrontier);
-        newFrontier.clear();
-        for (int r : frontiers.back()) {
-            if (marg.count(r) == 0 && r != *from && r != *to) {
-                minid = std::min(minid, r);
-            } else {
-                int v = vix(r);
-                visited.insert(r);
-                if (v < 0) continue;
-                for (int32_t eid : g->vr[v].adj) {
-                    const GEdge &e = g->edges[eid];
-                    if (e.nv != 2) continue;
-                    int a = g->vid[edge_verts(g, e)[0]], b = g->vid[edge_verts(g, e)[1]];
-                    int other = (a == r) ? b : a;
-                    if (visited.count(other) == 0 && other <= maxid && other != 0) newFrontier.insert(other);
-                }
+    const size_t NV = g->vid.size();
+    auto slot_of = [&](int id) -> int32_t { auto it = g->vidx.find(id); return (it == g->vidx.end() || !g->valive[it->second]) ? -1 : it->second; };
+    const int id_new = std::max(*from, *to), id_gone = std::min(*from, *to);   // the new vertex / its removed neighbour
+    const int32_t s_new = slot_of(id_new), s_gone = slot_of(id_gone);
+    if (s_new < 0 || s_gone < 0) return set_err(g->ctx, SPG_EINVAL, "substitute edge endpoint does not exist");
+    // per-slot flags: bit 0 = removed so far, bit 1 = expanded by the search, bit 2 = queued for the next level
+    std::vector<uint8_t> flag(NV, 0);
+    for (int i = 0; i < n_marg; i++) { int32_t sl = slot_of(marginalized[i]); if (sl >= 0) flag[sl] |= 1; }
+    // Breadth-first levels over vertex slots, every level in ascending id (the reference walks std::set<int>):
+    // level[lvl_off[l] .. lvl_off[l+1]). A vertex that is removed (or an endpoint of the edge) is expanded; the
+    // search stops at the first level that holds a surviving vertex and takes the smallest such id.
+    std::vector<int32_t> level, lvl_off{0}, nextl;
+    level.push_back(s_gone);
+    lvl_off.push_back(1);
+    flag[s_new] |= 2; flag[s_gone] |= 2;
+    int32_t hit = -1;
+    for (;;) {
+        const int32_t lo = lvl_off[lvl_off.size() - 2], hi = lvl_off.back();
+        nextl.clear();
+        for (int32_t p = lo; p < hi; p++) {
+            const int32_t v = level[p];
+            const int id = g->vid[v];
+            if (!(flag[v] & 1) && id != *from && id != *to) {
+                if (hit < 0 || id < g->vid[hit]) hit = v;   // a survivor: candidate for the substitute endpoint
+                continue;
+            }
+            flag[v] |= 2;
+            for (int32_t eid : g->vr[v].adj) {
+                const GEdge &e = g->edges[eid];
+                if (e.nv != 2) continue;
+                const int32_t u = (e.vtx[0] == v) ? e.vtx[1] : e.vtx[0];
+                if ((flag[u] & 2) || g->vid[u] > maxid || g->vid[u] == 0 || (flag[u] & 4)) continue;
+                flag[u] |= 4;
+                nextl.push_back(u);
             }
         }
-    } while (minid == NONE);
-    frontiers.insert(frontiers.begin(), std::set<int>{toConnect});
-    frontiers.pop_back();
-    std::vector<double> covsum((size_t)d * d, 0.0);
-    std::vector<double> m(ps, 0.0), tmp(ps), zi(ps);
-    if (d == 6) m[6] = 1.0;
-    int reach = minid;
-    while (!frontiers.empty()) {
-        std::set<int> last = frontiers.back();
-        frontiers.pop_back();
-        int v = vix(reach);
-        if (v < 0) return set_err(g->ctx, SPG_EINVAL, "substitute path broken");
-        std::vector<int32_t> es(g->vr[v].adj.begin(), g->vr[v].adj.end());
+        if (hit >= 0) break;
+        if (nextl.empty()) return set_err(g->ctx, SPG_EINVAL, "no surviving vertex reachable");
+        std::sort(nextl.begin(), nextl.end(), [&](int32_t a, int32_t b) { return g->vid[a] < g->vid[b]; });
+        for (int32_t u : nextl) flag[u] &= (uint8_t)~4;
+        level.insert(level.end(), nextl.begin(), nextl.end());
+        lvl_off.push_back((int32_t)level.size());
+    }
+    // Walk back from the survivor, level by level towards the new vertex: at each step the lowest-index pose-pose
+    // edge of the current vertex that touches the previous level; measurements compose, covariances add.
+    const int n_levels = (int)lvl_off.size() - 1;   // levels 0 .. n_levels-1; the survivor sits in the last one
+    std::vector<double> cov((size_t)d * d, 0.0), acc(ps, 0.0), nxt(ps), zinv(ps), om((size_t)d * d);
+    if (d == 6) acc[6] = 1.0;
+    std::vector<uint8_t> in_prev(NV, 0);
+    std::vector<int32_t> es;
+    int32_t cur = hit;
+    const bool new_is_from = (*from == id_new);
+    for (int l = n_levels - 2; l >= -1; l--) {
+        // previous level: l >= 0 -> the BFS level; l == -1 -> the new vertex alone
+        if (l >= 0) for (int32_t p = lvl_off[l]; p < lvl_off[l + 1]; p++) in_prev[level[p]] = 1;
+        else in_prev[s_new] = 1;
+        es.assign(g->vr[cur].adj.begin(), g->vr[cur].adj.end());
         std::sort(es.begin(), es.end());
+        bool stepped = false;
         for (int32_t eid : es) {
             const GEdge &e = g->edges[eid];
             if (e.nv != 2 || e.kind != SPG_EDGE_BINARY) continue;
-            int a = g->vid[edge_verts(g, e)[0]], b = g->vid[edge_verts(g, e)[1]];
-            if (!(last.count(a) || last.count(b))) continue;
+            if (!(in_prev[e.vtx[0]] || in_prev[e.vtx[1]])) continue;
             const double *rec = g->host.data() + e.off;
-            std::vector<double> info((size_t)d * d);
-            int pidx = 0;
-            for (int i = 0; i < d; i++) for (int j = i; j < d; j++) { info[(size_t)i * d + j] = info[(size_t)j * d + i] = rec[ps + pidx]; pidx++; }
-            if (!dense_inverse(d, info)) return set_err(g->ctx, SPG_EINVAL, "singular edge information on the substitute path");
-            for (int i = 0; i < d * d; i++) covsum[i] += info[i];
-            if (*from == toConnect) {
-                if (b == reach) pose_compose(d, rec, m.data(), tmp.data());                       // meas = z * meas
-                else { pose_inverse(d, rec, zi.data()); pose_compose(d, zi.data(), m.data(), tmp.data()); }
+            int q = 0;
+            for (int i = 0; i < d; i++) for (int j = i; j < d; j++) { om[(size_t)i * d + j] = om[(size_t)j * d + i] = rec[ps + q]; q++; }
+            if (!dense_inverse(d, om)) return set_err(g->ctx, SPG_EINVAL, "singular edge information on the substitute path");
+            for (int i = 0; i < d * d; i++) cov[i] += om[i];
+            const bool cur_is_head = (e.vtx[1] == cur);   // the edge points at the current vertex
+            if (new_is_from) {
+                if (cur_is_head) pose_compose(d, rec, acc.data(), nxt.data());
+                else { pose_inverse(d, rec, zinv.data()); pose_compose(d, zinv.data(), acc.data(), nxt.data()); }
             } else {
-                if (b == reach) { pose_inverse(d, rec, zi.data()); pose_compose(d, m.data(), zi.data(), tmp.data()); }  // meas *= z^-1
-                else pose_compose(d, m.data(), rec, tmp.data());
+                if (cur_is_head) { pose_inverse(d, rec, zinv.data()); pose_compose(d, acc.data(), zinv.data(), nxt.data()); }
+                else pose_compose(d, acc.data(), rec, nxt.data());
             }
-            m = tmp;
-            reach = (b == reach) ? a : b;
+            acc.swap(nxt);
+            cur = cur_is_head ? e.vtx[0] : e.vtx[1];
+            stepped = true;
             break;
         }
+        if (l >= 0) for (int32_t p = lvl_off[l]; p < lvl_off[l + 1]; p++) in_prev[level[p]] = 0;
+        else in_prev[s_new] = 0;
+        (void)stepped;   // as in the reference, a level without a matching edge is skipped
     }
-    if (!dense_inverse(d, covsum)) return set_err(g->ctx, SPG_EINVAL, "singular covariance sum");
-    int pidx = 0;
-    for (int i = 0; i < d; i++) for (int j = i; j < d; j++) info_upper[pidx++] = 0.5 * (covsum[(size_t)i * d + j] + covsum[(size_t)j * d + i]);
-    for (int i = 0; i < ps; i++) meas[i] = m[i];
-    if (*from == toConnect) *to = minid; else *from = minid;
+    if (!dense_inverse(d, cov)) return set_err(g->ctx, SPG_EINVAL, "singular covariance sum");
+    int q = 0;
+    for (int i = 0; i < d; i++) for (int j = i; j < d; j++) info_upper[q++] = 0.5 * (cov[(size_t)i * d + j] + cov[(size_t)j * d + i]);
+    for (int i = 0; i < ps; i++) meas[i] = acc[i];
+    if (new_is_from) *to = g->vid[hit]; else *from = g->vid[hit];
     return 0;
 }
 
@@ -1806,6 +1969,27 @@ extern "C" int64_t spg_graph_information(spg_graph *g, int32_t fixed_id, double 
     build_dense_stage(g, st);
     g->ctx->err[0] = 0;
     int rc = spg::hip_dense_information(spg::hip_backend_stream(&g->ctx->be), st.in, (int)n, out, g->ctx->err, sizeof g->ctx->err);
+    return rc ? rc : n;
+}
+
+extern "C" int64_t spg_graph_covariance(spg_graph *g, int32_t fixed_id, double *out, int64_t cap) {
+    if (!g || g->active) return SPG_EINVAL;
+    std::vector<int32_t> order = live_vertices_by_id(g);
+    int fixed = resolve_fixed(g, order, fixed_id);
+    if (fixed < 0) return set_err(g->ctx, SPG_EINVAL, "spg_graph_covariance: the fixed vertex is not in the graph");
+    const int64_t n = (int64_t)g->d * ((int64_t)order.size() - 1);
+    if (!out || cap < n * n) return n;
+    if (!g->ctx->is_hip) return set_err(g->ctx, SPG_ESTATE, "spg_graph_covariance needs the HIP backend");
+    if (n > 46000) return set_err(g->ctx, SPG_ECAPACITY, "spg_graph_covariance: dense formulation limited to 46k variables");
+    if (int rc = sync_device(g)) return rc;
+    if (int rc = g->ctx->be.synchronize(g->ctx->be.user)) return rc;
+    DenseStage st;
+    st.pos.assign(g->vid.size(), -1);
+    int p = 0;
+    for (int32_t v : order) if (v != fixed) { st.pos[v] = p; p += g->d; }
+    build_dense_stage(g, st);
+    g->ctx->err[0] = 0;
+    int rc = spg::hip_dense_covariance(spg::hip_backend_stream(&g->ctx->be), st.in, (int)n, out, g->ctx->err, sizeof g->ctx->err);
     return rc ? rc : n;
 }
 

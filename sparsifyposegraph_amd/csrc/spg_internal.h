@@ -29,11 +29,18 @@ struct DenseGraphIn {
     const void *dev_arena = nullptr;    // device arena of the graph
 };
 int hip_dense_information(void *stream, const DenseGraphIn &in, int n, double *out, char *err, size_t errlen);
+int hip_dense_covariance(void *stream, const DenseGraphIn &in, int n, double *out, char *err, size_t errlen);
 int hip_dense_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &other, int n_marg, int n_keep,
                   const int64_t *kept_vpo_base, const int64_t *kept_vpo_other, double *terms, double *seconds,
                   char *err, size_t errlen);
 
 int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iterations, double *stats, double *seconds,
                        char *err, size_t errlen);
+
+// RCCL binding (spg_rccl.cpp): librccl.so.1 is bound with dlopen when the first multi-rank context is created
+int rccl_get_unique_id(void *id_out, char *err, size_t errlen);
+int rccl_comm_create(int device, int rank, int nranks, const void *unique_id, void **handle, char *err, size_t errlen);
+int rccl_allgather_f64(void *handle, void *arena, int64_t region_off, int64_t chunk_len, void *stream, char *err, size_t errlen);
+void rccl_comm_destroy(void *handle);
 
 }  // namespace spg

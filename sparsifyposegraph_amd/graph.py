@@ -193,6 +193,43 @@ class GraphWrapperHIP:
         check(min(int(rc), 0), self.ctx.h, "information")
         return out
 
+    def covariance(self, fixed_id=-1):
+        """GraphWrapperG2O::covariance (src/graph_wrapper_g2o.cpp:368-373): inverse of information(), dense on
+        the device (blocked fp64-MFMA Cholesky, triangular inverse, L^-T L^-1)."""
+        n = self.L.spg_graph_covariance(self.h, int(fixed_id), None, 0)
+        check(min(int(n), 0), self.ctx.h, "covariance")
+        out = np.zeros((int(n), int(n)))
+        rc = self.L.spg_graph_covariance(self.h, int(fixed_id), _p(out, C.c_double), out.size)
+        check(min(int(rc), 0), self.ctx.h, "covariance")
+        return out
+
+    def clonePortion(self, maxid, optimize=True):
+        """GraphWrapperG2O::clonePortion (src/graph_wrapper_g2o.cpp:334-356): vertices / edges up to maxid on the
+        same context; the reference optimises the clone before returning it."""
+        h = C.c_void_p()
+        check(self.L.spg_graph_clone_portion(self.h, int(maxid), C.byref(h)), self.ctx.h, "clonePortion")
+        gw = GraphWrapperHIP(ctx=self.ctx, useGLC=self.useGLC, _handle=h)
+        if optimize and gw.numVertices() > 1 and gw.numEdges() > 0:
+            gw.optimize()
+        return gw
+
+    def vertexEdges(self, vertexid):
+        """GraphWrapper::Vertex::edges() (src/graph_wrapper.h:26): indices into edges() of the edges at the vertex"""
+        n = self.L.spg_graph_vertex_edges(self.h, int(vertexid), None, 0)
+        check(n, self.ctx.h, "vertexEdges")
+        out = np.zeros(max(n, 1), np.int32)
+        check(self.L.spg_graph_vertex_edges(self.h, int(vertexid), _p(out, C.c_int32), n), self.ctx.h, "vertexEdges")
+        return out[:n]
+
+    def writeString(self):
+        """GraphWrapper::write(std::ofstream &) (src/graph_wrapper.h:62): the .g2o text"""
+        txt, ln = C.c_void_p(), C.c_size_t()
+        check(self.L.spg_graph_write_g2o_mem(self.h, C.byref(txt), C.byref(ln)), self.ctx.h, "write")
+        try:
+            return C.string_at(txt.value, ln.value).decode()
+        finally:
+            self.L.spg_free(txt)
+
     def kullbackLeibler(self, other, fixed_id=-1):
         """GraphWrapperG2O::kullbackLeibler(other) called on the baseline
         (src/graph_wrapper_g2o.cpp:531-548). Returns the KLD; the terms are in `last_kld_terms`."""

@@ -19,6 +19,12 @@ _f64p, _i32p, _i64p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c
 SYMBOLS = {
     "spg_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "spg_ctx_create_injected": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(abi.Backend)]),
+    "spg_get_unique_id": (C.c_int, [C.c_void_p]),
+    "spg_ctx_create_ranks": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "spg_ctx_rank": (C.c_int, [C.c_void_p]),
+    "spg_ctx_nranks": (C.c_int, [C.c_void_p]),
+    "spg_allgather_region": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "spg_free": (None, [C.c_void_p]),
     "spg_ctx_destroy": (None, [C.c_void_p]),
     "spg_last_error": (C.c_char_p, [C.c_void_p]),
     "spg_ctx_stream": (C.c_void_p, [C.c_void_p]),
@@ -33,6 +39,10 @@ SYMBOLS = {
     "spg_graph_destroy": (None, [C.c_void_p]),
     "spg_graph_load_g2o": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "spg_graph_write_g2o": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "spg_graph_write_g2o_mem": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "spg_graph_clone_portion": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "spg_graph_covariance": (C.c_int64, [C.c_void_p, C.c_int32, _f64p, C.c_int64]),
+    "spg_graph_vertex_edges": (C.c_int, [C.c_void_p, C.c_int, _i32p, C.c_int]),
     "spg_graph_add_vertex": (C.c_int, [C.c_void_p, C.c_int, _f64p]),
     "spg_graph_add_edge": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _f64p, _f64p]),
     "spg_graph_add_vertices": (C.c_int, [C.c_void_p, C.c_int, _i32p, _f64p]),

@@ -10,6 +10,11 @@ int hip_backend_device(spg_backend *) { return -1; }
 void hip_backend_profile(spg_backend *, int) {}
 void hip_backend_profile_read(spg_backend *, double *, double *, long long *, long long *) {}
 int hip_dense_information(void *, const DenseGraphIn &, int, double *, char *, size_t) { return SPG_ENODEV; }
+int hip_dense_covariance(void *, const DenseGraphIn &, int, double *, char *, size_t) { return SPG_ENODEV; }
+int rccl_get_unique_id(void *, char *, size_t) { return SPG_ENODEV; }
+int rccl_comm_create(int, int, int, const void *, void **, char *, size_t) { return SPG_ENODEV; }
+int rccl_allgather_f64(void *, void *, int64_t, int64_t, void *, char *, size_t) { return SPG_ENODEV; }
+void rccl_comm_destroy(void *) {}
 int hip_dense_kld(void *, const DenseGraphIn &, const DenseGraphIn &, int, int, const int64_t *, const int64_t *, double *, double *, char *, size_t) { return SPG_ENODEV; }
 int hip_dense_optimize(void *, const DenseGraphIn &, int, int, double *, double *, char *, size_t) { return SPG_ENODEV; }
 }
