@@ -144,6 +144,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
+    wprof = ctx.profile_read_worker()
     ctx.profile(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else device)
@@ -207,6 +208,7 @@ def main():
             "kld_sum": stats["kld_sum"], "host_seconds_per_step": stats["host_seconds"], "device_wait_seconds_per_step": stats["device_seconds"],
             "schedule_seconds_per_step": stats["schedule_seconds"], "commit_seconds_per_step": stats["commit_seconds"],
             "launch_seconds_per_step": stats["launch_seconds"], "cpu_affinity": numa_note,
+            "batches": stats["n_batches"], "kernel_launches": stats["n_launches"], "worker": wprof,
         },
     }
     if prof["launches"] > 0 and prof["kernel_ms"] > 0:

@@ -152,6 +152,10 @@ int spg_ctx_synchronize(spg_ctx *ctx);
  * cost more host time than the two records they save.) */
 int spg_ctx_profile(spg_ctx *ctx, int enable);
 int spg_ctx_profile_read(spg_ctx *ctx, double *kernel_ms, double *alg_bytes, int64_t *launches, int64_t *blankets);
+/* the same for the persistent worker kernel (narrow batches are handed to one long-lived kernel per marginalisation
+ * instead of being launched one by one): its runs, their total duration (HIP events around the kernel), the
+ * algorithmic bytes and blankets it processed. Not included in spg_ctx_profile_read. */
+int spg_ctx_profile_read_worker(spg_ctx *ctx, double *kernel_ms, double *alg_bytes, int64_t *runs, int64_t *blankets);
 
 /* VertexRemover::remove restricted to its arithmetic, for B independent blankets at once
  * (replaces src/vertex_remover.cpp:108-132 + src/topology_provider_binary.hpp:23-70 +
@@ -368,9 +372,12 @@ typedef struct {
  * update needs (status, n_new, the new-edge table and the new records in the arena) is in place; the
  * per-blanket KLD [2] — and a status change to SPG_ST_KLD_NOT_PD — may land later, at the latest when
  * the launch has completed. A host that polls the mailbox can therefore commit a batch while its
- * KLD tails are still running. */
+ * KLD tails are still running.
+ * When the record is complete (KLD included) the device overwrites [5] with SPG_FINAL_WORD(tag): a poller treats
+ * either value as "ready", and FINAL as "this record will not change any more". */
 #define SPG_OUT_HDR 6
 #define SPG_READY_WORD(tag) (4503599627370496.0 + (double)(tag))
+#define SPG_FINAL_WORD(tag) (4503599627370496.0 + 4294967296.0 + (double)(tag))
 #define SPG_OUT_LEN(n_new_max, n_new_vert_max) (SPG_OUT_HDR + 4 * (n_new_max) + (n_new_vert_max))
 typedef struct {
     const spg_options *opts;

@@ -25,6 +25,11 @@
 #include <cstring>
 #include <set>
 #include <string>
+#include <thread>
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 #include <unordered_map>
 #include <vector>
 #include "../../include/spg.h"
@@ -171,6 +176,11 @@ struct Batch {
     double t_launch = 0;               // SPG_TRACE=1 diagnostics
     // blankets committed from the mailbox before their KLD tail finished: (log index, mailbox offset)
     std::vector<std::pair<int32_t, int64_t>> kld_pending;
+    // hand-over to the submission thread (pipelined driver): 0 while the batch's descriptors are being written and
+    // handed to the device, 1 once that is done (submit_rc = result); a commit waits for 1
+    alignas(64) std::atomic<int> submitted{1};
+    int submit_rc = 0;
+    char pad_[56];
 };
 
 struct OwnRefT { int32_t oid; uint32_t gen; };
@@ -220,6 +230,22 @@ struct spg_graph {
     double tr_age = 0, tr_wait = 0; long tr_n = 0;   // SPG_TRACE=1: launch->commit-start, wait inside commit
     std::vector<BlanketLog> log;
     std::vector<double> hdr_buf;
+    // Submission thread of the pipelined driver: the graph thread selects and commits, this one writes the descriptors
+    // of a selected batch and hands it to the device (descriptor work + device hand-over are ~25 % of the host time per
+    // batch and need nothing the graph thread mutates: poses, edge records' locations and the batch's own lists)
+    // (every word the two threads exchange sits on its own cache line: the submission thread polls sub_tail, and a line
+    //  shared with anything the graph thread writes per blanket would bounce between the cores all the time)
+    std::thread sub_thread;
+    static constexpr uint32_t SUBQ = 8;
+    bool sub_active = false;
+    struct alignas(64) SubShared {
+        alignas(64) std::atomic<uint32_t> tail{0};    // written by the graph thread
+        alignas(64) Batch *q[SUBQ] = {nullptr};       // written by the graph thread
+        alignas(64) std::atomic<uint32_t> head{0};    // written by the submission thread
+        alignas(64) double seconds = 0;               // submission thread only: time spent (descriptors + hand-over)
+        alignas(64) std::atomic<bool> run{false};
+        char pad_[64];
+    } sub;
     std::vector<int32_t> live_rank;                   // edge id -> index among live edges (spg_graph_vertex_edges)
     long n_mutations = 0, live_rank_stamp = -1;       // bumped whenever an edge is added or dies
     // scheduler scratch
@@ -320,6 +346,13 @@ extern "C" int spg_ctx_synchronize(spg_ctx *c) { return c ? c->be.synchronize(c-
 extern "C" int spg_ctx_profile(spg_ctx *c, int enable) {
     if (!c || !c->is_hip) return SPG_EINVAL;
     spg::hip_backend_profile(&c->be, enable);
+    return 0;
+}
+extern "C" int spg_ctx_profile_read_worker(spg_ctx *c, double *kernel_ms, double *alg_bytes, int64_t *runs, int64_t *blankets) {
+    if (!c || !c->is_hip || !kernel_ms || !alg_bytes || !runs || !blankets) return SPG_EINVAL;
+    long long r = 0, b = 0;
+    spg::hip_backend_profile_read_worker(&c->be, kernel_ms, alg_bytes, &r, &b);
+    *runs = r; *blankets = b;
     return 0;
 }
 extern "C" int spg_ctx_profile_read(spg_ctx *c, double *kernel_ms, double *alg_bytes, int64_t *launches, int64_t *blankets) {
@@ -437,7 +470,14 @@ extern "C" int spg_graph_add_vertex(spg_graph *g, int id, const double *pose) {
     return 0;
 }
 
+static void quiesce_submission(spg_graph *g);
 static int add_edge_idx(spg_graph *g, int kind, int nv, const int32_t *vix, int64_t off, int32_t len) {
+    // the submission thread reads edges[] / everts[] of batches in its queue: never move them under it
+    if (g->sub_active && (g->edges.size() == g->edges.capacity() || (nv != 2 && g->everts.size() + (size_t)nv > g->everts.capacity()))) {
+        quiesce_submission(g);
+        g->edges.reserve(std::max<size_t>(g->edges.capacity() * 2, 1024));
+        g->everts.reserve(std::max<size_t>(g->everts.capacity() * 2 + (size_t)nv, 1024));
+    }
     GEdge e;
     e.kind = (int8_t)kind; e.nv = (int16_t)nv; e.len = len; e.off = off; e.alive = 1;
     if (nv == 2) { e.vtx[0] = vix[0]; e.vtx[1] = vix[1]; }
@@ -1269,30 +1309,106 @@ static int prepare_scheduled(spg_graph *g, spg_round_info *info, double t0) {
     return 1;
 }
 
-// Late results of a batch that was committed by polling: once its launch has completed, pick up the
-// per-blanket KLD (and a possible SPG_ST_KLD_NOT_PD) from the mailbox.
-static int harvest_kld(spg_graph *g, Batch &bt) {
-    if (bt.kld_pending.empty()) return 0;
-    const bool slotted = g->ctx->be.synchronize_slot && g->ctx->be.mailbox_slot;
-    int rc = slotted ? g->ctx->be.synchronize_slot(g->ctx->be.user, bt.slot) : g->ctx->be.synchronize(g->ctx->be.user);
-    if (rc) return rc;
-    const double *mail = slotted ? g->ctx->be.mailbox_slot(g->ctx->be.user, bt.slot) : g->ctx->be.mailbox(g->ctx->be.user);
-    for (auto &pr : bt.kld_pending) {
-        const double *rec = mail + pr.second;
-        BlanketLog &lg = g->log[pr.first];
-        lg.kld = rec[2];
-        lg.status = (int32_t)rec[0];
-        if (std::isfinite(rec[2])) g->stats.kld_sum += rec[2];
+// ---- the same preparation split in two for the pipelined single-rank driver ----------------------------------
+// (1) graph thread: size and allocate the batch's output region (needs g->used / the arena), open the round;
+// (2) submission thread: write the descriptors (fill_descriptors_single) and hand the batch to the device.
+// Returns 1 = prepared, 0 = empty, 2 = the arena has to grow first (nothing may be in flight), < 0 error.
+static int prepare_region_single(spg_graph *g, Batch &bt, double t0) {
+    const int B = (int)bt.rb.size();
+    if (B == 0) { g->stats.host_seconds += now_s() - t0; return 0; }
+    const spg_options &o = g->opts;
+    const int d = g->d;
+    int64_t hdr = 0, body = 0;
+    for (RoundBlanket &r : bt.rb) {
+        // the part of the descriptor the commit needs is computed here, by the thread that commits (the submission
+        // thread derives the same numbers for its own copy and never writes into bt.rb)
+        spg_blanket_desc &bd = r.desc;
+        new_edge_budget(o, d, r.nv - r.n_remove, bd.n_new_max, bd.n_new_vert_max, bd.new_len);
+        bd.out_off = hdr;          // relative for now
+        bd.new_off = body;
+        hdr += SPG_OUT_LEN(bd.n_new_max, bd.n_new_vert_max);
+        body += bd.new_len;
+        r.rank = 0;
     }
-    bt.kld_pending.clear();
-    return 0;
+    const int64_t clen = align_up(std::max<int64_t>(hdr + body, 1), 32);
+    const int64_t region = align_up(g->used, 32), need = region + clen;
+    if (need > g->cap) {
+        for (int bi = 0; bi < spg_graph::NB; bi++) if (&g->bt[bi] != &bt && g->bt[bi].round_open) return 2;
+        if (int rc = arena_ensure(g, need + need / 2)) return rc;
+        if (int rc = sync_device(g)) return rc;
+    }
+    if ((int64_t)g->host.size() < need) {
+        // the graph thread copies out records into the mirror while the submission thread works: grow it generously
+        // here, never under a commit (HostMirror::resize may move the block; only this thread touches it)
+        g->host.resize((size_t)std::max<int64_t>(need, g->cap));
+    }
+    g->used = need;
+    g->dev_synced = need;
+    for (RoundBlanket &r : bt.rb) { r.desc.out_off += region; r.desc.new_off += region + hdr; }
+    bt.eff_ranks = 1; bt.eff_rank = 0;
+    bt.chunk_hdr.assign(1, hdr);
+    bt.rinfo.n_blankets = B; bt.rinfo.my_first = 0; bt.rinfo.my_count = B;
+    bt.rinfo.region_off = region; bt.rinfo.chunk_len = clen; bt.rinfo.exchange = 0; bt.rinfo.pad_ = 0;
+    bt.round_open = true;
+    g->stats.n_batches++;
+    g->round_no++;
+    bt.round_no = g->round_no;
+    bt.seq = g->launch_seq++;
+    g->stats.host_seconds += now_s() - t0;
+    return 1;
 }
 
-extern "C" int spg_graph_round_compute(spg_graph *g) {
-    if (!g || !g->active) return SPG_ESTATE;
-    Batch &bt = *g->B;
-    if (!bt.round_open) return SPG_ESTATE;
-    double t0 = now_s();
+// (2) descriptors of a batch prepared by prepare_region_single. Reads only what the graph thread never changes
+// while the batch is open: poses' offsets, the location / endpoints of existing edges, the batch's own lists.
+static void fill_descriptors_single(spg_graph *g, Batch &bt) {
+    const int B = (int)bt.rb.size(), d = g->d;
+    const spg_options &o = g->opts;
+    bt.h_blk.resize(B);
+    bt.h_vpo.clear(); bt.h_er.clear(); bt.h_ev.clear();
+    if (g->lidx.size() < g->vid.size()) g->lidx.resize(g->vid.size(), -1);
+    std::vector<int32_t> &lidx = g->lidx;
+    const int64_t base = bt.rinfo.region_off, hdr_total = bt.chunk_hdr[0];
+    int64_t hdr = 0, body = 0;
+    for (int b = 0; b < B; b++) {
+        const RoundBlanket &r = bt.rb[b];
+        const int k = r.nv - r.n_remove;
+        const int32_t *rverts = bt.rb_verts.data() + r.vbeg;
+        const int32_t *redges = bt.rb_edges.data() + r.ebeg;
+        spg_blanket_desc &bd = bt.h_blk[b];
+        memset(&bd, 0, sizeof bd);
+        bd.vert_begin = (int32_t)bt.h_vpo.size();
+        bd.n_vert = r.nv;
+        bd.n_remove = r.n_remove;
+        for (int i = 0; i < r.nv; i++) { bt.h_vpo.push_back(g->vpose[rverts[i]]); lidx[rverts[i]] = (int32_t)i; }
+        bd.edge_begin = (int32_t)bt.h_er.size();
+        bd.n_edge = r.ne;
+        int32_t scratch = 0;
+        for (int ei_ = 0; ei_ < r.ne; ei_++) {
+            const GEdge &e = g->edges[redges[ei_]];
+            if (e.kind == SPG_EDGE_GLC) scratch = std::max(scratch, e.len - d * e.nv + e.nv * 2 * d * d);
+            spg_edge_ref er;
+            er.off = e.off; er.len = e.len; er.kind = e.kind; er.vbegin = (int32_t)bt.h_ev.size(); er.nv = e.nv;
+            for (int i = 0; i < e.nv; i++) bt.h_ev.push_back(lidx[edge_verts(g, e)[i]]);
+            bt.h_er.push_back(er);
+        }
+        new_edge_budget(o, d, k, bd.n_new_max, bd.n_new_vert_max, bd.new_len);
+        bd.pad_ = scratch;
+        bd.out_off = base + hdr;
+        hdr += SPG_OUT_LEN(bd.n_new_max, bd.n_new_vert_max);
+        bd.new_off = base + hdr_total + body;
+        body += bd.new_len;
+        bd.tinfo_off = -1;
+    }
+}
+
+static int harvest_kld(spg_graph *g, Batch &bt);
+// graph-thread half of spg_graph_round_compute: launch tag, late results of the slot's previous launch
+static int compute_prologue(spg_graph *g, Batch &bt) {
+    bt.tag = ++g->ctx->tag_counter;
+    return harvest_kld(g, bt);
+}
+// submission-thread half: the round descriptor and the hand-over to the backend
+static int compute_submit(spg_graph *g, Batch &bt) {
     spg_round_desc rd{};
     rd.opts = &g->opts;
     rd.n_blankets = bt.rinfo.n_blankets;
@@ -1305,17 +1421,119 @@ extern "C" int spg_graph_round_compute(spg_graph *g) {
     rd.n_vert_total = (int64_t)bt.h_vpo.size();
     rd.n_edge_total = (int64_t)bt.h_er.size();
     rd.n_edge_vert_total = (int64_t)bt.h_ev.size();
-    // single rank: let the kernel deliver the out records straight into the backend's host mailbox
     rd.mail_base = bt.rinfo.region_off + bt.rinfo.chunk_len * bt.eff_rank;
     rd.mail_len = (bt.eff_ranks == 1 && g->ctx->be.mailbox) ? bt.chunk_hdr[bt.eff_rank] : 0;
     rd.slot = g->pipelined ? bt.slot : 0;
-    bt.tag = ++g->ctx->tag_counter;
     rd.tag = bt.tag;
-    // the mailbox of this slot is about to be rewritten: collect what the previous launch left in it
-    if (int hrc = harvest_kld(g, bt)) return hrc;
     bt.used_mailbox = rd.mail_len > 0;
-    bt.t_launch = t0;
-    int rc = g->ctx->be.run_round(g->ctx->be.user, g->dev, &rd);
+    bt.t_launch = now_s();
+    return g->ctx->be.run_round(g->ctx->be.user, g->dev, &rd);
+}
+
+static void submission_main(spg_graph *g) {
+    uint32_t idle = 0;
+    while (g->sub.run.load(std::memory_order_acquire)) {
+        const uint32_t h = g->sub.head.load(std::memory_order_relaxed);
+        if (h == g->sub.tail.load(std::memory_order_acquire)) {
+            if (++idle > 4096) std::this_thread::yield();
+#if defined(__x86_64__)
+            else __builtin_ia32_pause();
+#endif
+            continue;
+        }
+        idle = 0;
+        Batch *b = g->sub.q[h % spg_graph::SUBQ];
+        const double t0 = now_s();
+        fill_descriptors_single(g, *b);
+        b->submit_rc = compute_submit(g, *b);
+        g->sub.seconds += now_s() - t0;
+        g->sub.head.store(h + 1, std::memory_order_release);
+        b->submitted.store(1, std::memory_order_release);
+    }
+}
+static void submission_start(spg_graph *g) {
+    if (g->sub_active) return;
+    g->sub.head.store(0); g->sub.tail.store(0);
+    g->sub.seconds = 0;
+    g->sub.run.store(true, std::memory_order_release);
+    g->sub_thread = std::thread(submission_main, g);
+    g->sub_active = true;
+#if defined(__linux__)
+    // keep the two threads on neighbouring cores (same L3): the lists one writes and the other reads then move
+    // through the shared cache instead of across the socket. Best effort; only CPUs this process may use.
+    static const bool pin = [] { const char *e = getenv("SPG_PIN_THREADS"); return !(e && e[0] == '0'); }();
+    if (pin) {
+        int cpu = sched_getcpu();
+        cpu_set_t allowed;
+        if (cpu >= 0 && sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+            for (int cand : {cpu ^ 1, cpu + 1, cpu - 1}) {
+                if (cand >= 0 && cand < CPU_SETSIZE && cand != cpu && CPU_ISSET(cand, &allowed)) {
+                    cpu_set_t one;
+                    CPU_ZERO(&one); CPU_SET(cand, &one);
+                    (void)pthread_setaffinity_np(g->sub_thread.native_handle(), sizeof one, &one);
+                    break;
+                }
+            }
+        }
+    }
+#endif
+}
+static void wait_submitted(Batch &b) {
+    uint32_t spins = 0;
+    while (!b.submitted.load(std::memory_order_acquire)) {
+        if (++spins > 4096) std::this_thread::yield();
+#if defined(__x86_64__)
+        else __builtin_ia32_pause();
+#endif
+    }
+}
+static void quiesce_submission(spg_graph *g) {
+    for (int i = 0; i < spg_graph::NB; i++) wait_submitted(g->bt[i]);
+}
+static void submission_stop(spg_graph *g) {
+    if (!g->sub_active) return;
+    quiesce_submission(g);
+    g->sub.run.store(false, std::memory_order_release);
+    g->sub_thread.join();
+    g->sub_active = false;
+    g->stats.launch_seconds += g->sub.seconds;   // (the thread's time is reported as launch_seconds)
+}
+static void submission_push(spg_graph *g, Batch &b) {
+    b.submitted.store(0, std::memory_order_relaxed);
+    b.submit_rc = 0;
+    const uint32_t t = g->sub.tail.load(std::memory_order_relaxed);
+    g->sub.q[t % spg_graph::SUBQ] = &b;
+    g->sub.tail.store(t + 1, std::memory_order_release);
+}
+
+// Late results of a batch that was committed by polling: once its launch has completed, pick up the
+// per-blanket KLD (and a possible SPG_ST_KLD_NOT_PD) from the mailbox.
+static int harvest_kld(spg_graph *g, Batch &bt) {
+    if (bt.kld_pending.empty()) return 0;
+    const bool slotted = g->ctx->be.synchronize_slot && g->ctx->be.mailbox_slot;
+    int rc = slotted ? g->ctx->be.synchronize_slot(g->ctx->be.user, bt.slot) : g->ctx->be.synchronize(g->ctx->be.user);
+    if (rc) return rc;
+    const double *mail = slotted ? g->ctx->be.mailbox_slot(g->ctx->be.user, bt.slot) : g->ctx->be.mailbox(g->ctx->be.user);
+    for (auto &pr : bt.kld_pending) {
+        const double *rec = mail + pr.second;
+        BlanketLog &lg = g->log[pr.first];
+        lg.kld = rec[2];
+        lg.min_gap = rec[3];
+        lg.status = (int32_t)rec[0];
+        if (std::isfinite(rec[2])) g->stats.kld_sum += rec[2];
+    }
+    bt.kld_pending.clear();
+    return 0;
+}
+
+extern "C" int spg_graph_round_compute(spg_graph *g) {
+    if (!g || !g->active) return SPG_ESTATE;
+    Batch &bt = *g->B;
+    if (!bt.round_open) return SPG_ESTATE;
+    double t0 = now_s();
+    // the mailbox of this slot is about to be rewritten: collect what the previous launch left in it
+    if (int hrc = compute_prologue(g, bt)) return hrc;
+    int rc = compute_submit(g, bt);
     g->stats.device_seconds += now_s() - t0;
     g->stats.launch_seconds += now_s() - t0;
     if (rc && g->ctx->is_hip) snprintf(g->ctx->err, sizeof g->ctx->err, "%s", spg::hip_backend_error(&g->ctx->be));
@@ -1327,6 +1545,11 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
     Batch &bt = *g->B;
     if (!bt.round_open) return SPG_ESTATE;
     double t0 = now_s();
+    wait_submitted(bt);   // (pipelined driver: the submission thread may still be handing the batch over)
+    if (bt.submit_rc) {
+        if (g->ctx->is_hip) snprintf(g->ctx->err, sizeof g->ctx->err, "%s", spg::hip_backend_error(&g->ctx->be));
+        return bt.submit_rc;
+    }
     const int nr = bt.eff_ranks;
     const bool slotted = g->pipelined && g->ctx->be.synchronize_slot && g->ctx->be.mailbox_slot;
     const double *mail = nullptr;
@@ -1339,13 +1562,13 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
         // data is complete; the launch itself may still be finishing KLD tails. Bounded spin: after
         // ~5 s fall back to a stream synchronisation, which also surfaces a faulted kernel.
         const int64_t base = bt.rinfo.region_off + bt.rinfo.chunk_len * bt.eff_rank;
-        const double want = SPG_READY_WORD(bt.tag);
+        const double want = SPG_READY_WORD(bt.tag), want_final = SPG_FINAL_WORD(bt.tag);
         const double t_spin = now_s();
         polled = true;
         for (const RoundBlanket &r : bt.rb) {
             const volatile double *flag = mail + (r.desc.out_off - base) + 5;
             uint32_t spins = 0;
-            while (*flag != want) {
+            for (double fv = *flag; fv != want && fv != want_final; fv = *flag) {
                 if ((++spins & 0x3fff) == 0 && now_s() - t_spin > 5.0) { polled = false; break; }
 #if defined(__x86_64__)
                 __builtin_ia32_pause();
@@ -1437,12 +1660,14 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
 
 extern "C" int spg_graph_marginalize_end(spg_graph *g, spg_marg_stats *stats) {
     if (!g || !g->active) return SPG_ESTATE;
+    submission_stop(g);
     g->active = false;
     for (int i = 0; i < spg_graph::NB; i++) (void)harvest_kld(g, g->bt[i]);
     for (int i = 0; i < spg_graph::NB; i++) { g->bt[i].round_open = false; release_batch_owners(g, g->bt[i]); g->bt[i].rb.clear(); }
     for (int32_t oid : g->transient) owner_release(g, oid);
     g->transient.clear();
     g->B = &g->bt[0];
+    if (g->ctx->is_hip) (void)spg::hip_backend_end_of_call(&g->ctx->be);
     if (g->tr_n && getenv("SPG_TRACE"))
         fprintf(stderr, "spg trace: %ld batches; per batch: launch call -> commit start %.1f us, wait for the ready words %.1f us\n",
                 g->tr_n, 1e6 * g->tr_age / g->tr_n, 1e6 * g->tr_wait / g->tr_n);
@@ -1529,12 +1754,29 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
                 if (int c = spg_graph_round_commit(g)) return c;
             }
         };
+        // SPG_HOST_THREADS=2: descriptors + device hand-over on a second host thread. Off by default: measured on the
+        // bench workload it does not pay (33.1 vs 31.9 ms per step with the two threads on neighbouring cores, 48 ms
+        // on different L3s) — a batch waits for its round trip through the device, not for the graph thread.
+        static const bool use_thread = [] { const char *e = getenv("SPG_HOST_THREADS"); return e && e[0] == '2'; }();
         auto launch_batch = [&](Batch &b, double t0) -> int {
             g->B = &b;
+            const bool sharded = shard_pays(g, b);
+            if (use_thread && !sharded) {
+                // descriptors + hand-over on the submission thread; region, tag and late results here
+                int prc = prepare_region_single(g, b, t0);
+                if (prc == 2) {  // the arena has to grow: nothing may be running while it is re-allocated
+                    if (int c = commit_all()) return c;
+                    g->B = &b;
+                    prc = prepare_region_single(g, b, now_s());
+                }
+                if (prc <= 0) return prc;
+                if (int hrc = compute_prologue(g, b)) return hrc;
+                submission_start(g);
+                submission_push(g, b);
+                return 0;
+            }
             int prc = prepare_scheduled(g, nullptr, t0);
             if (prc == 2) {  // the arena has to grow: nothing may be running while it is re-allocated
-                bool was_open = b.round_open;
-                (void)was_open;
                 if (int c = commit_all()) return c;
                 g->B = &b;
                 prc = prepare_scheduled(g, nullptr, now_s());
@@ -1597,6 +1839,7 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
             if ((rc = spg_graph_round_commit(g)) != 0) break;
         }
         // drain on error
+        quiesce_submission(g);
         for (int s_ = 0; s_ < spg_graph::NB; s_++) if (g->bt[s_].round_open) { g->ctx->be.synchronize(g->ctx->be.user); g->bt[s_].round_open = false; }
         g->B = &g->bt[0];
     }

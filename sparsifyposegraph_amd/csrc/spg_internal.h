@@ -15,6 +15,8 @@ int hip_backend_launches(spg_backend *b);
 int hip_backend_device(spg_backend *b);
 void hip_backend_profile(spg_backend *b, int enable);
 void hip_backend_profile_read(spg_backend *b, double *ms, double *bytes, long long *launches, long long *blankets);
+void hip_backend_profile_read_worker(spg_backend *b, double *ms, double *bytes, long long *runs, long long *blankets);
+int hip_backend_end_of_call(spg_backend *b);   // the persistent worker retires (end of a marginalisation)
 
 // Dense global KLD (spg_dense.hip). Host-staged description of one graph for the dense assembly.
 struct DenseGraphIn {

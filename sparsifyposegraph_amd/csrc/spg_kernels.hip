@@ -139,23 +139,61 @@ struct KArgs {
     int64_t mail_base;   // arena offset that maps to mail[0]
 };
 
+// A value every lane holds identically: pin it to scalar registers. The descriptor fields steer every loop bound and
+// tile offset of a blanket; where they arrive through LDS or a stack slot (persistent worker) the compiler would
+// otherwise carry them — and everything derived from them — in vector registers.
+__device__ __forceinline__ int uni32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffu)), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+template <class T>
+__device__ __forceinline__ T *uniptr(T *p) { return reinterpret_cast<T *>(uni64(reinterpret_cast<unsigned long long>(p))); }
+
 // upper-triangular (row-wise) index of (r,c), r <= c
 __device__ __forceinline__ int utri(int r, int c, int D) { return r * D - (r * (r - 1)) / 2 + (c - r); }
 
-template <int D, int NT, bool GWS, int ALG>
-__global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
-    extern __shared__ double smem[];
+// One blanket on one workgroup of NT lanes. bd = its descriptor; bvpo[0..n_vert) the arena offsets of its poses,
+// ber[0..n_edge) its edge references (vbegin indexes bev[]); gws_slot = index of the workgroup's global workspace.
+// Called by blanket_kernel (one launch per batch, descriptors in global memory) and by blanket_worker (persistent
+// workgroups fed through a queue, descriptors staged in LDS).
+// Edge records written by OTHER workgroups of the same kernel (persistent worker: the new edges of earlier blankets)
+// are read with agent-scope loads: each XCD has its own L2, and a line that holds a neighbouring, earlier record may
+// already sit there stale. Launched kernels read them plainly (a kernel boundary lies between writer and reader).
+template <bool COH>
+__device__ __forceinline__ double ldrec(const double *p) {
+    if (COH) return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return *p;
+}
+
+template <int D, int NT, bool GWS, int ALG, bool COH = false>
+__device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanket_desc &bd_in, const int64_t *bvpo_in, const spg_edge_ref *ber_in,
+                                             const int32_t *bev_in, const int gws_slot, double *smem) {
+    KArgs a;
+    a.arena = uniptr(a_in.arena); a.gws = uniptr(a_in.gws); a.mail = uniptr(a_in.mail);
+    a.gws_stride = (int64_t)uni64((unsigned long long)a_in.gws_stride); a.mail_base = (int64_t)uni64((unsigned long long)a_in.mail_base);
+    a.topology = uni32(a_in.topology); a.algorithm = uni32(a_in.algorithm); a.flags = uni32(a_in.flags);
+    a.lin_point = uni32(a_in.lin_point); a.tag = uni32(a_in.tag);
+    a.chord_ratio = __longlong_as_double((long long)uni64((unsigned long long)__double_as_longlong(a_in.chord_ratio)));
+    a.blk = nullptr; a.vpo = nullptr; a.er = nullptr; a.ev = nullptr; a.list = nullptr;
+    spg_blanket_desc bd;
+    bd.vert_begin = 0; bd.edge_begin = 0; bd.new_len = 0;
+    bd.n_vert = uni32(bd_in.n_vert); bd.n_remove = uni32(bd_in.n_remove); bd.n_edge = uni32(bd_in.n_edge);
+    bd.n_new_max = uni32(bd_in.n_new_max); bd.n_new_vert_max = uni32(bd_in.n_new_vert_max); bd.pad_ = uni32(bd_in.pad_);
+    bd.new_off = (int64_t)uni64((unsigned long long)bd_in.new_off); bd.out_off = (int64_t)uni64((unsigned long long)bd_in.out_off);
+    bd.tinfo_off = (int64_t)uni64((unsigned long long)bd_in.tinfo_off);
+    const int64_t *bvpo = uniptr(bvpo_in);
+    const spg_edge_ref *ber = uniptr(ber_in);
+    const int32_t *bev = uniptr(bev_in);
     constexpr int DD = D * D;
     constexpr int PS = (D == 6) ? 7 : 3;    // pose / measurement doubles in the arena
     constexpr int PSZ = (D == 6) ? 12 : 3;  // pose doubles in LDS
     constexpr int REC = PS + D * (D + 1) / 2;
     const int tid = threadIdx.x;
-    const int b = a.list[blockIdx.x];
-    const spg_blanket_desc bd = a.blk[b];
     const int nv = bd.n_vert, m = bd.n_remove, k = nv - m;
     const Layout L = make_layout(D, NT, k, m, ALG, a.topology, bd.pad_);
     const int n = L.n, nm = L.nm, ld = L.ld, ldm = L.ldm;
-    double *mat = GWS ? (a.gws + (size_t)blockIdx.x * (size_t)a.gws_stride) : (smem + L.small_doubles);
+    double *mat = GWS ? (a.gws + (size_t)gws_slot * (size_t)a.gws_stride) : (smem + L.small_doubles);
     double *pose = smem + L.o_pose, *cs = smem + L.o_cs, *ev = smem + L.o_ev, *Sv = smem + L.o_S;
     double *w = smem + L.o_w, *ldb = smem + L.o_ldb, *Lb = smem + L.o_Lb, *nJ = smem + L.o_nJ, *X = smem + L.o_X;
     double *eJ = smem + L.o_eJ, *eO = smem + L.o_eO, *eT = smem + L.o_eT;
@@ -200,8 +238,13 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         published = true;
     };
     auto finish = [&]() {
-        if (!published) { publish(); return; }
-        if (tid == 0) { orec[2] = kld; orec[0] = (double)status; }
+        if (!published) publish();
+        else if (tid == 0) { orec[2] = kld; orec[0] = (double)status; }
+        // the record is complete (KLD and a possible SPG_ST_KLD_NOT_PD included): final word, after a release
+        if (tid == 0) {
+            __threadfence_system();
+            __hip_atomic_store(&orec[5], SPG_FINAL_WORD(a.tag), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     };
     // diagnostic cycle stamps (flags bit 16, needs tinfo_off >= 0): written only to the debug region
     const bool stamping = ((a.flags >> 16) & 1) && bd.tinfo_off >= 0;
@@ -215,7 +258,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     // ---------------------------------------------------------------- gather poses, clear H
     if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0; misc[6] = 0; misc[7] = 0; misc[8] = 0; misc[9] = 0; }
     for (int v = tid; v < nv; v += NT) {
-        const double *p = arena + a.vpo[bd.vert_begin + v];
+        const double *p = arena + bvpo[v];
         if (D == 6) iso_from_tq(p, pose + v * PSZ);
         else { pose[v * PSZ] = p[0]; pose[v * PSZ + 1] = p[1]; pose[v * PSZ + 2] = p[2]; }
     }
@@ -243,9 +286,9 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         for (int v = tid; v < nv; v += NT) cntv[v] = 0;
         T.sync();
         for (int e = tid; e < bd.n_edge; e += NT) {
-            const spg_edge_ref er = a.er[bd.edge_begin + e];
+            const spg_edge_ref er = ber[e];
             if (er.kind != SPG_EDGE_BINARY) { misc[8] = 1; continue; }
-            int vi = a.ev[er.vbegin], vj = a.ev[er.vbegin + 1];
+            int vi = bev[er.vbegin], vj = bev[er.vbegin + 1];
             if (vi != 0) atomicAdd(&cntv[vi], 1);
             if (vj != 0) atomicAdd(&cntv[vj], 1);
         }
@@ -268,8 +311,8 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
             else { pose[0] = 0; pose[1] = 0; pose[2] = 0; }
         }
         for (int e = tid; e < bd.n_edge; e += NT) {
-            const spg_edge_ref er = a.er[bd.edge_begin + e];
-            int vi = a.ev[er.vbegin], vj = a.ev[er.vbegin + 1];
+            const spg_edge_ref er = ber[e];
+            int vi = bev[er.vbegin], vj = bev[er.vbegin + 1];
             const double *rec = arena + er.off;
             if (vi == 0 && vj == 0) continue;
             if (D == 6) {
@@ -330,11 +373,13 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     for (int base = 0; base < bd.n_edge; base += EC) {
         int cnt = min(EC, bd.n_edge - base);
         if (tid < cnt) {
-            const spg_edge_ref er = a.er[bd.edge_begin + base + tid];
+            const spg_edge_ref er = ber[base + tid];
             int vi = 0, vj = 0;
             if (er.kind == SPG_EDGE_BINARY) {
-                vi = a.ev[er.vbegin]; vj = a.ev[er.vbegin + 1];
-                const double *rec = arena + er.off;
+                vi = bev[er.vbegin]; vj = bev[er.vbegin + 1];
+                double rec[PS];
+#pragma unroll
+                for (int i = 0; i < PS; i++) rec[i] = ldrec<COH>(arena + er.off + i);
                 if (D == 6) {
                     double Z[kIso];
                     iso_from_tq(rec, Z);
@@ -350,9 +395,9 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         }
         for (int it = tid; it < cnt * DD; it += NT) {
             int e = it / DD, rc = it - e * DD, r = rc / D, c = rc - r * D;
-            const spg_edge_ref er = a.er[bd.edge_begin + base + e];
+            const spg_edge_ref er = ber[base + e];
             int lo = r < c ? r : c, hi = r < c ? c : r;
-            eO[it] = (er.kind == SPG_EDGE_BINARY) ? arena[er.off + PS + utri(lo, hi, D)] : 0.0;
+            eO[it] = (er.kind == SPG_EDGE_BINARY) ? ldrec<COH>(arena + er.off + PS + utri(lo, hi, D)) : 0.0;
         }
         T.sync();
         STAMP(24);  // jacobians + omega staged
@@ -588,14 +633,14 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
         // Jacobian at the current estimates (src/glc_edge.cpp:40-49, src/glc_reparam_binary.hpp:78-127)
         double *gA = mat + L.o_gA;
         for (int e = 0; e < bd.n_edge; e++) {
-            const spg_edge_ref er = a.er[bd.edge_begin + e];
+            const spg_edge_ref er = ber[e];
             if (er.kind != SPG_EDGE_GLC) continue;
             const int q = er.nv, dq = D * q, rr_ = (er.len - dq) / dq;
             const double *rec = arena + er.off;   // meas (dq) then W (rr_ x dq)
             double *Jb = gA;                      // q x (Ji0 | Jii), 2*DD each
             double *Aw = gA + q * 2 * DD;         // rr_ x dq
             for (int i = tid; i < q; i += NT) {
-                int v0 = a.ev[er.vbegin], vi = a.ev[er.vbegin + i];
+                int v0 = bev[er.vbegin], vi = bev[er.vbegin + i];
                 if (D == 6) {
                     double Z[kIso], Xz[kIso] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
                     iso_from_mqt(rec + 6 * i, Z);
@@ -626,7 +671,7 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
                 int R = it / dq, Cc = it - R * dq;
                 double sacc = 0;
                 for (int p = 0; p < rr_; p++) sacc += Aw[p * dq + R] * Aw[p * dq + Cc];
-                int vR = a.ev[er.vbegin + R / D], vC = a.ev[er.vbegin + Cc / D];
+                int vR = bev[er.vbegin + R / D], vC = bev[er.vbegin + Cc / D];
                 hadd(vR * D + (R % D), vC * D + (Cc % D), sacc);
             }
             T.sync();
@@ -1314,6 +1359,135 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     finish();
 }
 
+// out-of-line entry for the persistent worker: the body keeps its own register allocation (inlined into the worker's
+// ticket loop it spilled 119 VGPRs to scratch)
+template <int D, int ALG>
+__device__ __attribute__((noinline)) void blanket_body_call(const KArgs *a, const spg_blanket_desc *bd, const int64_t *bvpo, const spg_edge_ref *ber,
+                                                           const int32_t *bev, double *smem) {
+    blanket_body<D, 128, false, ALG, true>(*a, *bd, bvpo, ber, bev, 0, uniptr(smem));
+}
+
+template <int D, int NT, bool GWS, int ALG>
+__global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
+    extern __shared__ double smem[];
+    const int b = a.list[blockIdx.x];
+    const spg_blanket_desc bd = a.blk[b];
+    blanket_body<D, NT, GWS, ALG>(a, bd, a.vpo + bd.vert_begin, a.er + bd.edge_begin, a.ev, (int)blockIdx.x, smem);
+}
+
+// ---------------------------------------------------------------------------------- persistent worker
+// Narrow rounds (a few dozen blankets that depend on the previous few dozen) are bound by the launch-to-result latency
+// of a batch, not by arithmetic. For them the device runs ONE long-lived kernel per marginalisation: kWorkerWGs
+// workgroups that take tickets from a queue in fine-grained device memory which the host fills through the PCIe BAR
+// (posted stores: blanket packets, then the item slots, then `tail`). A batch then costs the host a few cache-line
+// writes instead of a kernel launch, and reaches a workgroup ~1-2 us after the store of `tail` instead of ~15 us after
+// hipLaunchKernel. Results travel as before (out records in the pinned host mailbox, ready / final words).
+//
+// Packet of one blanket (8-byte words; written by the host, read with system-scope loads):
+//   [0] arena  [1] mailbox (device address, 0 = none)  [2] mail_base  [3] out_off  [4] new_off  [5] tinfo_off
+//   [6] n_vert | n_remove << 32   [7] n_edge | n_new_max << 32   [8] n_new_vert_max | scratch << 32
+//   [9] topology | flags << 32    [10] lin_point | tag << 32     [11] chord_ratio (f64 bits)
+//   [12] n_words | 0              then vpo[n_vert] (i64), er[n_edge] (spg_edge_ref, 3 words each, vbegin relative to the
+//   packet's ev), ev (i32 pairs)
+constexpr int kQCap = 16384;          // queue slots (items in flight are bounded by the host's four launch slots)
+constexpr int kPktHdr = 13;
+constexpr int kPktWords = 192;        // largest packet a worker stages (1.5 KB of LDS); larger blankets are launched
+constexpr int kPktStride = 64;        // the first pass reads 64 words blindly (packets are kPktWords apart)
+constexpr int kWorkerMaxN = 36;       // largest target dimension n = d*k a worker takes (LDS of the worker is sized for it)
+constexpr int kBells = 16, kBellStride = 512;   // doorbell copies, 4 KB apart (idle workgroups poll: spread them over channels)
+struct WorkQ {
+    unsigned long long stop;          // 1: leave when no published item is left (host)
+    unsigned long long pad[7];
+    unsigned long long tail[kBells * kBellStride];   // items published (host writes every copy in use)
+    unsigned long long item[kQCap];   // device address of the packet of item i (mod kQCap)
+};
+
+__device__ __forceinline__ unsigned long long load_sys(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+
+template <int D, int ALG>
+__global__ void __launch_bounds__(128, 2) blanket_worker(WorkQ *q, unsigned long long *ticket, long long idle_ticks, int n_bells, int lazy) {
+    extern __shared__ double smem[];
+    __shared__ unsigned long long pk[kPktWords];
+    __shared__ unsigned long long s_item;
+    const int tid = threadIdx.x;
+    for (;;) {
+        if (tid == 0) {
+            const unsigned long long my = atomicAdd(ticket, 1ULL);
+            unsigned long long it = 0;
+            long long t0 = wall_clock64();
+            unsigned long long seen = ~0ULL;
+            for (;;) {
+                const unsigned long long tail = __hip_atomic_load(&q->tail[(blockIdx.x % n_bells) * kBellStride], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (tail > my) { it = load_sys(&q->item[my % kQCap]); break; }
+                if (load_sys(&q->stop)) break;
+                if (tail != seen) { seen = tail; t0 = wall_clock64(); }
+                else if (wall_clock64() - t0 > idle_ticks) break;   // the host went away: every wave must be able to leave
+                // the next few tickets poll back to back, the others doze (one poll is an uncached HBM read)
+                const unsigned long long ahead = my - tail;
+                if (lazy) {
+                    if (ahead >= 2) for (int z = 0; z < lazy; z++) __builtin_amdgcn_s_sleep(32);   // lazy x ~0.9 us
+                } else {
+                    if (ahead >= 64) __builtin_amdgcn_s_sleep(64);
+                    else if (ahead >= 4) __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            s_item = it;
+        }
+        __syncthreads();
+        const unsigned long long it = s_item;
+        if (!it) return;
+        const long long t_pick = wall_clock64();
+        const unsigned long long *gp = reinterpret_cast<const unsigned long long *>(it);
+        if (tid < kPktStride) pk[tid] = load_sys(gp + tid);
+        __syncthreads();
+        const int n_words = (int)(uni64(pk[12]) & 0xffffffffu);
+        for (int w = kPktStride + tid; w < n_words && w < kPktWords; w += 128) pk[w] = load_sys(gp + w);
+        // (records written by other workgroups of this kernel are read with agent-scope loads inside the body — an
+        //  agent-scope acquire fence here would also drop the kernel's code and the poses from this XCD's L2 per item)
+        __syncthreads();
+        unsigned long long h[kPktHdr];
+#pragma unroll
+        for (int w = 0; w < kPktHdr; w++) h[w] = uni64(pk[w]);
+        KArgs a;
+        a.arena = reinterpret_cast<double *>(h[0]);
+        a.mail = reinterpret_cast<double *>(h[1]);
+        a.mail_base = (int64_t)h[2];
+        a.blk = nullptr; a.vpo = nullptr; a.er = nullptr; a.ev = nullptr; a.list = nullptr; a.gws = nullptr; a.gws_stride = 0;
+        a.algorithm = ALG == SPG_ALG_GLC ? SPG_ALG_GLC : SPG_ALG_NFR;
+        a.topology = (int)(h[9] & 0xffffffffu); a.flags = (int)(h[9] >> 32);
+        a.lin_point = (int)(h[10] & 0xffffffffu); a.tag = (int)(h[10] >> 32);
+        a.chord_ratio = __longlong_as_double((long long)h[11]);
+        spg_blanket_desc bd;
+        bd.vert_begin = 0; bd.edge_begin = 0;
+        bd.out_off = (int64_t)h[3]; bd.new_off = (int64_t)h[4]; bd.tinfo_off = (int64_t)h[5]; bd.new_len = 0;
+        bd.n_vert = (int)(h[6] & 0xffffffffu); bd.n_remove = (int)(h[6] >> 32);
+        bd.n_edge = (int)(h[7] & 0xffffffffu); bd.n_new_max = (int)(h[7] >> 32);
+        bd.n_new_vert_max = (int)(h[8] & 0xffffffffu); bd.pad_ = (int)(h[8] >> 32);
+        const int64_t *vpo = reinterpret_cast<const int64_t *>(pk + kPktHdr);
+        const spg_edge_ref *er = reinterpret_cast<const spg_edge_ref *>(pk + kPktHdr + bd.n_vert);
+        const int32_t *ev = reinterpret_cast<const int32_t *>(pk + kPktHdr + bd.n_vert + 3 * bd.n_edge);
+        const long long t_body = wall_clock64();
+#ifdef SPG_WORKER_INLINE
+        blanket_body<D, 128, false, ALG, true>(a, bd, vpo, er, ev, 0, smem);
+#else
+        blanket_body_call<D, ALG>(&a, &bd, vpo, er, ev, smem);
+#endif
+        __syncthreads();
+        if ((h[12] >> 32) & 0x40000000u) {
+            // diagnostic (SPG_WORKER_STAMP=1): min_gap slot <- staging ticks + 1e-6 * body ticks (100 MHz wall clock); the final
+            // word is rewritten after it so that the host's late harvest sees the stamp
+            if (tid == 0 && a.mail) {
+                double *orec = a.mail + (bd.out_off - a.mail_base);
+                orec[3] = (double)(t_body - t_pick) + 1e-6 * (double)(wall_clock64() - t_body);   // ticks of 10 ns
+                __threadfence_system();
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // =================================================================================== HIP backend
@@ -1345,6 +1519,13 @@ struct HipBackend {
         hipEvent_t done = nullptr, wait_ev = nullptr;
         void *d_bar = nullptr;                        // fine-grained device memory the host writes through the PCIe BAR
         size_t c_bar = 0;
+        // blankets of the last batch that went through the persistent worker: addresses of their final words in the
+        // pinned mailbox (wait_slot polls them: the slot's buffers may be rewritten once all of them are final)
+        std::vector<const volatile double *> finals;
+        double final_word = 0;
+        void *d_pkt = nullptr;                        // fine-grained device memory for the packets (host writes, BAR)
+        size_t c_pkt = 0;
+        bool stream_dirty = false;                    // something was queued on `stream` since the last wait
         std::vector<Timed> pending;
         // per slot, so that a submission thread working on one slot and the graph thread draining
         // another never share state
@@ -1354,6 +1535,26 @@ struct HipBackend {
     };
     static constexpr int NSLOT = 4;
     Slot slots[NSLOT];
+    // the persistent worker kernel (one per backend, alive between the first narrow batch of a marginalisation and
+    // the next full synchronisation)
+    struct Worker {
+        hipStream_t stream = nullptr;
+        WorkQ *q = nullptr;                           // fine-grained device memory; the host stores through the BAR
+        unsigned long long *ticket = nullptr;         // device memory
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        bool running = false, disabled = false;
+        int D = 0, alg = 0;
+        unsigned long long tail = 0;                  // host copy of q->tail
+        double bytes = 0;                             // algorithmic bytes / blankets handed over since it started
+        long long blankets = 0;
+        int bells = 1, lazy = 0;                     // (more doorbell copies / lazier polls: measured, no effect)
+        int wgs = 256;                                // one per CU: launched kernels must always find room next to it
+        std::chrono::steady_clock::time_point last_push;
+    } worker;
+    int batches_in_call = 0;                          // batches since the last full synchronisation
+    int worker_cooldown = 0;                          // batches to go before the worker is considered again
+    double prof_worker_ms = 0, prof_worker_bytes = 0;
+    long long prof_worker_runs = 0, prof_worker_blankets = 0;
     int lds_limit = 160 * 1024;
     bool large_bar = false;       // the host can store straight into device memory (hipDeviceAttributeIsLargeBar)
     std::atomic<int> n_launches{0};
@@ -1365,21 +1566,41 @@ struct HipBackend {
     int ensure(Slot &S, void **p, size_t *cap, size_t need) {
         if (need <= *cap) return 0;
         size_t nc = std::max(need, *cap * 2);
-        if (*p) { HIPCHK(hipStreamSynchronize(S.stream)); HIPCHK(hipFree(*p)); *p = nullptr; }
+        if (*p) { if (int rc = worker_stop()) return rc; HIPCHK(hipStreamSynchronize(S.stream)); HIPCHK(hipFree(*p)); *p = nullptr; }
         HIPCHK(hipMalloc(p, nc));
         *cap = nc;
         return 0;
     }
     int wait_slot(Slot &S) {
         if (S.wait_ev) { HIPCHK(hipEventSynchronize(S.wait_ev)); S.wait_ev = nullptr; }
-        else HIPCHK(hipStreamSynchronize(S.stream));
+        else if (S.stream_dirty) HIPCHK(hipStreamSynchronize(S.stream));
+        S.stream_dirty = false;
+        if (!S.finals.empty()) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (const volatile double *p : S.finals) {
+                uint32_t spins = 0;
+                while (*p != S.final_word) {
+                    if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+                        snprintf(err, sizeof err, "persistent worker: a blanket did not complete within 10 s");
+                        return SPG_EHIP;
+                    }
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            S.finals.clear();
+        }
         S.busy = false;
         return 0;
     }
+    int worker_stop();
+    int worker_start(int D, int alg);
     int ensure_stage(Slot &S, size_t need) {
         if (need <= S.c_stage) return 0;
         size_t nc = std::max(need, S.c_stage * 2);
-        if (S.h_stage) { HIPCHK(hipStreamSynchronize(S.stream)); HIPCHK(hipHostFree(S.h_stage)); S.h_stage = nullptr; }
+        if (S.h_stage) { if (int rc = worker_stop()) return rc; HIPCHK(hipStreamSynchronize(S.stream)); HIPCHK(hipHostFree(S.h_stage)); S.h_stage = nullptr; }
         HIPCHK(hipHostMalloc(&S.h_stage, nc, hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer(&S.d_stage, S.h_stage, 0));
         S.c_stage = nc;
@@ -1412,6 +1633,79 @@ static int launch_bin(HipBackend *hb, HipBackend::Slot &S, const KArgs &ka, int 
         S.wait_ev = S.done;
     }
     hb->n_launches++;
+    S.stream_dirty = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- worker control (host)
+static inline void bar_fence() {
+    std::atomic_thread_fence(std::memory_order_release);
+#if defined(__x86_64__)
+    __builtin_ia32_sfence();   // write-combining buffers drained: stores through the BAR leave in program order
+#endif
+}
+
+template <int D, int ALG>
+static int launch_worker(HipBackend *hb, size_t lds) {
+    char *err = hb->err;
+    auto kern = blanket_worker<D, ALG>;
+    if (lds > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long idle_ticks = 10LL * 100000000LL;   // 10 s of the 100 MHz wall clock
+    hipExtLaunchKernelGGL(kern, dim3(hb->worker.wgs), dim3(128), (uint32_t)lds, hb->worker.stream, hb->worker.ev_a, hb->worker.ev_b, 0,
+                          hb->worker.q, hb->worker.ticket, idle_ticks, hb->worker.bells, hb->worker.lazy);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int HipBackend::worker_start(int D, int alg) {
+    Worker &W = worker;
+    if (W.running && W.D == D && W.alg == alg) {
+        // an idle worker leaves by itself after 10 s without a new item (every wave needs an exit the host cannot
+        // withhold): after a pause of more than 1 s retire it and start a fresh one rather than trust a half-gone grid
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - W.last_push).count() < 1.0) return 0;
+    }
+    if (W.running) if (int rc = worker_stop()) return rc;
+    if (!W.stream) {
+        HIPCHK(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&W.ev_a));
+        HIPCHK(hipEventCreate(&W.ev_b));
+        if (hipExtMallocWithFlags((void **)&W.q, sizeof(WorkQ), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); W.disabled = true; return 1; }
+        HIPCHK(hipMalloc((void **)&W.ticket, 64));
+        const char *e = getenv("SPG_WORKER_WGS");
+        if (e && atoi(e) > 0) W.wgs = atoi(e);
+        if ((e = getenv("SPG_WORKER_BELLS")) && atoi(e) >= 1 && atoi(e) <= kBells) W.bells = atoi(e);
+        if ((e = getenv("SPG_WORKER_LAZY")) && atoi(e) >= 0) W.lazy = atoi(e);
+    }
+    for (int c = 0; c < W.bells; c++) W.q->tail[c * kBellStride] = 0;     // through the BAR
+    W.q->stop = 0;
+    bar_fence();
+    W.tail = 0; W.bytes = 0; W.blankets = 0;
+    HIPCHK(hipMemsetAsync(W.ticket, 0, 64, W.stream));
+    // LDS of the largest blanket a worker takes: n <= kWaveMax, one removed vertex, the two-wavefront carve-up
+    Layout L = make_layout(D, 128, kWorkerMaxN / D, 1, alg, SPG_TOPO_TREE, 0);
+    const size_t lds = (size_t)(L.small_doubles + L.mat_doubles) * 8;
+    int rc = (D == 6) ? launch_worker<6, SPG_ALG_NFR>(this, lds) : launch_worker<3, SPG_ALG_NFR>(this, lds);
+    if (rc) return rc;
+    W.running = true; W.D = D; W.alg = alg;
+    W.last_push = std::chrono::steady_clock::now();
+    n_launches++;
+    return 0;
+}
+
+int HipBackend::worker_stop() {
+    Worker &W = worker;
+    if (!W.running) return 0;
+    W.q->stop = 1;
+    bar_fence();
+    HIPCHK(hipStreamSynchronize(W.stream));
+    W.running = false;
+    if (profiling) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, W.ev_a, W.ev_b) == hipSuccess) {
+            prof_worker_ms += ms; prof_worker_bytes += W.bytes; prof_worker_runs++; prof_worker_blankets += W.blankets;
+        }
+    }
     return 0;
 }
 
@@ -1490,6 +1784,108 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     drain_profile(hb, S);
     S.busy = true;
     LP(1);
+    // ---- narrow batch: hand the blankets to the persistent worker instead of launching
+    // While the worker runs nothing else is submitted to the device: HIP multiplexes streams onto a few hardware queues
+    // and a dispatch queued behind the never-ending worker kernel would wait for it. So a batch goes to the worker
+    // whole (every blanket eligible) or the worker is retired first and the batch is launched as before.
+    static const bool worker_env = [] { const char *e = getenv("SPG_WORKER"); return !(e && e[0] == '0'); }();
+    static const bool worker_stamp = [] { const char *e = getenv("SPG_WORKER_STAMP"); return e && e[0] == '1'; }();
+    // (not for the first two batches after a synchronisation: a call that removes a handful of vertices, e.g. online
+    //  decimation, is cheaper as a plain launch than as worker start + stop)
+    hb->batches_in_call++;
+    bool to_worker = worker_env && hb->large_bar && !hb->worker.disabled && rd->mail_len > 0 && o.algorithm == SPG_ALG_NFR &&
+                     o.lin_point == SPG_LIN_GLOBAL && o.flags == 0 && rd->count <= 512 && !hb->force_one_wave &&
+                     hb->worker_cooldown == 0 && (hb->batches_in_call > 2 || hb->worker.running);
+    if (hb->worker_cooldown > 0) hb->worker_cooldown--;
+    if (to_worker) {
+        // eligible: pose-pose edges only, one removed vertex, n <= kWorkerMaxN, packet fits the staging area
+        for (int b = rd->first; b < rd->first + rd->count && to_worker; b++) {
+            const spg_blanket_desc &bd = rd->blankets[b];
+            const int k = bd.n_vert - bd.n_remove;
+            int nev = 0;
+            bool bin = true;
+            for (int e = bd.edge_begin; e < bd.edge_begin + bd.n_edge; e++) { nev += rd->edges[e].nv; bin &= (rd->edges[e].kind == SPG_EDGE_BINARY); }
+            const int words = kPktHdr + bd.n_vert + 3 * bd.n_edge + (nev + 1) / 2;
+            to_worker = bin && bd.n_remove == 1 && k >= 1 && D * k <= kWorkerMaxN && words <= kPktWords && bd.tinfo_off < 0;
+        }
+        if (!to_worker) hb->worker_cooldown = 8;   // mixed batches: stay with launches for a while rather than stop / start per batch
+    }
+    if (to_worker) {
+        const size_t n_push = (size_t)rd->count;
+        int wrc = 0;
+        const size_t need = n_push * (size_t)kPktWords * 8, mneed = (size_t)rd->mail_len * 8;
+        if (need > S.c_pkt || mneed > S.c_mail) {
+            if (int rc2 = hb->worker_stop()) return rc2;   // hipFree waits for the device: nothing may be spinning on it
+            if (need > S.c_pkt) {
+                if (S.d_pkt) { HIPCHK(hipFree(S.d_pkt)); S.d_pkt = nullptr; S.c_pkt = 0; }
+                size_t nc = std::max(need, (size_t)512 * kPktWords * 8);
+                if (hipExtMallocWithFlags(&S.d_pkt, nc, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); hb->worker.disabled = true; }
+                else S.c_pkt = nc;
+            }
+            if (mneed > S.c_mail) {
+                if (S.h_mail) HIPCHK(hipHostFree(S.h_mail));
+                size_t nc = std::max(mneed, S.c_mail * 2);
+                HIPCHK(hipHostMalloc(&S.h_mail, nc, hipHostMallocMapped));
+                HIPCHK(hipHostGetDevicePointer(&S.d_mail, S.h_mail, 0));
+                memset(S.h_mail, 0, nc);
+                S.c_mail = nc;
+            }
+        }
+        if (!hb->worker.disabled) wrc = hb->worker_start(D, SPG_ALG_NFR);
+        if (wrc < 0) return wrc;
+        if (wrc == 0 && !hb->worker.disabled) {
+            HipBackend::Worker &W = hb->worker;
+            unsigned long long *pbase = (unsigned long long *)S.d_pkt;
+            const double *hmail = (const double *)S.h_mail;
+            S.final_word = SPG_FINAL_WORD(rd->tag);
+            double wbytes = 0;
+            for (size_t i = 0; i < n_push; i++) {
+                const int32_t b = rd->first + (int32_t)i;
+                const spg_blanket_desc &bd = rd->blankets[b];
+                unsigned long long pkt[kPktWords];
+                int nev = 0;
+                for (int e = bd.edge_begin; e < bd.edge_begin + bd.n_edge; e++) nev += rd->edges[e].nv;
+                const int words = kPktHdr + bd.n_vert + 3 * bd.n_edge + (nev + 1) / 2;
+                auto pack = [](int lo, int hi) { return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)hi << 32); };
+                pkt[0] = (unsigned long long)(uintptr_t)arena;
+                pkt[1] = (unsigned long long)(uintptr_t)S.d_mail;
+                pkt[2] = (unsigned long long)rd->mail_base;
+                pkt[3] = (unsigned long long)bd.out_off; pkt[4] = (unsigned long long)bd.new_off; pkt[5] = (unsigned long long)bd.tinfo_off;
+                pkt[6] = pack(bd.n_vert, bd.n_remove); pkt[7] = pack(bd.n_edge, bd.n_new_max); pkt[8] = pack(bd.n_new_vert_max, bd.pad_);
+                pkt[9] = pack(o.topology, o.flags); pkt[10] = pack(o.lin_point, rd->tag);
+                memcpy(&pkt[11], &o.chord_ratio, 8);
+                pkt[12] = pack(words, nev | (worker_stamp ? 0x40000000 : 0));
+                int w = kPktHdr;
+                for (int v = 0; v < bd.n_vert; v++) pkt[w++] = (unsigned long long)rd->vert_pose_off[bd.vert_begin + v];
+                int32_t *evp = (int32_t *)(pkt + kPktHdr + bd.n_vert + 3 * bd.n_edge);
+                int evn = 0;
+                double by = 8.0 * ((D == 6) ? 7 : 3) * bd.n_vert + 12.0 + 8.0 * bd.new_len;
+                for (int e = bd.edge_begin; e < bd.edge_begin + bd.n_edge; e++) {
+                    spg_edge_ref er = rd->edges[e];
+                    for (int t = 0; t < er.nv; t++) evp[evn + t] = rd->edge_vert[er.vbegin + t];
+                    er.vbegin = evn;
+                    evn += er.nv;
+                    memcpy(&pkt[w], &er, 24);
+                    w += 3;
+                    by += 4.0 * er.nv + 8.0 * er.len;
+                }
+                if (evn & 1) evp[evn] = 0;
+                wbytes += by;
+                unsigned long long *dst = pbase + i * (size_t)kPktWords;
+                memcpy(dst, pkt, (size_t)words * 8);                       // through the BAR (write-combined)
+                W.q->item[(W.tail + i) % kQCap] = (unsigned long long)(uintptr_t)dst;
+                S.finals.push_back(hmail + (bd.out_off - rd->mail_base) + 5);
+            }
+            bar_fence();
+            W.tail += n_push;
+            for (int c = 0; c < W.bells; c++) W.q->tail[c * kBellStride] = W.tail;   // the doorbells
+            bar_fence();
+            W.last_push = std::chrono::steady_clock::now();
+            W.bytes += wbytes; W.blankets += (long long)n_push;
+            return 0;                                                      // the whole batch is with the worker
+        }
+    }
+    if (int rcw = hb->worker_stop()) return rcw;                           // a launch follows: the worker must not be in its way
     // Where the descriptors of this launch go:
     //  - small launch, large-BAR system: the host stores them straight into (fine-grained) device memory —
     //    posted writes ahead of the doorbell, no copy engine hop, and the kernel reads local HBM;
@@ -1501,7 +1897,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     bool via_bar = small && hb->large_bar && bar_ok;
     char *st;
     if (via_bar && tot > S.c_bar) {
-        if (S.d_bar) { HIPCHK(hipFree(S.d_bar)); S.d_bar = nullptr; S.c_bar = 0; }
+        if (S.d_bar) { if (int rc = hb->worker_stop()) return rc; HIPCHK(hipFree(S.d_bar)); S.d_bar = nullptr; S.c_bar = 0; }
         size_t nc = std::max(tot, (size_t)1 << 16);
         if (hipExtMallocWithFlags(&S.d_bar, nc, hipDeviceMallocFinegrained) == hipSuccess) S.c_bar = nc;
         else { (void)hipGetLastError(); S.d_bar = nullptr; hb->large_bar = false; via_bar = false; }   // fall back to the mapped staging buffer
@@ -1540,6 +1936,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     if (rd->mail_len > 0) {
         size_t need = (size_t)rd->mail_len * 8;
         if (need > S.c_mail) {
+            if (int rc = hb->worker_stop()) return rc;
             if (S.h_mail) HIPCHK(hipHostFree(S.h_mail));
             size_t nc = std::max(need, S.c_mail * 2);
             HIPCHK(hipHostMalloc(&S.h_mail, nc, hipHostMallocMapped));
@@ -1623,12 +2020,14 @@ static void *hip_alloc(void *user, int64_t doubles) {
 }
 static void hip_release(void *user, void *p) {
     HipBackend *hb = (HipBackend *)user;
+    (void)hb->worker_stop();   // hipFree waits for the whole device
     (void)hipStreamSynchronize(hb->slots[0].stream);
     (void)hipFree(p);
 }
 static int hip_upload(void *user, void *dst, const double *src, int64_t doubles) {
     HipBackend *hb = (HipBackend *)user;
     char *err = hb->err;
+    if (int rcw = hb->worker_stop()) return rcw;
     HIPCHK(hipMemcpyAsync(dst, src, (size_t)doubles * 8, hipMemcpyHostToDevice, hb->slots[0].stream));
     HIPCHK(hipStreamSynchronize(hb->slots[0].stream));
     return 0;
@@ -1636,6 +2035,7 @@ static int hip_upload(void *user, void *dst, const double *src, int64_t doubles)
 static int hip_download(void *user, double *dst, const void *src, int64_t doubles) {
     HipBackend *hb = (HipBackend *)user;
     char *err = hb->err;
+    if (int rcw = hb->worker_stop()) return rcw;
     HIPCHK(hipMemcpyAsync(dst, src, (size_t)doubles * 8, hipMemcpyDeviceToHost, hb->slots[0].stream));
     HIPCHK(hipStreamSynchronize(hb->slots[0].stream));
     return 0;
@@ -1644,11 +2044,13 @@ static int hip_sync(void *user) {
     HipBackend *hb = (HipBackend *)user;
     char *err = hb->err;
     for (auto &S : hb->slots) {
-        if (S.busy || S.wait_ev) { if (int rcw = hb->wait_slot(S)) return rcw; }
+        if (S.busy || S.wait_ev || !S.finals.empty()) { if (int rcw = hb->wait_slot(S)) return rcw; }
         else HIPCHK(hipStreamSynchronize(S.stream));   // copies issued outside hip_run_round
         drain_profile(hb, S);
     }
-    return 0;
+    // a full synchronisation leaves the device idle: the persistent worker retires (it restarts on demand)
+    hb->batches_in_call = 0;
+    return hb->worker_stop();
 }
 static int hip_sync_slot(void *user, int slot) {
     HipBackend *hb = (HipBackend *)user;
@@ -1709,7 +2111,14 @@ void hip_backend_destroy(spg_backend *b) {
     HipBackend *hb = (HipBackend *)b->user;
     if (!hb) return;
     (void)hipSetDevice(hb->device);
+    (void)hb->worker_stop();
+    if (hb->worker.q) (void)hipFree(hb->worker.q);
+    if (hb->worker.ticket) (void)hipFree(hb->worker.ticket);
+    if (hb->worker.ev_a) (void)hipEventDestroy(hb->worker.ev_a);
+    if (hb->worker.ev_b) (void)hipEventDestroy(hb->worker.ev_b);
+    if (hb->worker.stream) (void)hipStreamDestroy(hb->worker.stream);
     for (auto &S : hb->slots) {
+        if (S.d_pkt) (void)hipFree(S.d_pkt);
         (void)hipStreamSynchronize(S.stream);
         if (S.d_desc) (void)hipFree(S.d_desc);
         if (S.d_gws) (void)hipFree(S.d_gws);
@@ -1736,6 +2145,18 @@ void hip_backend_profile(spg_backend *b, int enable) {
     hb->prof_stride = enable > 1 ? enable : 1;   // enable = n > 1: HIP events around every n-th launch only
     hb->prof_tick = 0;
     for (auto &S : hb->slots) { S.prof_ms = S.prof_bytes = 0; S.prof_launches = S.prof_blankets = 0; }
+    hb->prof_worker_ms = hb->prof_worker_bytes = 0; hb->prof_worker_runs = hb->prof_worker_blankets = 0;
+}
+void hip_backend_profile_read_worker(spg_backend *b, double *ms, double *bytes, long long *runs, long long *blankets) {
+    HipBackend *hb = (HipBackend *)b->user;
+    if (!hb) return;
+    *ms = hb->prof_worker_ms; *bytes = hb->prof_worker_bytes; *runs = hb->prof_worker_runs; *blankets = hb->prof_worker_blankets;
+}
+int hip_backend_end_of_call(spg_backend *b) {
+    HipBackend *hb = (HipBackend *)b->user;
+    if (!hb) return 0;
+    hb->batches_in_call = 0;
+    return hb->worker_stop();
 }
 void hip_backend_profile_read(spg_backend *b, double *ms, double *bytes, long long *launches, long long *blankets) {
     HipBackend *hb = (HipBackend *)b->user;

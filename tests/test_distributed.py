@@ -100,13 +100,19 @@ for case in sys.argv[2:]:
     for thr, stepwise in ((0, True), (0, False)):   # every batch sharded over the two ranks + exchanged
         st = check(g, which, opts, bool(opts.algorithm), thr, stepwise)
     print(f"rank {rank} {case} ok rounds={st['n_rounds']}")
-# default threshold (2048) on a graph whose rounds are wide enough to be sharded: 2 rings of 6000 poses
-# give batches of ~3000 independent blankets, each split over the two ranks and all-gathered
+# a blanket-count threshold (2048) on a graph whose rounds are wide: 2 rings of 6000 poses give batches of ~3000
+# independent blankets, each split over the two ranks and all-gathered
 g = g2o_io.synth_sphere(12000, 6000)
 which = np.array([i for i in range(4, 12000) if i % 2], np.int32)
+st = check(g, which, abi.make_options(6), False, 2048, False)
+assert st["n_rounds"] <= 8 and st["n_exchanged"] >= 2, st
+# the default policy (cost model, include/spg.h): at two ranks a batch has to be ~5000 blankets wide before
+# halving its device time buys more than one exchange costs; 2 rings of 24000 poses give batches of ~12000
+g = g2o_io.synth_sphere(48000, 24000)
+which = np.array([i for i in range(4, 48000) if i % 2], np.int32)
 st = check(g, which, abi.make_options(6), False, None, False)
-assert st["n_rounds"] <= 8, st["n_rounds"]
-print(f"rank {rank} synthetic ok rounds={st['n_rounds']}")
+assert st["n_exchanged"] >= 1 and st["n_exchanged"] < st["n_batches"], st
+print(f"rank {rank} synthetic ok rounds={st['n_rounds']} exchanged={st['n_exchanged']} of {st['n_batches']}")
 dist.destroy_process_group()
 '''
 
