@@ -156,6 +156,10 @@ int spg_ctx_profile_read(spg_ctx *ctx, double *kernel_ms, double *alg_bytes, int
  * instead of being launched one by one): its runs, their total duration (HIP events around the kernel), the
  * algorithmic bytes and blankets it processed. Not included in spg_ctx_profile_read. */
 int spg_ctx_profile_read_worker(spg_ctx *ctx, double *kernel_ms, double *alg_bytes, int64_t *runs, int64_t *blankets);
+/* and for the large-blanket pipeline (GLC Dense blankets beyond the LDS kernel's capacity run dense in HBM on the fp64
+ * matrix cores): blankets processed since the last spg_ctx_profile call, their total device time (HIP events), the
+ * n^3-class flops of their factorisations, the largest (k + m) * pose_dim seen. */
+int spg_ctx_profile_read_big(spg_ctx *ctx, double *kernel_ms, double *flops, int64_t *blankets, int32_t *n_max);
 
 /* VertexRemover::remove restricted to its arithmetic, for B independent blankets at once
  * (replaces src/vertex_remover.cpp:108-132 + src/topology_provider_binary.hpp:23-70 +

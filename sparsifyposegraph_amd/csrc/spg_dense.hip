@@ -625,6 +625,258 @@ __global__ void pose_diff_kernel(const double *arena_b, const int64_t *vpo_b, co
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ large blankets
+// GLC Dense on a blanket too large for the LDS kernel (clusters of an SE3 lattice reach k + m = 150-200
+// vertices, n + nm ~ 1000): the same steps as VertexRemover::remove + TopologyProviderGLC::getEdge on dense matrices
+// in HBM, the O(n^3) parts on the fp64 matrix cores (tile_abt_kernel):
+//   H over [removed | kept]            dense_assemble_kernel (binary + n-ary GLC edges)        src/vertex_remover.cpp:397-402
+//   Lambda_t = H_kk - H_mk^T H_mm^-1 H_mk   blocked right-looking Cholesky stopped at the kept block: what it has
+//                                      made of that block by then IS the Schur complement              :409-449
+//   J = d reparam / d x (block arrow), T = J^-1 (block arrow too), M = sym(T^T Lambda_t T)            topology_provider_glc.cpp:73-84
+//   W with W^T W = M                   the reference takes eig(M) and keeps lambda >= 1e-8 (:59-71). M is exactly
+//                                      [0 0; 0 M_rel] (a blanket of relative measurements carries no absolute information
+//                                      on its first vertex), so W = [0 | L^T] with M_rel = L L^T — the blocked fp64-MFMA
+//                                      Cholesky again — has the same W^T W whenever every eigenvalue of M_rel passes the
+//                                      cut; that is PROVEN per blanket by trace(M_rel^-1) = ||L^-1||_F^2 < 1e8
+//                                      (=> lambda_min > 1e-8). Otherwise the blanket reports SPG_ST_EIG_FAIL: the
+//                                      truncating eigen-decomposition of a rank-deficient n ~ 1000 target is not built.
+struct BigArrow {
+    double *Jinv;      // k x 2 x DD: per kept vertex i the blocks (T_i0 | T_ii) of T = J^-1 (vertex 0: (unused | T_00))
+    double *meas;      // n: reparametrised measurement
+};
+
+// partial-pivot Gauss-Jordan inverse of a D x D block in registers (Eigen PartialPivLU::inverse on the full J reduces to
+// these blocks for a block-arrow matrix)
+template <int D>
+__device__ __forceinline__ bool small_inverse(const double *A, double *X) {
+    double a[D * D], x[D * D];
+#pragma unroll
+    for (int i = 0; i < D * D; i++) { a[i] = A[i]; x[i] = ((i / D) == (i % D)) ? 1.0 : 0.0; }
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+        int p = c;
+        double best = fabs(a[c * D + c]);
+#pragma unroll
+        for (int r = 0; r < D; r++) if (r > c && fabs(a[r * D + c]) > best) { best = fabs(a[r * D + c]); p = r; }
+        if (!(best > 0.0)) ok = false;
+#pragma unroll
+        for (int r = 0; r < D; r++) if (r == p && p != c) {
+#pragma unroll
+            for (int j = 0; j < D; j++) { double t = a[c * D + j]; a[c * D + j] = a[r * D + j]; a[r * D + j] = t; t = x[c * D + j]; x[c * D + j] = x[r * D + j]; x[r * D + j] = t; }
+        }
+        double ip = 1.0 / a[c * D + c];
+#pragma unroll
+        for (int j = 0; j < D; j++) { a[c * D + j] *= ip; x[c * D + j] *= ip; }
+#pragma unroll
+        for (int r = 0; r < D; r++) if (r != c) {
+            double f = a[r * D + c];
+#pragma unroll
+            for (int j = 0; j < D; j++) { a[r * D + j] -= f * a[c * D + j]; x[r * D + j] -= f * x[c * D + j]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D * D; i++) X[i] = x[i];
+    return ok;
+}
+
+// GLCReparamBinary (src/glc_reparam_binary.hpp:35-127) for the k kept vertices (arena poses at vpo[m + i]): the
+// measurement and the blocks of T = J^-1. One lane per vertex.
+template <int D>
+__global__ void big_reparam_kernel(const double *arena, const int64_t *vpo, int m, int k, BigArrow out, int *bad) {
+    constexpr int DD = D * D, PSZ = (D == 6) ? kIso : 3;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    double X0[PSZ], Xi[PSZ], Ji[DD], Jj[DD];
+    load_pose<D>(arena, vpo[m], X0);
+    load_pose<D>(arena, vpo[m + i], Xi);
+    double *ms = out.meas + i * D;
+    if (D == 6) {
+        double Z[kIso], qv[4];
+        if (i == 0) {
+            double Xz[kIso] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < kIso; t++) Z[t] = X0[t];
+            se3_edge_jac(Xz, X0, Z, Ji, Jj, nullptr);
+        } else {
+            iso_inv_mul(X0, Xi, Z);
+            se3_edge_jac(X0, Xi, Z, Ji, Jj, nullptr);
+        }
+        R_to_quat(Z, qv);
+        ms[0] = Z[9]; ms[1] = Z[10]; ms[2] = Z[11]; ms[3] = qv[0]; ms[4] = qv[1]; ms[5] = qv[2];
+    } else {
+        double z[3], xz[3] = {0, 0, 0};
+        const double *xa = (i == 0) ? xz : X0;
+        se2_between(xa, Xi, z);
+        z[2] = normalize_theta(z[2]);
+        se2_edge_jac(xa, Xi, z, Ji, Jj, nullptr);
+        ms[0] = z[0]; ms[1] = z[1]; ms[2] = z[2];
+    }
+    // row i of J: (J_i0 = Ji | J_ii = Jj), row 0: J_00 = Jj. T_ii = J_ii^-1, T_i0 = -J_ii^-1 J_i0 J_00^-1 (second factor below)
+    double Tii[DD];
+    if (!small_inverse<D>(Jj, Tii)) *bad = 1;
+    double *dst = out.Jinv + (size_t)i * 2 * DD;
+    double Tmp[DD];
+#pragma unroll
+    for (int r = 0; r < D; r++)
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+            double sacc = 0;
+#pragma unroll
+            for (int p = 0; p < D; p++) sacc += Tii[r * D + p] * Ji[p * D + c];
+            Tmp[r * D + c] = (i == 0) ? 0.0 : -sacc;     // -J_ii^-1 J_i0 (times J_00^-1 in big_arrow_finish_kernel)
+        }
+#pragma unroll
+    for (int t = 0; t < DD; t++) { dst[t] = Tmp[t]; dst[DD + t] = Tii[t]; }
+}
+// T_i0 <- T_i0 * T_00 for i > 0
+template <int D>
+__global__ void big_arrow_finish_kernel(int k, BigArrow out) {
+    constexpr int DD = D * D;
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const double *T00 = out.Jinv + DD;
+    double *Ti0 = out.Jinv + (size_t)i * 2 * DD;
+    double A[DD], R[DD];
+#pragma unroll
+    for (int t = 0; t < DD; t++) A[t] = Ti0[t];
+#pragma unroll
+    for (int r = 0; r < D; r++)
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+            double sacc = 0;
+#pragma unroll
+            for (int p = 0; p < D; p++) sacc += A[r * D + p] * T00[p * D + c];
+            R[r * D + c] = sacc;
+        }
+#pragma unroll
+    for (int t = 0; t < DD; t++) Ti0[t] = R[t];
+}
+
+// Y = S T for symmetric S (n x n, stored lower incl. diagonal in Lam with leading dimension ldl) and block-arrow T:
+// column block b > 0: Y[:, b] = S[:, b] T_bb ; column block 0: Y[:, 0] = S[:, 0] T_00 + sum_{c > 0} S[:, c] T_c0.
+// One wavefront per row; lanes over (block, column) pairs.
+template <int D>
+__global__ __launch_bounds__(64) void big_right_mul_kernel(const double *Lam, int ldl, int k, const double *Jinv, double *Y, int ldy) {
+    constexpr int DD = D * D;
+    const int i = blockIdx.x, n = D * k, lane = threadIdx.x;
+    auto S = [&](int r, int c) { return (c <= r) ? Lam[(long long)r * ldl + c] : Lam[(long long)c * ldl + r]; };
+    for (int j = lane; j < n; j += 64) {
+        const int b = j / D, c = j - b * D;
+        double sacc = 0;
+        if (b > 0) {
+            const double *Tbb = Jinv + (size_t)b * 2 * DD + DD;
+#pragma unroll
+            for (int p = 0; p < D; p++) sacc += S(i, b * D + p) * Tbb[p * D + c];
+        } else {
+            const double *T00 = Jinv + DD;
+#pragma unroll
+            for (int p = 0; p < D; p++) sacc += S(i, p) * T00[p * D + c];
+            for (int cb = 1; cb < k; cb++) {
+                const double *Tc0 = Jinv + (size_t)cb * 2 * DD;
+#pragma unroll
+                for (int p = 0; p < D; p++) sacc += S(i, cb * D + p) * Tc0[p * D + c];
+            }
+        }
+        Y[(long long)i * ldy + j] = sacc;
+    }
+}
+// Mt = T^T Y (n x n): row block a > 0: T_aa^T Y[a, :]; row block 0: T_00^T Y[0, :] + sum_{c > 0} T_c0^T Y[c, :].
+template <int D>
+__global__ __launch_bounds__(64) void big_left_mul_kernel(const double *Y, int ldy, int k, const double *Jinv, double *Mt, int ldm) {
+    constexpr int DD = D * D;
+    const int i = blockIdx.x, n = D * k, lane = threadIdx.x;
+    const int a = i / D, r = i - a * D;
+    for (int j = lane; j < n; j += 64) {
+        double sacc = 0;
+        if (a > 0) {
+            const double *Taa = Jinv + (size_t)a * 2 * DD + DD;
+#pragma unroll
+            for (int p = 0; p < D; p++) sacc += Taa[p * D + r] * Y[(long long)(a * D + p) * ldy + j];
+        } else {
+            const double *T00 = Jinv + DD;
+#pragma unroll
+            for (int p = 0; p < D; p++) sacc += T00[p * D + r] * Y[(long long)p * ldy + j];
+            for (int cb = 1; cb < k; cb++) {
+                const double *Tc0 = Jinv + (size_t)cb * 2 * DD;
+#pragma unroll
+                for (int p = 0; p < D; p++) sacc += Tc0[p * D + r] * Y[(long long)(cb * D + p) * ldy + j];
+            }
+        }
+        Mt[(long long)i * ldm + j] = sacc;
+    }
+}
+// Mrel (Nr x Nr, zeroed, padded with a unit diagonal) <- sym(Mt)[D.., D..] ; stats[0] = max |sym(Mt)| over the first D
+// rows / columns (the absolute part, ~0), stats[1] = max |sym(Mt)| overall
+template <int D>
+__global__ __launch_bounds__(256) void big_extract_kernel(const double *Mt, int ldm, int n, double *Mrel, int Nr, double *stats) {
+    __shared__ double red[2][256];
+    double ga = 0, gm = 0;
+    const long long tot = (long long)n * n;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < tot; it += (long long)gridDim.x * 256) {
+        const int i = (int)(it / n), j = (int)(it - (long long)i * n);
+        if (j > i) continue;
+        const double v = 0.5 * (Mt[(long long)i * ldm + j] + Mt[(long long)j * ldm + i]);
+        gm = fmax(gm, fabs(v));
+        if (j < D) ga = fmax(ga, fabs(v));
+        else Mrel[(long long)(i - D) * Nr + (j - D)] = v;
+    }
+    red[0][threadIdx.x] = ga; red[1][threadIdx.x] = gm;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] = fmax(red[0][threadIdx.x], red[0][threadIdx.x + o]); red[1][threadIdx.x] = fmax(red[1][threadIdx.x], red[1][threadIdx.x + o]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // (fp64 max through the integer ordering of non-negative doubles)
+        atomicMax(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)__double_as_longlong(red[0][0]));
+        atomicMax(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)__double_as_longlong(red[1][0]));
+    }
+}
+// the edge record: meas (n) then W (r x n) = [0 | L^T], r = n - D
+template <int D>
+__global__ __launch_bounds__(256) void big_write_record_kernel(const double *L, int Nr, int n, const double *meas, double *rec) {
+    const int r = n - D;
+    const long long tot = (long long)n + (long long)r * n;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < tot; it += (long long)gridDim.x * 256) {
+        if (it < n) { rec[it] = meas[it]; continue; }
+        const long long w = it - n;
+        const int e = (int)(w / n), c = (int)(w - (long long)e * n);
+        double v = 0.0;
+        if (c >= D) { const int j = c - D; if (j >= e) v = L[(long long)j * Nr + e]; }
+        rec[it] = v;
+    }
+}
+// out record of the blanket (layout in include/spg.h). flags[0] = H_mm not PD, flags[1] = a reparametrisation block is
+// singular, flags[2] = M_rel not PD; stats as above; partial[0..np) = sum of squares of L^-T (trace of M_rel^-1).
+__global__ void big_out_record_kernel(double *orec, const int *flags, const double *stats, const double *partial, int np, int n, int D_, int m, int k,
+                                      int n_new_max, int tag, long long rec_len) {
+    __shared__ double red[256];
+    double s = 0;
+    for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x != 0) return;
+    const double tr_inv = red[0] - 0.0;
+    int status = SPG_OK;
+    if (flags[0]) status = SPG_ST_HMM_NOT_PD;
+    else if (flags[1] || !isfinite(stats[1])) status = SPG_ST_NONFINITE;
+    else if (flags[2] || !(tr_inv < 1e8) || !(stats[0] <= 1e-9 * fmax(stats[1], 1e-300))) status = SPG_ST_EIG_FAIL;   // needs the truncating eig route
+    const int n_new = (status == SPG_OK) ? 1 : 0;
+    orec[0] = (double)status; orec[1] = 0.0; orec[2] = __builtin_nan(""); orec[3] = __builtin_inf(); orec[4] = (double)n_new;
+    if (n_new) {
+        orec[SPG_OUT_HDR + 0] = (double)SPG_EDGE_GLC;
+        orec[SPG_OUT_HDR + 1] = 0.0;
+        orec[SPG_OUT_HDR + 2] = (double)rec_len;
+        orec[SPG_OUT_HDR + 3] = (double)k;
+        for (int i = 0; i < k; i++) orec[SPG_OUT_HDR + 4 * n_new_max + i] = (double)(m + i);
+    }
+    __threadfence_system();
+    __hip_atomic_store(&orec[5], SPG_FINAL_WORD(tag), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------------------------------------ host side
 struct DevBuf {
     void *p = nullptr;
@@ -659,7 +911,7 @@ int stage_graph(const spg::DenseGraphIn &in, GraphBufs &gb, hipStream_t s) {
         gb.max_q = std::max(gb.max_q, q);
         gb.has_glc = true;
     }
-    if ((size_t)gb.max_q * (2 * in.D * in.D + in.D) * sizeof(double) > 60000) return SPG_ECAPACITY;   // LDS staging of one GLC edge's Jacobians
+    if ((size_t)gb.max_q * (2 * in.D * in.D + in.D) * sizeof(double) > 160 * 1024) return SPG_ECAPACITY;   // LDS staging of one GLC edge's Jacobians
     int rc;
     if ((rc = upload(gb.pos, in.pos, (size_t)in.nv, s))) return rc;
     if ((rc = upload(gb.vpo, in.vpo, (size_t)in.nv, s))) return rc;
@@ -679,6 +931,7 @@ template <int D>
 void launch_assemble(const GraphBufs &gb, double *M, int ld, hipStream_t s, double *bvec = nullptr) {
     if (gb.has_glc) {
         size_t sh = (size_t)gb.max_q * (2 * D * D + D) * sizeof(double);
+        if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(glc_weighted_jacobian_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipLaunchKernelGGL((glc_weighted_jacobian_kernel<D>), dim3(gb.dev.ne), dim3(64), sh, s, gb.dev);
     }
     hipLaunchKernelGGL((dense_assemble_kernel<D>), dim3(gb.dev.nv), dim3(64), 0, s, gb.dev, M, ld, bvec);
@@ -697,11 +950,14 @@ void launch_tiles(const TileOp &op, hipStream_t s) {
 // then the whole trailing matrix is updated ONCE with K = 512 — the trailing read-modify-write of C is
 // what bounds a K = 64 update (10 flop/B), and it shrinks with the outer width.
 constexpr int OUTER = 8;   // 64-tiles per outer block
-void potrf_lower(double *M, int N, double *linv /*64*64*/, int *bad, hipStream_t s) {
+// stop_tiles >= 0: factorise the first stop_tiles block columns only — the trailing block then holds the Schur complement
+// of the leading one (lower triangle), which is how a blanket's target information is formed (big blankets below).
+void potrf_lower(double *M, int N, double *linv /*64*64*/, int *bad, hipStream_t s, int stop_tiles = -1) {
     const int nt = N / TB;
+    const int lim = stop_tiles < 0 ? nt : std::min(stop_tiles, nt);
     const long long ld = N;
-    for (int J0 = 0; J0 < nt; J0 += OUTER) {
-        const int J1 = std::min(nt, J0 + OUTER);
+    for (int J0 = 0; J0 < lim; J0 += OUTER) {
+        const int J1 = std::min(lim, J0 + OUTER);
         for (int j = J0; j < J1; j++) {
             hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(64), 0, s, M + (long long)j * TB * (ld + 1), N, linv, bad, 1);
             const int rem = nt - j - 1;
@@ -761,6 +1017,79 @@ void rsolve_lower_transposed(double *Y, int ldy, const double *Ls, int ld, int N
 }
 
 inline int round_up(int n) { return (n + TB - 1) / TB * TB; }
+
+// One large GLC Dense blanket, asynchronously on `stream` up to the final synchronisation that releases the scratch.
+// in: the blanket as a local graph (vertices = blanket-local indices, removed first; pos[l] = l*D for removed vertices,
+// Nm + (l - m)*D for kept ones, Nm = nm rounded up to 64). The new edge record goes to arena[new_off ...), the out
+// record (include/spg.h) to orec (device address: arena or pinned mailbox).
+template <int D>
+static int big_glc_dense_impl(hipStream_t s, const spg::DenseGraphIn &in, int m, int k, int Nm, int64_t new_off, double *orec, int n_new_max, int tag,
+                              double *seconds, char *err, size_t errlen) {
+    int rc = 0;
+    constexpr int DD = D * D;
+    const int n = D * k, nm = D * m, Ng = round_up(std::max(n, 1)), N = Nm + Ng, Nr = round_up(std::max(n - D, 1)), ntr = Nr / TB;
+    double *arena = (double *)const_cast<void *>(in.dev_arena);
+    GraphBufs gb;
+    DevBuf H, Y, Mt, Mrel, Yi, linv, linv_all, flags, stats, partial, jinv, meas, vpo_d;
+    const int np = 256;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0;
+    if (hipMalloc(&H.p, (size_t)N * N * 8) != hipSuccess || hipMalloc(&Y.p, (size_t)Ng * Ng * 8) != hipSuccess ||
+        hipMalloc(&Mt.p, (size_t)Ng * Ng * 8) != hipSuccess || hipMalloc(&Mrel.p, (size_t)Nr * Nr * 8) != hipSuccess ||
+        hipMalloc(&Yi.p, (size_t)Nr * Nr * 8) != hipSuccess) {
+        snprintf(err, errlen, "hipMalloc of the dense matrices of a large blanket failed (N = %d)", N);
+        return SPG_ENOMEM;
+    }
+    HIPCHK(hipMalloc(&linv.p, TB * TB * 8));
+    HIPCHK(hipMalloc(&linv_all.p, (size_t)ntr * TB * TB * 8));
+    HIPCHK(hipMalloc(&flags.p, 4 * sizeof(int)));
+    HIPCHK(hipMalloc(&stats.p, 2 * 8));
+    HIPCHK(hipMalloc(&partial.p, np * 8));
+    HIPCHK(hipMalloc(&jinv.p, (size_t)std::max(k, 1) * 2 * DD * 8));
+    HIPCHK(hipMalloc(&meas.p, (size_t)std::max(n, 1) * 8));
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    if ((rc = stage_graph(in, gb, s))) { snprintf(err, errlen, "staging a large blanket failed (%d)", rc); goto done; }
+    HIPCHK(hipEventRecord(e0, s));
+    HIPCHK(hipMemsetAsync(H.p, 0, (size_t)N * N * 8, s));
+    HIPCHK(hipMemsetAsync(Mrel.p, 0, (size_t)Nr * Nr * 8, s));
+    HIPCHK(hipMemsetAsync(Yi.p, 0, (size_t)Nr * Nr * 8, s));
+    HIPCHK(hipMemsetAsync(flags.p, 0, 4 * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(stats.p, 0, 2 * 8, s));
+    launch_assemble<D>(gb, (double *)H.p, N, s);
+    if (Nm > nm) hipLaunchKernelGGL(pad_identity_kernel, dim3((Nm - nm + 255) / 256), dim3(256), 0, s, (double *)H.p, N, nm, Nm);
+    if (Ng > n) hipLaunchKernelGGL(pad_identity_kernel, dim3((Ng - n + 255) / 256), dim3(256), 0, s, (double *)H.p, N, Nm + n, N);
+    // Schur complement onto the kept block: the factorisation stops where that block begins
+    potrf_lower((double *)H.p, N, (double *)linv.p, (int *)flags.p, s, Nm / TB);
+    {
+        const double *Lam = (const double *)H.p + ((long long)Nm * N + Nm);
+        BigArrow ar{(double *)jinv.p, (double *)meas.p};
+        hipLaunchKernelGGL((big_reparam_kernel<D>), dim3((k + 63) / 64), dim3(64), 0, s, (const double *)arena, gb.dev.vpo, m, k, ar, (int *)flags.p + 1);
+        if (k > 1) hipLaunchKernelGGL((big_arrow_finish_kernel<D>), dim3((k + 62) / 64), dim3(64), 0, s, k, ar);
+        hipLaunchKernelGGL((big_right_mul_kernel<D>), dim3(n), dim3(64), 0, s, Lam, N, k, (const double *)jinv.p, (double *)Y.p, Ng);
+        hipLaunchKernelGGL((big_left_mul_kernel<D>), dim3(n), dim3(64), 0, s, (const double *)Y.p, Ng, k, (const double *)jinv.p, (double *)Mt.p, Ng);
+        hipLaunchKernelGGL((big_extract_kernel<D>), dim3(256), dim3(256), 0, s, (const double *)Mt.p, Ng, n, (double *)Mrel.p, Nr, (double *)stats.p);
+        if (Nr > n - D) hipLaunchKernelGGL(pad_identity_kernel, dim3((Nr - (n - D) + 255) / 256), dim3(256), 0, s, (double *)Mrel.p, Nr, n - D, Nr);
+        potrf_lower((double *)Mrel.p, Nr, (double *)linv.p, (int *)flags.p + 2, s);
+        // lambda_min(M_rel) > 1e-8 is proven by trace(M_rel^-1) = ||L^-T||_F^2 < 1e8
+        hipLaunchKernelGGL(pad_identity_kernel, dim3((Nr + 255) / 256), dim3(256), 0, s, (double *)Yi.p, Nr, 0, Nr);
+        rsolve_lower_transposed((double *)Yi.p, Nr, (const double *)Mrel.p, Nr, Nr, (double *)linv_all.p, (int *)flags.p + 3, s);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(np), dim3(256), 0, s, (const double *)Yi.p, Nr, n - D, (double *)partial.p);
+        const long long rec_len = (long long)n + (long long)(n - D) * n;
+        hipLaunchKernelGGL((big_write_record_kernel<D>), dim3(512), dim3(256), 0, s, (const double *)Mrel.p, Nr, n, (const double *)meas.p, arena + new_off);
+        hipLaunchKernelGGL(big_out_record_kernel, dim3(1), dim3(256), 0, s, orec, (const int *)flags.p, (const double *)stats.p, (const double *)partial.p, np,
+                           n, D, m, k, n_new_max, tag, rec_len);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipStreamSynchronize(s));   // the scratch is released below
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (seconds) *seconds = 1e-3 * ms;
+done:
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+}
 
 }  // namespace
 
@@ -835,6 +1164,15 @@ int hip_dense_covariance(void *stream, const DenseGraphIn &in, int n, double *ou
         for (int j = 0; j < n; j++) out[(size_t)i * n + j] = (j <= i) ? h[(size_t)i * N + j] : h[(size_t)j * N + i];
 done:
     return rc;
+}
+
+int hip_big_glc_dense(void *stream, const DenseGraphIn &in, int m, int k, int Nm, int64_t new_off, double *orec, int n_new_max, int tag,
+                      double *seconds, double *flops, char *err, size_t errlen) {
+    const double n = (double)in.D * k, nm = (double)in.D * m, nr = n - in.D;
+    // the n^3-class work on the matrix cores: H_mm Cholesky + panel solves + Schur update, M_rel Cholesky, L^-T
+    if (flops) *flops = nm * nm * nm / 3.0 + nm * nm * n + nm * n * n + nr * nr * nr / 3.0 + nr * nr * nr / 3.0;
+    return in.D == 6 ? big_glc_dense_impl<6>((hipStream_t)stream, in, m, k, Nm, new_off, orec, n_new_max, tag, seconds, err, errlen)
+                     : big_glc_dense_impl<3>((hipStream_t)stream, in, m, k, Nm, new_off, orec, n_new_max, tag, seconds, err, errlen);
 }
 
 // Global KLD. base.pos orders the baseline's variables [marginalised | pad | kept | pad] with the

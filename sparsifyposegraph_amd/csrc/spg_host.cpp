@@ -355,6 +355,14 @@ extern "C" int spg_ctx_profile_read_worker(spg_ctx *c, double *kernel_ms, double
     *runs = r; *blankets = b;
     return 0;
 }
+extern "C" int spg_ctx_profile_read_big(spg_ctx *c, double *kernel_ms, double *flops, int64_t *blankets, int32_t *n_max) {
+    if (!c || !c->is_hip || !kernel_ms || !flops || !blankets || !n_max) return SPG_EINVAL;
+    long long cnt = 0;
+    int nm = 0;
+    spg::hip_backend_profile_read_big(&c->be, kernel_ms, flops, &cnt, &nm);
+    *blankets = cnt; *n_max = nm;
+    return 0;
+}
 extern "C" int spg_ctx_profile_read(spg_ctx *c, double *kernel_ms, double *alg_bytes, int64_t *launches, int64_t *blankets) {
     if (!c || !c->is_hip || !kernel_ms || !alg_bytes || !launches || !blankets) return SPG_EINVAL;
     long long l = 0, b = 0;

@@ -16,6 +16,7 @@ int hip_backend_device(spg_backend *b);
 void hip_backend_profile(spg_backend *b, int enable);
 void hip_backend_profile_read(spg_backend *b, double *ms, double *bytes, long long *launches, long long *blankets);
 void hip_backend_profile_read_worker(spg_backend *b, double *ms, double *bytes, long long *runs, long long *blankets);
+void hip_backend_profile_read_big(spg_backend *b, double *ms, double *flops, long long *count, int *nmax);
 int hip_backend_end_of_call(spg_backend *b);   // the persistent worker retires (end of a marginalisation)
 
 // Dense global KLD (spg_dense.hip). Host-staged description of one graph for the dense assembly.
@@ -36,6 +37,9 @@ int hip_dense_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &ot
                   const int64_t *kept_vpo_base, const int64_t *kept_vpo_other, double *terms, double *seconds,
                   char *err, size_t errlen);
 
+// One GLC Dense blanket too large for the LDS kernel, dense in HBM on the fp64 matrix cores (spg_dense.hip)
+int hip_big_glc_dense(void *stream, const DenseGraphIn &local_graph, int m, int k, int Nm, int64_t new_off, double *orec, int n_new_max, int tag,
+                      double *seconds, double *flops, char *err, size_t errlen);
 int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iterations, double *stats, double *seconds,
                        char *err, size_t errlen);
 

@@ -1553,6 +1553,9 @@ struct HipBackend {
     } worker;
     int batches_in_call = 0;                          // batches since the last full synchronisation
     int worker_cooldown = 0;                          // batches to go before the worker is considered again
+    double prof_big_ms = 0, prof_big_flops = 0;       // large-blanket dense pipeline (always accumulated)
+    long long prof_big_count = 0;
+    int prof_big_nmax = 0;
     double prof_worker_ms = 0, prof_worker_bytes = 0;
     long long prof_worker_runs = 0, prof_worker_blankets = 0;
     int lds_limit = 160 * 1024;
@@ -1763,6 +1766,43 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         bins[bi].kmax = std::max(bins[bi].kmax, k);
         bins[bi].mmax = std::max(bins[bi].mmax, m);
         bins[bi].smax = std::max(bins[bi].smax, (int)bd.pad_);
+    }
+    // Blankets whose side buffers (Chow-Liu pair tables, GLC batch buffers) exceed LDS even with the tiles in the L2
+    // workspace: GLC Dense ones go through the dense HBM pipeline on the matrix cores (spg_dense.hip) after the
+    // launches below, one at a time; for the others there is no path (SPG_ECAPACITY, as before).
+    std::vector<int32_t> big_list;
+    static const bool force_big = [] { const char *e = getenv("SPG_FORCE_BIG"); return e && e[0] == '1'; }();   // diagnostic / tests
+    if (force_big && o.algorithm == SPG_ALG_GLC && o.topology == SPG_TOPO_DENSE && o.lin_point == SPG_LIN_GLOBAL) {
+        // every blanket with at least one kept vertex takes the dense pipeline (parity of that path on small blankets)
+        for (int i = 0; i < NB; i++) {
+            size_t keep = 0;
+            for (int32_t b : bins[i].list) {
+                if (rd->blankets[b].n_vert - rd->blankets[b].n_remove >= 2 && rd->blankets[b].n_edge > 0) big_list.push_back(b);
+                else bins[i].list[keep++] = b;
+            }
+            bins[i].list.resize(keep);
+        }
+        std::sort(big_list.begin(), big_list.end());
+    } else {
+        Bin &bb = bins[NB - 1];
+        size_t keep = 0;
+        int kmax = 0, mmax = 0, smax = 0;
+        for (int32_t b : bb.list) {
+            const spg_blanket_desc &bd = rd->blankets[b];
+            const int k = bd.n_vert - bd.n_remove, m = bd.n_remove;
+            Layout Lb = make_layout(D, 256, k, m, o.algorithm, o.topology, bd.pad_);
+            if ((size_t)Lb.small_doubles * 8 <= (size_t)hb->lds_limit) {
+                bb.list[keep++] = b;
+                kmax = std::max(kmax, k); mmax = std::max(mmax, m); smax = std::max(smax, (int)bd.pad_);
+                continue;
+            }
+            if (!(o.algorithm == SPG_ALG_GLC && o.topology == SPG_TOPO_DENSE && o.lin_point == SPG_LIN_GLOBAL)) {
+                snprintf(err, sizeof hb->err, "blanket too large for LDS side buffers: k=%d m=%d (only GLC Dense blankets have a large-blanket path)", k, m);
+                return SPG_ECAPACITY;
+            }
+            big_list.push_back(b);
+        }
+        if (!big_list.empty()) { bb.list.resize(keep); bb.kmax = kmax; bb.mmax = mmax; bb.smax = smax; }
     }
     LP(0);
     // ---- upload the round's descriptors (one pinned staging buffer, async copies)
@@ -2003,6 +2043,35 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         }
         if (rc) return rc;
     }
+    // ---- large GLC Dense blankets: dense in HBM, O(n^3) parts on the fp64 matrix cores
+    for (int32_t b : big_list) {
+        const spg_blanket_desc &bd = rd->blankets[b];
+        const int k = bd.n_vert - bd.n_remove, m = bd.n_remove;
+        // the blanket as a local graph: vertices = blanket-local indices (removed first), edges as staged for the kernel
+        const int nm = D * m, Nm = (nm + 63) / 64 * 64;
+        std::vector<int32_t> pos(bd.n_vert), rowptr(bd.n_vert + 1, 0), inc;
+        for (int l = 0; l < bd.n_vert; l++) pos[l] = l < m ? l * D : Nm + (l - m) * D;
+        std::vector<std::vector<int32_t>> per(bd.n_vert);
+        for (int e = 0; e < bd.n_edge; e++) {
+            const spg_edge_ref &er = rd->edges[bd.edge_begin + e];
+            for (int t = 0; t < er.nv; t++) {
+                int32_t l = rd->edge_vert[er.vbegin + t];
+                if (per[l].empty() || per[l].back() != e) per[l].push_back(e);
+            }
+        }
+        for (int l = 0; l < bd.n_vert; l++) { inc.insert(inc.end(), per[l].begin(), per[l].end()); rowptr[l + 1] = (int32_t)inc.size(); }
+        spg::DenseGraphIn in;
+        in.D = D; in.nv = bd.n_vert; in.ne = bd.n_edge;
+        in.pos = pos.data(); in.vpo = rd->vert_pose_off + bd.vert_begin; in.rowptr = rowptr.data(); in.inc = inc.data();
+        in.er = rd->edges + bd.edge_begin; in.ev = rd->edge_vert; in.n_ev = rd->n_edge_vert_total; in.dev_arena = arena;
+        double *orec = mail_dev ? (mail_dev + (bd.out_off - rd->mail_base)) : ((double *)arena + bd.out_off);
+        double secs = 0, flops = 0;
+        int brc = spg::hip_big_glc_dense((void *)S.stream, in, m, k, Nm, bd.new_off, orec, bd.n_new_max, rd->tag, &secs, &flops, hb->err, sizeof hb->err);
+        if (brc) return brc;
+        hb->prof_big_ms += 1e3 * secs; hb->prof_big_flops += flops; hb->prof_big_count++;
+        hb->prof_big_nmax = std::max(hb->prof_big_nmax, D * (k + m));
+        S.stream_dirty = true;
+    }
     LP(3);
 #ifdef SPG_LAUNCH_PROF
     if (lp_n % 1005 == 0) fprintf(stderr, "launch prof: bins %.2f sync+drain %.2f desc write %.2f launch %.2f us (avg over %ld)\n",
@@ -2146,11 +2215,17 @@ void hip_backend_profile(spg_backend *b, int enable) {
     hb->prof_tick = 0;
     for (auto &S : hb->slots) { S.prof_ms = S.prof_bytes = 0; S.prof_launches = S.prof_blankets = 0; }
     hb->prof_worker_ms = hb->prof_worker_bytes = 0; hb->prof_worker_runs = hb->prof_worker_blankets = 0;
+    hb->prof_big_ms = hb->prof_big_flops = 0; hb->prof_big_count = 0; hb->prof_big_nmax = 0;
 }
 void hip_backend_profile_read_worker(spg_backend *b, double *ms, double *bytes, long long *runs, long long *blankets) {
     HipBackend *hb = (HipBackend *)b->user;
     if (!hb) return;
     *ms = hb->prof_worker_ms; *bytes = hb->prof_worker_bytes; *runs = hb->prof_worker_runs; *blankets = hb->prof_worker_blankets;
+}
+void hip_backend_profile_read_big(spg_backend *b, double *ms, double *flops, long long *count, int *nmax) {
+    HipBackend *hb = (HipBackend *)b->user;
+    if (!hb) return;
+    *ms = hb->prof_big_ms; *flops = hb->prof_big_flops; *count = hb->prof_big_count; *nmax = hb->prof_big_nmax;
 }
 int hip_backend_end_of_call(spg_backend *b) {
     HipBackend *hb = (HipBackend *)b->user;

@@ -32,6 +32,7 @@ SYMBOLS = {
     "spg_ctx_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "spg_ctx_profile_read": (C.c_int, [C.c_void_p, _f64p, _f64p, _i64p, _i64p]),
     "spg_ctx_profile_read_worker": (C.c_int, [C.c_void_p, _f64p, _f64p, _i64p, _i64p]),
+    "spg_ctx_profile_read_big": (C.c_int, [C.c_void_p, _f64p, _f64p, _i64p, _i32p]),
     "spg_marginalize_batch": (C.c_int, [C.c_void_p, C.POINTER(abi.Options), C.POINTER(abi.Batch), C.POINTER(abi.Result)]),
     "spg_decimate_global": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, C.c_int]),
     "spg_decimate_online": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, C.c_int]),
@@ -170,6 +171,12 @@ class Context:
         nl, nb = C.c_int64(), C.c_int64()
         check(self.L.spg_ctx_profile_read_worker(self.h, C.byref(ms), C.byref(by), C.byref(nl), C.byref(nb)), self.h, "spg_ctx_profile_read_worker")
         return {"kernel_ms": ms.value, "alg_bytes": by.value, "runs": nl.value, "blankets": nb.value}
+
+    def profile_read_big(self):
+        ms, fl = C.c_double(), C.c_double()
+        nb, nm = C.c_int64(), C.c_int32()
+        check(self.L.spg_ctx_profile_read_big(self.h, C.byref(ms), C.byref(fl), C.byref(nb), C.byref(nm)), self.h, "spg_ctx_profile_read_big")
+        return {"kernel_ms": ms.value, "flops": fl.value, "blankets": nb.value, "n_max": nm.value}
 
     def marginalize_batch(self, opts, batch, want_target=True):
         return abi.marginalize_batch(self.L, self.h, opts, batch, want_target)

@@ -1,0 +1,107 @@
+"""Large GLC Dense blankets (the large-blanket path): Dense clustering on an SE3 lattice grows blankets to
+k + m = 150-200 vertices (n + nm ~ 1000), beyond the LDS kernel; they run dense in HBM with the O(n^3) parts on the fp64
+matrix cores (csrc/spg_dense.hip, hip_big_glc_dense). Parity: the oracle's full-size digest for sphere.g2o
+(tests/golden/make_dense_digest.py), the oracle's full-size fixture for manhattan.g2o with EVERY blanket forced through
+the dense pipeline, and the invariant that GLC Dense is exact (global KLD against the baseline ~ 0)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from sparsifyposegraph_amd import abi, g2o_io
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_digest_roundtrip_on_the_oracle():
+    """CPU: the digest of a small GLC Dense oracle run equals the digest computed from its stored fixture edges."""
+    from tests import oracle_lib
+    g, which, opts, out, *_ = util.load_golden("manhattan_glc_dense")
+    og = oracle_lib.OracleGraph.from_dict(g)
+    assert og.marginalize(which, opts) == 0
+    assert util.compare_digests(util.edge_digest(3, og.edges()), util.edge_digest(3, out)) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_sphere_full_glc_dense_matches_oracle_digest(hip_ctx):
+    """BASELINE config 3's dataset under GLC Dense at FULL size: 25 clusters of 50 removed + ~100 kept SE3 vertices
+    (n + nm ~ 900), each consuming the n-ary edge of the previous one. No SPG_ECAPACITY; topology identical and W^T W
+    (through four probe vectors) within 1e-9 of the oracle."""
+    from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    src, alg, topo, ref, z = util.load_digest("sphere_full_glc_dense")
+    g, which, *_ = util.load_golden(src)
+    hg = GraphWrapperHIP.from_dict(g, ctx=hip_ctx, useGLC=True)
+    hip_ctx.profile(True)
+    st = hg.marginalizeNoOptimize(which, abi.make_options(6, alg, topo))
+    big = hip_ctx.profile_read_big()
+    hip_ctx.profile(False)
+    assert st["n_bad_status"] == 0 and st["n_removed"] == len(which)
+    assert big["blankets"] >= 20 and big["n_max"] >= 600, big     # the clusters did take the dense pipeline
+    assert np.array_equal(hg.vertices()[0], z["out_vertex_ids"])
+    worst = util.compare_digests(util.edge_digest(6, hg.edges()), ref)
+    print(f"sphere GLC Dense full size: {big['blankets']} large blankets (largest n + nm = {big['n_max']}), "
+          f"{big['kernel_ms']:.1f} ms on the device, {1e-9 * big['flops'] / max(big['kernel_ms'], 1e-9):.2f} TFLOP/s of n^3 work, worst rel err {worst:.2e}")
+
+
+FORCED = r'''
+import os, sys
+os.environ["SPG_FORCE_BIG"] = "1"
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from sparsifyposegraph_amd.graph import GraphWrapperHIP
+from sparsifyposegraph_amd.lib import Context
+from tests import util
+ctx = Context(0)
+for case in sys.argv[2:]:
+    g, which, opts, out, bl, vids = util.load_golden(case)
+    hg = GraphWrapperHIP.from_dict(g, ctx=ctx, useGLC=True)
+    ctx.profile(True)
+    st = hg.marginalizeNoOptimize(which, opts)
+    big = ctx.profile_read_big()
+    assert st["n_bad_status"] == 0, st
+    assert big["blankets"] > 0.5 * st["n_removed"] / 4, big
+    worst = util.compare_edge_sets(g["pose_dim"], out, hg.edges())
+    print(f"{case} ok: {big['blankets']} blankets through the dense pipeline, worst rel err {worst:.2e}")
+'''
+
+
+@pytest.mark.gpu
+def test_dense_pipeline_forced_on_every_blanket_matches_fixtures(tmp_path):
+    """The dense HBM pipeline on blankets the LDS kernel also takes (SPG_FORCE_BIG=1, own process): manhattan.g2o GLC Dense
+    at full size (1748 removals, clusters up to k + m = 33) and its 1200-vertex prefix against the oracle fixtures, every
+    edge to 1e-9 — many small, differently shaped blankets through the same code as the large ones."""
+    script = tmp_path / "forced.py"
+    script.write_text(FORCED)
+    out = subprocess.run([sys.executable, str(script), ROOT, "manhattan_glc_dense", "manhattan_full_glc_dense"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "manhattan_full_glc_dense ok" in out.stdout
+    print(out.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", ["lattice6000", "parking"])
+def test_glc_dense_is_exact_on_large_clusters(graph, hip_ctx):
+    """GLC Dense reproduces the marginal exactly ((W J)^T (W J) = Lambda_t), so the global KLD of the sparsified graph
+    against its baseline vanishes — an oracle-free check of the large-blanket path on a 6000-pose synthetic SE3 lattice
+    (clusters of k + m ~ 180) and on parking.g2o at full size."""
+    from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    if graph == "lattice6000":
+        g = g2o_io.synth_sphere(n_poses=6000, ring=60)
+        which = np.array([i for i in range(4, 6000) if i % 2], np.int32)
+    else:
+        g, which, *_ = util.load_golden("parking_full_nfr_tree")
+    base = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+    hg = GraphWrapperHIP.from_dict(g, ctx=hip_ctx, useGLC=True)
+    hip_ctx.profile(True)
+    st = hg.marginalizeNoOptimize(which, abi.make_options(6, abi.ALG_GLC, abi.TOPO_DENSE))
+    big = hip_ctx.profile_read_big()
+    hip_ctx.profile(False)
+    assert st["n_bad_status"] == 0 and st["n_removed"] == len(which), st
+    kld = base.kullbackLeibler(hg)
+    n = base.last_kld_terms["n"]
+    print(f"{graph}: {big['blankets']} large blankets (largest n + nm = {big['n_max']}), max blanket {st['max_blanket']}, global KLD {kld:.3e} over {n} variables")
+    assert big["blankets"] > 0
+    assert abs(kld) <= 1e-7 * n, kld

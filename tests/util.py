@@ -14,7 +14,8 @@ GAP_TOL = 1e-10
 
 
 def golden_cases():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [n for n in names if not n.startswith("digest_")]   # digests of full-size Dense runs: tests/golden/make_dense_digest.py
 
 
 def load_golden(name):
@@ -69,6 +70,56 @@ def compare_edge_sets(d, ea, eb, rtol=RTOL):
             worst = max(worst, rel_err(xa[:n], xb[:n]))
             ga, gb = glc_gram(d, ids, xa), glc_gram(d, ids, xb)
             worst = max(worst, rel_err(ga, gb))
+    assert worst <= rtol, f"edge payload mismatch: {worst:.3e} > {rtol}"
+    return worst
+
+
+def probe_vectors(n, seed=20240611):
+    """Four deterministic probe vectors of length n (SplitMix64 -> uniform in [-1, 1))."""
+    idx = np.arange(4 * n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = (idx + np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return ((x >> np.uint64(11)).astype(np.float64) / float(1 << 53) * 2.0 - 1.0).reshape(4, n)
+
+
+def edge_digest(d, edges):
+    """edges() dict -> [(kind, ids, meas, sketch[4, n])] in canonical order: the action of every edge's information on four
+    fixed probe vectors — (W^T W) z for GLC edges (W is only defined up to an orthogonal factor), Omega z for pose-pose
+    edges. What tests/golden/make_dense_digest.py stores for full-size Dense runs whose W blocks are too large to commit."""
+    ps = abi.pose_stride(d)
+    out = []
+    for kind, ids, data in canonical(edges):
+        if kind == abi.EDGE_BINARY:
+            om = np.zeros((d, d))
+            om[np.triu_indices(d)] = data[ps:]
+            om = om + om.T - np.diag(np.diag(om))
+            out.append((kind, ids, np.asarray(data[:ps]), probe_vectors(d) @ om))
+        else:
+            n = d * len(ids)
+            W = np.asarray(data[n:]).reshape(-1, n)
+            z = probe_vectors(n)
+            out.append((kind, ids, np.asarray(data[:n]), (z @ W.T) @ W))
+    return out
+
+
+def load_digest(name):
+    z = np.load(os.path.join(GOLDEN_DIR, "digest_" + name + ".npz"))
+    out = []
+    for e in range(len(z["kinds"])):
+        ids = tuple(int(x) for x in z["ids"][z["id_off"][e]:z["id_off"][e + 1]])
+        sk = z["sketch"][z["sketch_off"][e]:z["sketch_off"][e + 1]].reshape(4, -1)
+        out.append((int(z["kinds"][e]), ids, z["meas"][z["meas_off"][e]:z["meas_off"][e + 1]], sk))
+    return str(z["source"]), int(z["algorithm"]), int(z["topology"]), out, z
+
+
+def compare_digests(da, db, rtol=RTOL):
+    assert [(k, i) for k, i, *_ in da] == [(k, i) for k, i, *_ in db], "edge topology differs"
+    worst = 0.0
+    for (_, _, ma, sa), (_, _, mb, sb) in zip(da, db):
+        worst = max(worst, rel_err(ma, mb), rel_err(sa, sb))
     assert worst <= rtol, f"edge payload mismatch: {worst:.3e} > {rtol}"
     return worst
 

@@ -10,7 +10,9 @@ int hip_backend_device(spg_backend *) { return -1; }
 void hip_backend_profile(spg_backend *, int) {}
 void hip_backend_profile_read(spg_backend *, double *, double *, long long *, long long *) {}
 void hip_backend_profile_read_worker(spg_backend *, double *, double *, long long *, long long *) {}
+void hip_backend_profile_read_big(spg_backend *, double *, double *, long long *, int *) {}
 int hip_backend_end_of_call(spg_backend *) { return 0; }
+int hip_big_glc_dense(void *, const DenseGraphIn &, int, int, int, int64_t, double *, int, int, double *, double *, char *, size_t) { return SPG_ENODEV; }
 int hip_dense_information(void *, const DenseGraphIn &, int, double *, char *, size_t) { return SPG_ENODEV; }
 int hip_dense_covariance(void *, const DenseGraphIn &, int, double *, char *, size_t) { return SPG_ENODEV; }
 int rccl_get_unique_id(void *, char *, size_t) { return SPG_ENODEV; }
