@@ -32,6 +32,7 @@ CASES = [
     ("sphere_glc_tree", "sphere.g2o", 399, abi.ALG_GLC, abi.TOPO_TREE, ("sparsity", 2)),
     # BASELINE.json config 2 at full size: all 3500 vertices, Dense clustering (blankets up to k+m = 33)
     ("manhattan_full_glc_dense", "manhattan.g2o", 3499, abi.ALG_GLC, abi.TOPO_DENSE, ("sparsity", 2)),
+    ("manhattan_full_glc_tree", "manhattan.g2o", 3499, abi.ALG_GLC, abi.TOPO_TREE, ("sparsity", 2)),
     # configs 3 and 4 at full size
     ("sphere_full_nfr_tree", "sphere.g2o", 2499, abi.ALG_NFR, abi.TOPO_TREE, ("sparsity", 2)),
     ("parking_full_nfr_tree", "parking.g2o", 1660, abi.ALG_NFR, abi.TOPO_TREE, ("sparsity", 2)),

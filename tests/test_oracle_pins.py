@@ -264,16 +264,178 @@ def test_glc_reparam_jacobian_by_central_differences(oracle):
                     assert np.abs((ep - em) / (2 * h) - J[:, v * 3 + c]).max() < 1e-6
 
 
+# The only numbers the reference ships for this path: the GLC_EDGE line quoted at
+# src/test_marginalize_within_window.cpp:198-206 (an edge its own sliding-window run wrote).
+REF_GLC_LINE = ("GLC_EDGE 10 16 || GLC_REPARAM_SE2_ISAM 3 6 10 0 0 6 0 0 0 6.44942e-14 7.37069e-14 -5.38607e-12 -0.0781786 -2.09314e-05 "
+                "-0 -2.5976e-16 -3.96149e-14 0.0782534 -5.39122e-12 -1.42468e-15 0 5.67138e-15 -1.09704e-14 -1.87717e-15 -0.00209596 7.82839 "
+                "1 0 0 1 0 1")
+REF_GLC_W = np.array([[0, 6.44942e-14, 7.37069e-14, -5.38607e-12, -0.0781786, -2.09314e-05],
+                      [-0, -2.5976e-16, -3.96149e-14, 0.0782534, -5.39122e-12, -1.42468e-15],
+                      [0, 5.67138e-15, -1.09704e-14, -1.87717e-15, -0.00209596, 7.82839]])
+REF_GLC_MEAS = np.array([10.0, 0, 0, 6, 0, 0])
+
+
 def test_known_glc_edge_from_reference_comment(oracle):
-    """The only numbers the reference ships for this path: the GLC_EDGE line quoted at
-    src/test_marginalize_within_window.cpp:198-206 (vertex 10 at (10,0,0), relative (6,0,0),
-    W 3x6 with a zero absolute block). Its W^T W has rank 3 and no information on the absolute pose."""
-    W = np.array([[0, 6.44942e-14, 7.37069e-14, -5.38607e-12, -0.0781786, -2.09314e-05],
-                  [-0, -2.5976e-16, -3.96149e-14, 0.0782534, -5.39122e-12, -1.42468e-15],
-                  [0, 5.67138e-15, -1.09704e-14, -1.87717e-15, -0.00209596, 7.82839]])
-    G = W.T @ W
-    assert np.abs(G[:3, :]).max() < 1e-10  # gauge: nothing on the absolute first block
-    assert np.linalg.matrix_rank(G[3:, 3:], tol=1e-12) == 3
+    """Pins the oracle's GLC machinery to the one edge the reference quotes.
+    (1) reparametrize(vertices 10 at (10,0,0), 16 at (16,0,0)) IS the quoted measurement `10 0 0 6 0 0`
+        (first pose absolute, second relative to the first: src/glc_reparam_binary.hpp:35-75).
+    (2) The quoted W is what glc_chol produces: orthogonal rows sqrt(lambda) v^T in ascending eigenvalue order, no
+        information on the absolute block (src/topology_provider_glc.cpp:59-71).
+    (3) Fixed point: a graph that holds exactly this GLC edge plus a third vertex tied to 10 and 16 by edges of negligible
+        information (1e-12) is sparsified by removing that vertex. The blanket's target is then the quoted edge's own
+        information (n-ary edge Jacobian W J_reparam, src/glc_edge.cpp:40-49, Schur, reparametrisation, LU inverse, eig,
+        1e-8 cut, sqrt scaling — the whole GLC path), so the oracle must hand back the quoted record: same measurement,
+        3 x 6 W equal to the quoted one up to the sign of each row, to the 6 digits the reference printed."""
+    poses = np.array([[10.0, 0, 0], [16.0, 0, 0]])
+    meas, J = np.zeros(6), np.zeros((6, 6))
+    oracle.spgref_glc_reparam(3, 2, P(poses), None, P(meas), P(J))
+    assert np.array_equal(meas, REF_GLC_MEAS)
+    G = REF_GLC_W.T @ REF_GLC_W
+    assert np.abs(G[:3, :]).max() < 1e-10 and np.linalg.matrix_rank(G[3:, 3:], tol=1e-12) == 3
+    WWt = REF_GLC_W @ REF_GLC_W.T
+    assert np.abs(WWt - np.diag(np.diag(WWt))).max() < 2e-6 * WWt.max()         # rows orthogonal (6 printed digits)
+    assert np.all(np.diff(np.diag(WWt)) > 0)                                      # ascending eigenvalues
+    og = oracle_lib.OracleGraph(3)
+    for vid, p in ((10, [10.0, 0, 0]), (13, [13.0, 0.4, 0.1]), (16, [16.0, 0, 0])):
+        og.L.spgref_graph_add_vertex(og.h, vid, P(np.array(p)))
+    assert og.add_edge(abi.EDGE_GLC, [10, 16], np.concatenate([REF_GLC_MEAS, REF_GLC_W.ravel()])) == 0
+    weak = 1e-12 * np.eye(3)[np.triu_indices(3)]
+    for a, b, pa, pb in ((10, 13, [10.0, 0, 0], [13.0, 0.4, 0.1]), (13, 16, [13.0, 0.4, 0.1], [16.0, 0, 0])):
+        z = np.zeros(3)
+        oracle.spgref_se2_between(P(np.array(pa)), P(np.array(pb)), P(z))
+        assert og.add_edge(abi.EDGE_BINARY, [a, b], np.concatenate([z, weak])) == 0
+    for topo in (abi.TOPO_DENSE,):
+        assert og.marginalize(np.array([13], np.int32), abi.make_options(3, abi.ALG_GLC, topo)) == 0
+    (kind, ids, data), = util.edge_list(og.edges())
+    assert kind == abi.EDGE_GLC and ids == (10, 16) and len(data) == 6 + 3 * 6
+    assert np.abs(data[:6] - REF_GLC_MEAS).max() < 1e-12
+    W = data[6:].reshape(3, 6)
+    assert np.abs(W[:, :3]).max() < 1e-9
+    for r in range(3):
+        s = np.sign(W[r] @ REF_GLC_W[r])
+        assert np.abs(s * W[r, 3:] - REF_GLC_W[r, 3:]).max() <= 2e-6 * np.abs(REF_GLC_W[r]).max(), (r, W[r], REF_GLC_W[r])
+
+
+def test_reference_glc_line_through_the_product_reader_and_writer(tmp_path):
+    """f3: the product's .g2o reader takes the reference's own GLC_EDGE sample line (src/test_marginalize_within_window.cpp:
+    198-206; grammar of GLCEdge::read, src/glc_edge.cpp:65-93) and its writer gives back the same grammar: tag, the `||`
+    separator, reparametrisation tag, r, d*q, measurement, W row by row, the upper triangle of the identity."""
+    from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    path = tmp_path / "ref_line.g2o"
+    path.write_text("VERTEX_SE2 10 10 0 0\nVERTEX_SE2 16 16 0 0\n" + REF_GLC_LINE + "\n")
+    ctx = oracle_lib.injected_context()
+    g = GraphWrapperHIP.load(str(path), ctx=ctx, useGLC=True)
+    e = g.edges()
+    assert list(e["kind"]) == [abi.EDGE_GLC] and list(e["vert_ids"]) == [10, 16]
+    assert np.array_equal(e["data"][:6], REF_GLC_MEAS) and np.array_equal(e["data"][6:].reshape(3, 6), REF_GLC_W)
+    tokens = [l for l in g.writeString().splitlines() if l.startswith("GLC_EDGE")][0].split()
+    ref = REF_GLC_LINE.split()
+    assert tokens[:8] == ref[:8]                                   # GLC_EDGE 10 16 || GLC_REPARAM_SE2_ISAM 3 6 10
+    assert [float(t) for t in tokens[7:]] == [float(t) for t in ref[7:]]   # measurement, W, information: the same numbers
+    assert tokens[-6:] == ["1", "0", "0", "1", "0", "1"]
+
+
+def numpy_chow_liu(d, T):
+    """pseudo-Chow-Liu tree of src/pseudo_chow_liu.cpp:169-196,253-289 in numpy: Tikhonov inverse, pairwise mutual
+    information from log-determinants, Kruskal on descending weight with the (weight, i, j) tie-break."""
+    k = T.shape[0] // d
+    S = np.linalg.inv(T + np.eye(d * k))
+    ld = lambda idx: np.linalg.slogdet(S[np.ix_(idx, idx)])[1]   # noqa: E731
+    blk = lambda i: list(range(i * d, (i + 1) * d))               # noqa: E731
+    w = sorted(((-(ld(blk(i)) + ld(blk(j)) - ld(blk(i) + blk(j))), i, j) for i in range(k) for j in range(i + 1, k)))
+    comp, tree = list(range(k)), []
+    for _, i, j in w:
+        if comp[i] != comp[j]:
+            tree.append((i, j))
+            ci, cj = comp[i], comp[j]
+            comp = [ci if c == cj else c for c in comp]
+    return tree
+
+
+def numpy_glc_edge(d, T, poses, oracle):
+    """TopologyProviderGLC::getEdge + glc_chol (src/topology_provider_glc.cpp:59-98) in numpy: returns (measurement,
+    W^T W) — W itself is defined up to the eigenvectors' signs. The reparametrisation is the oracle's unit function,
+    pinned above by central differences."""
+    q = len(poses)
+    pp = np.ascontiguousarray(np.stack(poses))
+    meas, J = np.zeros(d * q), np.zeros((d * q, d * q))
+    oracle.spgref_glc_reparam(d, q, P(pp), None, P(meas), P(J))
+    oracle.spgref_glc_reparam(d, q, P(pp), P(meas), P(np.zeros(d * q)), P(J))
+    iJ = np.linalg.inv(J)
+    M = iJ.T @ T @ iJ
+    M = 0.5 * (M + M.T)
+    w, V = np.linalg.eigh(M)
+    keep = w >= 1e-8
+    return meas, (V[:, keep] * w[keep]) @ V[:, keep].T, int(keep.sum())
+
+
+def numpy_schur_onto(T, keep):
+    """PseudoChowLiu::marginal (src/pseudo_chow_liu.cpp:130-138)"""
+    rest = [i for i in range(T.shape[0]) if i not in set(keep)]
+    if not rest:
+        return T[np.ix_(keep, keep)]
+    return T[np.ix_(keep, keep)] - T[np.ix_(keep, rest)] @ np.linalg.solve(T[np.ix_(rest, rest)], T[np.ix_(rest, keep)])
+
+
+def numpy_posdef_pinv(a):
+    """posdef_pinv (src/topology_provider_glc.cpp:42-56)"""
+    w, V = np.linalg.eigh(a)
+    tol = np.finfo(float).eps * a.shape[0] * np.abs(w).max()
+    inv = np.where(w > tol, 1.0 / np.where(w > tol, w, 1.0), 0.0)
+    return (V * inv) @ V.T
+
+
+@pytest.mark.parametrize("case", ["manhattan_glc_tree", "sphere_glc_tree", "intel_glc_tree_10pct"])
+def test_glc_tree_blanket_against_numpy_restatement(case, oracle):
+    """The GLC Tree tail restated independently in numpy/LAPACK on first-round blankets: the Chow-Liu tree (topology
+    bit-identical), the root marginal, the conditional targets [[jaa, jab],[jba, jba pinv(jaa) jab]]
+    (src/topology_provider_glc.cpp:134-176) and getEdge; measurements and W^T W of every edge the oracle emits."""
+    g, which, opts, _, _, _ = util.load_golden(case)
+    d = g["pose_dim"]
+    ps = abi.pose_stride(d)
+    batch, roots = util.first_round_batch(g, which, opts, limit=40)
+    ref = abi.marginalize_batch(oracle, None, opts, batch)
+    checked = 0
+    for b in range(len(roots)):
+        v0, v1 = batch["vert_off"][b], batch["vert_off"][b + 1]
+        k = (v1 - v0) - 1
+        if ref["status"][b] != 0 or k < 2:
+            continue
+        ids = list(batch["vert_id"][v0:v1])
+        poses = [np.ascontiguousarray(batch["pose"][v * ps:(v + 1) * ps]) for v in range(v0 + 1, v1)]   # kept, ascending id
+        lo, hi = ref["target_info_off"][b], ref["target_info_off"][b + 1]
+        T = ref["target_info"][lo:hi].reshape(d * k, d * k)
+        tree = numpy_chow_liu(d, T)
+        expect = []
+        root = tree[0][0]
+        rblk = list(range(root * d, (root + 1) * d))
+        m_, G_, r_ = numpy_glc_edge(d, numpy_schur_onto(T, rblk), [poses[root]], oracle)
+        if r_ > 0:
+            expect.append(((ids[1 + root],), m_, G_))
+        for (i, j) in tree:
+            idx = list(range(i * d, (i + 1) * d)) + list(range(j * d, (j + 1) * d))
+            jm = numpy_schur_onto(T, idx)
+            jaa, jab, jba = jm[:d, :d], jm[:d, d:], jm[d:, :d]
+            tgt = np.block([[jaa, jab], [jba, jba @ numpy_posdef_pinv(jaa) @ jab]])
+            tgt = np.triu(tgt) + np.triu(tgt, 1).T
+            m_, G_, r_ = numpy_glc_edge(d, tgt, [poses[i], poses[j]], oracle)
+            if r_ > 0:
+                expect.append(((ids[1 + i], ids[1 + j]), m_, G_))
+        got = []
+        for e in range(ref["new_edge_off"][b], ref["new_edge_off"][b + 1]):
+            vs = tuple(int(x) for x in ref["new_edge_vert"][ref["new_edge_vert_off"][e]:ref["new_edge_vert_off"][e + 1]])
+            data = ref["new_edge_data"][ref["new_edge_data_off"][e]:ref["new_edge_data_off"][e + 1]]
+            n = d * len(vs)
+            W = data[n:].reshape(-1, n)
+            got.append((vs, data[:n], W.T @ W))
+        if ref["min_gap"][b] < 1e-9:
+            continue   # a near-tie between two Chow-Liu weights: the tree is not determined at this precision
+        assert [v for v, *_ in got] == [v for v, *_ in expect], (b, [v for v, *_ in got], [v for v, *_ in expect])
+        for (_, ma, Ga), (_, mb, Gb) in zip(got, expect):
+            assert util.rel_err(ma, mb) < 1e-10
+            assert util.rel_err(Ga, Gb) < 1e-8
+        checked += 1
+    assert checked >= 15
 
 
 def test_local_linearization_point_chain(oracle):
