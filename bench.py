@@ -4,18 +4,22 @@
 One "step" = one full GraphWrapper::marginalizeNoOptimize of the globalDecimate(sparsity 2) removal
 list (49 998 vertices) on a fresh, HBM-resident replica of the graph: host scheduling of the
 conflict-free rounds + the per-blanket HIP kernel + graph update. Inputs (poses + edge records) are
-resident in HBM before the timed region starts; per round only int descriptors go up and the
+resident in HBM before the timed region starts; per batch only int descriptors go up and the
 per-blanket output records come back.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds a replica; batches of
->= 2048 blankets are sharded over the ranks with one all-gather (RCCL over xGMI) of the recovered edge
-records, narrower (latency-bound) batches are computed redundantly by every rank — total work is
-fixed, so scaling is "strong" (DESIGN.md 6 explains why it stays near 1x on this workload).
+N > 1 (launched by torch.distributed.run, one rank per GPU): the path partitions by graph — the reference's own
+parallelism is one whole job per thread (src/evaluate.cpp:413-433) — so every rank sparsifies ITS OWN 100k-pose graph
+(same generator, rank-dependent seed), no data-path collective, `value` = nodes all ranks removed / max-over-ranks
+time, "scaling": "weak". The one-graph-on-N-GPUs view (replicas, batches sharded + RCCL all-gather when the cost model
+says it pays: never on this workload, whose rounds are ~200 blankets deep-chained) is reported under `multi_gpu`.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel,
-HIP-event timed on its own stream) and, at N = 1, `cpu_baseline` (the CPU oracle: strictly sequential
-on 1 core = the reference's execution model, plus `rounds_all_cores`: the same rounds over the host
-cores) and `parity` (the device result of the last step against that sequential oracle run).
+`--config parking`: BASELINE config 4 (parking.g2o, NFR Tree, sparsity 2; graph from tests/golden) with the same
+contract; at N > 1 the ranks share one replicated graph and the line carries `exchanged_batches` / bytes all-gathered.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel — the persistent
+worker kernel that processes the narrow batches, HIP-event timed on its own stream) and, at N = 1, `cpu_baseline` (the
+CPU oracle: strictly sequential on 1 core = the reference's execution model, plus `rounds_all_cores`) and `parity` (the
+device result of the last step against that sequential oracle run).
 """
 import argparse
 import json
@@ -67,6 +71,8 @@ def main():
     ap.add_argument("--sparsity", type=int, default=2)
     ap.add_argument("--lin-point", choices=["global", "local"], default="global",
                     help="linearisation point (BASELINE config 5 is Global; local = the reference's default, LM on the blankets)")
+    ap.add_argument("--config", choices=["synthetic", "parking"], default="synthetic",
+                    help="synthetic = BASELINE config 5 (the headline metric); parking = config 4 (parking.g2o from tests/golden)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-poses", type=int, default=0, help="0 = full workload")
     args = ap.parse_args()
@@ -108,9 +114,15 @@ def main():
             numa_note += ", graph thread on one core"
         except Exception:
             pass
-    g = g2o_io.synth_sphere(n_poses=args.poses, ring=args.ring)
-    last = int(g["ids"][-1])
-    which = np.array(globalDecimate(last, last, DecimateOptions(args.sparsity)), np.int32)
+    if args.config == "parking":
+        from tests import util as _util
+        g, which, *_ = _util.load_golden("parking_full_nfr_tree")
+        which = np.asarray(which, np.int32)
+    else:
+        # N > 1: one graph per rank (weak scaling), same generator, rank-dependent noise seed
+        g = g2o_io.synth_sphere(n_poses=args.poses, ring=args.ring, seed=20240611 + rank)
+        last = int(g["ids"][-1])
+        which = np.array(globalDecimate(last, last, DecimateOptions(args.sparsity)), np.int32)
     opts = abi.make_options(6, abi.ALG_NFR, abi.TOPO_TREE, abi.LIN_GLOBAL if args.lin_point == "global" else abi.LIN_LOCAL)
 
     n_rep = args.warmup + args.steps
@@ -121,8 +133,10 @@ def main():
         hg.reserve(arena_need)  # uploads poses + edge records: resident in HBM before timing
         replicas.append(hg)
 
+    shared_graph = world > 1 and args.config == "parking"   # one replicated graph, sharded by the library's policy
+
     def run(hg):
-        if world > 1:
+        if shared_graph:
             return marginalize_sharded(hg, which, opts, device=device)
         return hg.marginalizeNoOptimize(which, opts)
 
@@ -151,10 +165,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # N > 1 only, outside the timed region of `value`: two more views of the same machine, each guarded so
-    # that a failure costs a field, not the bench line.
+    # N > 1 only, outside the timed region of `value`: the one-graph views, each guarded so that a failure costs a
+    # field, not the bench line.
     multi = {}
-    if world > 1:
+    if world > 1 and args.config == "synthetic":
         def timed(fn, reps):
             fence()
             t1 = time.perf_counter()
@@ -166,17 +180,19 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item()), res
         try:
-            # (1) one independent 100k-pose graph per GPU, no collective (the reference's job farm runs one
-            #     graph per thread): aggregate nodes/s over all ranks
-            reps = [GraphWrapperHIP.from_dict(g, ctx=ctx) for _ in range(2)]
+            # (1) ONE 100k-pose graph replicated on all ranks, the library's default sharding policy (cost model): its
+            #     rounds are ~200 blankets, so nothing is worth an exchange and every rank computes everything
+            g0 = g2o_io.synth_sphere(n_poses=args.poses, ring=args.ring)
+            reps = [GraphWrapperHIP.from_dict(g0, ctx=ctx) for _ in range(2)]
             for hg in reps:
                 hg.reserve(arena_need)
             it = iter(reps)
-            secs, st1 = timed(lambda: next(it).marginalizeNoOptimize(which, opts), len(reps))
-            multi["independent_graphs"] = {"value": world * st1["n_removed"] * len(reps) / secs, "unit": "nodes/s", "scaling": "weak",
-                                           "what": f"{world} x the same workload, one graph per GPU, no collective"}
+            secs, st1 = timed(lambda: marginalize_sharded(next(it), which, opts, device=device), len(reps))
+            multi["one_graph_replicated"] = {"value": st1["n_removed"] * len(reps) / secs, "unit": "nodes/s", "scaling": "strong",
+                                             "exchanged_batches": st1["n_exchanged"], "batches": st1["n_batches"],
+                                             "what": "the same single graph on every rank; batches sharded + all-gathered only when the cost model says it pays"}
         except Exception as e:
-            multi["independent_graphs"] = {"error": str(e)[:200]}
+            multi["one_graph_replicated"] = {"error": str(e)[:200]}
         try:
             # (2) a graph whose rounds are wide (2 rings of 100 000 poses: ~50k independent blankets per
             #     batch), so that every batch IS sharded over the ranks and all-gathered (RCCL over xGMI)
@@ -188,22 +204,28 @@ def main():
             itw = iter(hw)
             secs, stw = timed(lambda: marginalize_sharded(next(itw), ww, opts, device=device), len(hw))
             multi["wide_rounds"] = {"value": stw["n_removed"] * len(hw) / secs, "unit": "nodes/s", "scaling": "strong",
-                                    "removed": stw["n_removed"], "batches": stw["n_rounds"], "kld_sum": stw["kld_sum"],
-                                    "what": "synthetic SE3 graph of 2 rings x 100 000 poses: every batch (~50k blankets) sharded over the ranks + one all-gather"}
+                                    "removed": stw["n_removed"], "batches": stw["n_batches"], "exchanged_batches": stw["n_exchanged"],
+                                    "exchanged_bytes": stw["exchanged_bytes"], "exchange_seconds": stw["exchange_seconds"], "kld_sum": stw["kld_sum"],
+                                    "what": "synthetic SE3 graph of 2 rings x 100 000 poses: batches of ~50k blankets sharded over the ranks + one all-gather each"}
         except Exception as e:
             multi["wide_rounds"] = {"error": str(e)[:200]}
 
     removed = stats["n_removed"]
-    value = removed * args.steps / dt
+    weak = world > 1 and not shared_graph
+    value = (world if weak else 1) * removed * args.steps / dt
     out = {
         "metric": "nodes_marginalized_per_s", "value": value, "unit": "nodes/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic" if args.config == "synthetic" else "parking.g2o (reference dataset, via tests/golden)",
         "config": {
-            "workload": f"synthetic SE3 sphere-spiral pose graph, {args.poses} poses ({args.poses // args.ring} rings x {args.ring}), "
+            "workload": (f"synthetic SE3 sphere-spiral pose graph, {args.poses} poses ({args.poses // args.ring} rings x {args.ring}), " if args.config == "synthetic"
+                         else f"parking.g2o SE3, {len(g['ids'])} poses, ") +
                         f"{len(g['edge_ij'])} edges, NFR Tree, " + ("Global linearisation point = stored estimates, " if args.lin_point == "global" else "Local linearisation point (10 LM iterations per blanket), ") +
                         f"globalDecimate sparsity {args.sparsity} ({len(which)} removals), marginalizeNoOptimize only",
-            "parallelism": "single GPU" if world == 1 else f"replicated graph on {world} GPUs; batches of >= 2048 blankets sharded + one all-gather, narrower batches computed by every rank",
+            "parallelism": "single GPU" if world == 1 else (f"one graph per GPU ({world} independent graphs, no collective)" if weak else
+                           f"one replicated graph on {world} GPUs; a batch is sharded + all-gathered (RCCL) when the cost model says it pays, otherwise computed by every rank"),
+            "exchanged_batches": stats["n_exchanged"], "exchanged_bytes": stats["exchanged_bytes"], "exchange_seconds": stats["exchange_seconds"],
             "rounds": stats["n_rounds"], "removed": removed, "max_blanket": stats["max_blanket"],
             "kld_sum": stats["kld_sum"], "host_seconds_per_step": stats["host_seconds"], "device_wait_seconds_per_step": stats["device_seconds"],
             "schedule_seconds_per_step": stats["schedule_seconds"], "commit_seconds_per_step": stats["commit_seconds"],
@@ -211,28 +233,46 @@ def main():
             "batches": stats["n_batches"], "kernel_launches": stats["n_launches"], "worker": wprof,
         },
     }
-    if prof["launches"] > 0 and prof["kernel_ms"] > 0:
+    # The dominant kernel. Narrow batches (this workload: all of them after the first two) run inside ONE persistent
+    # worker kernel per marginalisation (blanket_worker, csrc/spg_kernels.hip): "a launch" is one such run = one step,
+    # its duration (HIP events on its stream) includes the time its workgroups wait for the host's next batch.
+    traffic, traffic_note = None, None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+        if world == 1 and args.config == "synthetic" and args.poses == 100000 and args.ring == 400:
+            traffic = pm["traffic_bytes_per_launch"]
+            traffic_note = ("NOT measured in this run: from the committed rocprofv3 --pmc passes of this same command (profiles/r02_pmc_summary.json: "
+                            "FETCH_SIZE + WRITE_SIZE of the worker kernel, separate passes, per launch)")
+    except Exception:
+        pass
+    if wprof["runs"] > 0 and wprof["kernel_ms"] > 0 and wprof["blankets"] >= 0.5 * removed * args.steps:
+        per_launch_bytes = wprof["alg_bytes"] / wprof["runs"]
+        per_launch_s = 1e-3 * wprof["kernel_ms"] / wprof["runs"]
+        achieved = per_launch_bytes / per_launch_s / 1e9
+        flops = FLOP_PER_NODE_K4 * wprof["blankets"] / (1e-3 * wprof["kernel_ms"]) / 1e12
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_note": traffic_note,
+            "kernel": "blanket_worker<6,NFR> (persistent: one launch per marginalisation, fed through a queue)",
+            "launches": wprof["runs"], "event_sampling": "HIP events around every run of the worker kernel in the timed region",
+            "avg_launch_us": 1e6 * per_launch_s, "alg_bytes_per_launch": per_launch_bytes,
+            "blankets_per_launch": wprof["blankets"] / wprof["runs"],
+            "other_launches": {"launches": prof["launches"], "kernel_ms": prof["kernel_ms"], "blankets": prof["blankets"],
+                               "what": "batches launched the ordinary way (first two of a call, blankets the worker does not take)"},
+            "note": "the path is latency-bound, not HBM-bound: ~250 dependent rounds of ~200 blankets, one blanket = one ~45 us dependent chain "
+                    "(SURVEY.md 8d: ~110 flop/B on paper); fp64 vector fraction alongside",
+            "fp64_vector_tflops_est": flops, "fp64_vector_frac_est": flops / FP64_VECTOR_PEAK_TFLOPS,
+        }
+    elif prof["launches"] > 0 and prof["kernel_ms"] > 0:
         per_launch_bytes = prof["alg_bytes"] / prof["launches"]
         per_launch_s = 1e-3 * prof["kernel_ms"] / prof["launches"]
         achieved = per_launch_bytes / per_launch_s / 1e9
         flops = FLOP_PER_NODE_K4 * prof["blankets"] / (1e-3 * prof["kernel_ms"]) / 1e12
-        # HBM traffic cannot be read inside this process: it comes from separate rocprofv3 --pmc passes
-        # of this same command (FETCH_SIZE, WRITE_SIZE), summarised under profiles/
-        traffic, traffic_note = None, None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            if world == 1 and args.poses == 100000 and args.ring == 400:
-                # per launch, from the PMC passes of this same command
-                traffic = pm["traffic_bytes_total_uncorrected_per_step"] / pm["launches_per_step"]
-                traffic_note = "profiles/r01_pmc_summary.json: (FETCH_SIZE + WRITE_SIZE) * 1024 per launch, separate --pmc passes, uncorrected (8 B/lane gathers are outside the guide's calibration; includes instruction fetch)"
-        except Exception:
-            pass
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic, "traffic_note": traffic_note,
-            # launches of <= 512 blankets give every blanket two wavefronts (NT = 128), larger ones one (NT = 64)
+            "traffic": None, "traffic_note": None,
             "kernel": "blanket_kernel<6,128,false,NFR>" if prof["blankets"] / prof["launches"] <= 512 else "blanket_kernel<6,64,false,NFR>",
-            "launches": prof["launches"], "event_sampling": "HIP events around every launch of the timed region" if EVENT_STRIDE == 1 else f"HIP events around every {EVENT_STRIDE}-th launch",
+            "launches": prof["launches"], "event_sampling": "HIP events around every launch of the timed region",
             "avg_launch_us": 1e6 * per_launch_s, "alg_bytes_per_launch": per_launch_bytes,
             "blankets_per_launch": prof["blankets"] / prof["launches"],
             "note": "path is fp64-ALU/latency-bound on paper (SURVEY.md 8d: ~110 flop/B); fp64 vector fraction alongside",

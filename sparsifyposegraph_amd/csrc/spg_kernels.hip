@@ -1359,14 +1359,6 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
     finish();
 }
 
-// out-of-line entry for the persistent worker: the body keeps its own register allocation (inlined into the worker's
-// ticket loop it spilled 119 VGPRs to scratch)
-template <int D, int ALG>
-__device__ __attribute__((noinline)) void blanket_body_call(const KArgs *a, const spg_blanket_desc *bd, const int64_t *bvpo, const spg_edge_ref *ber,
-                                                           const int32_t *bev, double *smem) {
-    blanket_body<D, 128, false, ALG, true>(*a, *bd, bvpo, ber, bev, 0, uniptr(smem));
-}
-
 template <int D, int NT, bool GWS, int ALG>
 __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     extern __shared__ double smem[];
@@ -1408,7 +1400,7 @@ __device__ __forceinline__ unsigned long long load_sys(const unsigned long long 
 
 
 template <int D, int ALG>
-__global__ void __launch_bounds__(128, 2) blanket_worker(WorkQ *q, unsigned long long *ticket, long long idle_ticks, int n_bells, int lazy) {
+__global__ void __launch_bounds__(128) blanket_worker(WorkQ *q, unsigned long long *ticket, long long idle_ticks, int n_bells, int lazy) {
     extern __shared__ double smem[];
     __shared__ unsigned long long pk[kPktWords];
     __shared__ unsigned long long s_item;
@@ -1420,7 +1412,9 @@ __global__ void __launch_bounds__(128, 2) blanket_worker(WorkQ *q, unsigned long
             long long t0 = wall_clock64();
             unsigned long long seen = ~0ULL;
             for (;;) {
-                const unsigned long long tail = __hip_atomic_load(&q->tail[(blockIdx.x % n_bells) * kBellStride], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                // (relaxed: an acquire here would invalidate this XCD's L1 / L2 on every poll of every idle workgroup — the item and
+                //  the packet are read with system-scope loads that bypass the caches anyway)
+                const unsigned long long tail = load_sys(&q->tail[(blockIdx.x % n_bells) * kBellStride]);
                 if (tail > my) { it = load_sys(&q->item[my % kQCap]); break; }
                 if (load_sys(&q->stop)) break;
                 if (tail != seen) { seen = tail; t0 = wall_clock64(); }
@@ -1470,11 +1464,11 @@ __global__ void __launch_bounds__(128, 2) blanket_worker(WorkQ *q, unsigned long
         const spg_edge_ref *er = reinterpret_cast<const spg_edge_ref *>(pk + kPktHdr + bd.n_vert);
         const int32_t *ev = reinterpret_cast<const int32_t *>(pk + kPktHdr + bd.n_vert + 3 * bd.n_edge);
         const long long t_body = wall_clock64();
-#ifdef SPG_WORKER_INLINE
+        // inlined: as an out-of-line call the body saved / restored 56 callee-saved VGPRs per blanket through scratch —
+        // 28 KB per workgroup and item, 1.3 GB of HBM writes per step of the bench workload (rocprofv3 WRITE_SIZE). Inlined
+        // it needs the whole register file of a SIMD (256 VGPRs + ~110 AGPRs as spill space, no scratch): one wave per
+        // SIMD, which is what a grid of one 2-wave workgroup per CU uses anyway.
         blanket_body<D, 128, false, ALG, true>(a, bd, vpo, er, ev, 0, smem);
-#else
-        blanket_body_call<D, ALG>(&a, &bd, vpo, er, ev, smem);
-#endif
         __syncthreads();
         if ((h[12] >> 32) & 0x40000000u) {
             // diagnostic (SPG_WORKER_STAMP=1): min_gap slot <- staging ticks + 1e-6 * body ticks (100 MHz wall clock); the final

@@ -10,9 +10,13 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
 python bench.py --steps $STEPS --warmup 1 > $OUT/prof_bench.json 2> $OUT/prof_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o run -- python3 bench.py --steps $STEPS --warmup 1 --no-cpu-baseline > $OUT/prof_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch -o run -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write -o run -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_write.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kld -o run -- python3 tools/kld_bench.py 2500 > $OUT/prof_kld.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o run -- python3 bench.py --steps $STEPS --warmup 1 --no-cpu-baseline > $OUT/prof_stats.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/prof_fetch.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/prof_write.log 2>&1
+if [ "${WITH_KLD:-0}" = "1" ]; then
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kld -o run -- python3 tools/kld_bench.py 2500 > $OUT/prof_kld.log 2>&1
 python tools/throughput_bench.py 64 512 16384 131072 > $OUT/prof_throughput.log 2>&1
+fi
+# large-blanket path (GLC Dense on sphere.g2o at full size): kernel stats of the dense pipeline
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_big -o run -- python3 tools/big_bench.py > $OUT/prof_big.log 2>&1 || true
 find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -name '*.csv' | head -20

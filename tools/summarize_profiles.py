@@ -36,9 +36,10 @@ def counter(dirname, name):
             if r["Counter_Name"] != name:
                 continue
             k = r["Kernel_Name"]
-            s = per.setdefault(k, [0, 0.0])
+            s = per.setdefault(k, [0, 0.0, 0.0])
             s[0] += 1
             s[1] += float(r["Counter_Value"])
+            s[2] = float(r["Counter_Value"])   # the last dispatch (rows are in dispatch order)
             meta[k] = {x: r.get(x) for x in ("VGPR_Count", "Scratch_Size", "LDS_Block_Size", "Workgroup_Size")}
     return per, meta
 
@@ -48,19 +49,31 @@ write, _ = counter("prof_write", "WRITE_SIZE")
 kernels = {}
 tot_f = tot_w = 0.0
 launches = 0
+worker = None
 for k in fetch:
-    if "blanket_kernel" not in k:
+    if "blanket_kernel" not in k and "blanket_worker" not in k:
         continue
-    n, f = fetch[k]
-    w = write.get(k, [0, 0.0])[1]
+    if "blanket_worker" in k:
+        worker = k
+    n, f, f_last = fetch[k]
+    w, w_last = write.get(k, [0, 0.0, 0.0])[1:3]
     tot_f += f
     tot_w += w
     launches += n
-    kernels[k] = {"launches": n, "FETCH_SIZE_KB_total": f, "WRITE_SIZE_KB_total": w, **meta[k]}
+    kernels[k] = {"launches": n, "FETCH_SIZE_KB_total": f, "WRITE_SIZE_KB_total": w, "FETCH_SIZE_KB_last_dispatch": f_last,
+                  "WRITE_SIZE_KB_last_dispatch": w_last, **meta[k]}
 rf = bench.get("roofline", {})
 steps_alg = rf.get("alg_bytes_per_launch", 0) * rf.get("launches", 0) / max(bench["steps"], 1)
+wk = kernels.get(worker) if worker else None
 summary = {
-    "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+    # the dominant kernel of the pipelined driver since round 2: one persistent worker kernel per marginalisation
+    "dominant_kernel": worker,
+    # per launch = the LAST dispatch of the worker kernel in the pass (the timed step after one warm-up step; the first step
+    # of a process restarts the worker a few times while its buffers grow)
+    "traffic_bytes_per_launch": ((wk["FETCH_SIZE_KB_last_dispatch"] + wk["WRITE_SIZE_KB_last_dispatch"]) * 1024) if wk else None,
+    "fetch_bytes_per_launch_uncorrected": (wk["FETCH_SIZE_KB_last_dispatch"] * 1024) if wk else None,
+    "write_bytes_per_launch": (wk["WRITE_SIZE_KB_last_dispatch"] * 1024) if wk else None,
+    "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline",
     "kernels": kernels,
     "launches_per_step": launches,
     "traffic_bytes_total_uncorrected_per_step": (tot_f + tot_w) * 1024,
@@ -69,7 +82,7 @@ summary = {
     "notes": [
         "counter unit = KB (guide: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024); one step = one whole marginalizeNoOptimize of the 100k-pose workload",
         "the guide's gfx950 x2 correction of FETCH_SIZE is calibrated for 16 B/lane coalesced streams only; this kernel gathers 8 B/lane records, so the absolute is uncalibrated and reported uncorrected",
-        "FETCH includes the instruction fetch of a fully unrolled kernel through 8 per-XCD L2s, which dominates at the ~50-200 blankets per launch of the pipelined driver",
+        "FETCH includes the instruction fetch of a fully unrolled kernel through 8 per-XCD L2s, the polls of idle worker workgroups (uncached 8-byte reads of the queue tail) and the agent-scope (L2-bypassing) reads of edge records",
         "WRITE includes the out records the kernel stores straight into the pinned host mailbox",
     ],
 }
