@@ -282,7 +282,10 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
         // possible iff every vertex but the first removed one sits in exactly one (pose-pose) blanket edge;
         // then the removed vertex goes to the origin and each neighbour to z (or z^-1) of its edge.
         if (is_glc) { status = SPG_ST_UNSUPPORTED; finish(); return; }  // src/topology_provider_glc.cpp:110-111
-        int *cntv = perm;  // n >= nv ints whenever k >= 1 (D >= 3); k == 0 has no kept vertex to place
+        // the per-vertex edge counters below live in perm[] (n ints): a cluster with many removed and few kept vertices
+        // (n < nv) would write past it, and clusters under a Local point are not built anyway — leave before any write
+        if (n < nv || m != 1) { status = SPG_ST_NEEDS_LOCAL_OPTIMIZATION; finish(); return; }
+        int *cntv = perm;
         for (int v = tid; v < nv; v += NT) cntv[v] = 0;
         T.sync();
         for (int e = tid; e < bd.n_edge; e += NT) {
