@@ -211,7 +211,7 @@ struct spg_graph {
     std::vector<int32_t> pending;   // removal list (vertex indices) in the caller's order; [pend_head, end) is still to do
     size_t pend_head = 0;
     std::vector<uint8_t> in_set;   // vertex index is in the removal list
-    static constexpr int NB = 4;                      // batches that can be in flight (= backend launch slots)
+    static constexpr int NB = 8;                      // batches that can be in flight (= backend launch slots)
     Batch bt[NB];
     Batch *B = &bt[0];                                // batch the round functions currently work on
     // Owner registry of the scheduler: every scheduled-but-uncommitted blanket and every vertex deferred
@@ -227,7 +227,7 @@ struct spg_graph {
     int round_no = 0, launch_seq = 0;
     bool pipelined = false;                           // two batches in flight (single rank, backend with slots)
     spg_marg_stats stats{};
-    double tr_age = 0, tr_wait = 0; long tr_n = 0;   // SPG_TRACE=1: launch->commit-start, wait inside commit
+    double tr_age = 0, tr_wait = 0, tr_first = 0; long tr_n = 0;   // SPG_TRACE=1: launch->commit-start, wait inside commit, launch->first ready word
     std::vector<BlanketLog> log;
     std::vector<double> hdr_buf;
     // Submission thread of the pipelined driver: the graph thread selects and commits, this one writes the descriptors
@@ -1101,7 +1101,7 @@ static void schedule_round(spg_graph *g) {
             // (almost always) waiting on them too, and not scanning only defers more
             // (with another batch in flight the blocked stretch is usually exactly the part of the list
             //  that waits for it: give up sooner, the next call comes right after that batch commits)
-            static const int pat_inflight = [] { const char *e = getenv("SPG_PATIENCE"); return e ? atoi(e) : 12; }();
+            static const int pat_inflight = [] { const char *e = getenv("SPG_PATIENCE"); return e ? atoi(e) : 16; }();
             size_t patience = inflight ? pat_inflight + bt.rb.size() / 16 : 48 + bt.rb.size() / 8;
             if (++consec > patience || n_deferred > 256 + 2 * bt.rb.size()) stop = true;
             PT(3);
@@ -1573,8 +1573,10 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
         const double want = SPG_READY_WORD(bt.tag), want_final = SPG_FINAL_WORD(bt.tag);
         const double t_spin = now_s();
         polled = true;
+        bool first_seen = false;
         for (const RoundBlanket &r : bt.rb) {
             const volatile double *flag = mail + (r.desc.out_off - base) + 5;
+            if (first_seen == false && &r != &bt.rb[0]) { g->tr_first += now_s() - bt.t_launch; first_seen = true; }
             uint32_t spins = 0;
             for (double fv = *flag; fv != want && fv != want_final; fv = *flag) {
                 if ((++spins & 0x3fff) == 0 && now_s() - t_spin > 5.0) { polled = false; break; }
@@ -1677,9 +1679,9 @@ extern "C" int spg_graph_marginalize_end(spg_graph *g, spg_marg_stats *stats) {
     g->B = &g->bt[0];
     if (g->ctx->is_hip) (void)spg::hip_backend_end_of_call(&g->ctx->be);
     if (g->tr_n && getenv("SPG_TRACE"))
-        fprintf(stderr, "spg trace: %ld batches; per batch: launch call -> commit start %.1f us, wait for the ready words %.1f us\n",
-                g->tr_n, 1e6 * g->tr_age / g->tr_n, 1e6 * g->tr_wait / g->tr_n);
-    g->tr_n = 0; g->tr_age = g->tr_wait = 0;
+        fprintf(stderr, "spg trace: %ld batches; per batch: launch call -> commit start %.1f us, wait for the ready words %.1f us (launch call -> first blanket ready %.1f us)\n",
+                g->tr_n, 1e6 * g->tr_age / g->tr_n, 1e6 * g->tr_wait / g->tr_n, 1e6 * g->tr_first / g->tr_n);
+    g->tr_n = 0; g->tr_age = g->tr_wait = g->tr_first = 0;
     if (g->ctx->is_hip) g->stats.n_launches = spg::hip_backend_launches(&g->ctx->be);
 #ifdef SPG_SCHED_PROF
     if (getenv("SPG_SCHED_PROF")) {
@@ -1751,8 +1753,10 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
         constexpr int NB = spg_graph::NB;
         rc = 0;
         const char *e1 = getenv("SPG_SPLIT_MIN"), *e2 = getenv("SPG_MAX_INFLIGHT");
-        const size_t split_min = e1 ? (size_t)atoi(e1) : 24;
-        const int max_inflight = e2 ? std::max(1, std::min(NB, atoi(e2))) : NB;
+        // defaults from sweeps on 100k-pose lattices with rings of 250 ... 1000: parts of >= 48 blankets,
+        // four batches in flight (more only add passes), patience 16
+        const size_t split_min = e1 ? (size_t)atoi(e1) : 48;
+        const int max_inflight = e2 ? std::max(1, std::min(NB, atoi(e2))) : 4;
         auto commit_all = [&]() -> int {
             for (;;) {
                 Batch *o = nullptr;

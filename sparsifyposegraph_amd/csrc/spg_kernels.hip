@@ -166,6 +166,16 @@ __device__ __forceinline__ double ldrec(const double *p) {
     return *p;
 }
 
+// ... and written with system-scope (write-through) stores there: the ready word may then follow after a plain
+// s_waitcnt instead of a system-scope release fence, which writes back every dirty line of the XCD's L2 (measured:
+// publish() 11.7k cycles of a 90k-cycle blanket with the fence).
+template <bool COH>
+__device__ __forceinline__ void strec(double *p, double v) {
+    if (COH) __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else *p = v;
+}
+__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int D, int NT, bool GWS, int ALG, bool COH = false>
 __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanket_desc &bd_in, const int64_t *bvpo_in, const spg_edge_ref *ber_in,
                                              const int32_t *bev_in, const int gws_slot, double *smem) {
@@ -217,7 +227,42 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
     // publish(): everything the host's graph update needs — status so far, n_new, the new-edge table —
     // followed by a system-scope release and the ready tag. finish() = publish (unless done) + KLD.
     bool published = false;
+    // Worker (COH): the new edge records and the out record are staged in LDS (recbuf / orl) and leave as a few
+    // coalesced write-through stores — one word per lane — instead of ~110 single stores by the lanes that compute them:
+    // a system-scope store is acknowledged over the fabric (PCIe for the mailbox), and a lane that issues them one by one
+    // pays that round trip per store.
+    double *recbuf = smem + L.o_eJ;     // ne x REC doubles (eJ is free after the assembly)
+    double *orl = smem + L.o_eO;        // the out record (<= 6 + 4 k + 2 k doubles; eO is free after the assembly)
     auto publish = [&]() {
+        if (COH) {
+            T.sync();   // recbuf is complete
+            const int nrec = n_new * REC;
+            for (int it = tid; it < nrec; it += NT) strec<true>(arena + bd.new_off + it, recbuf[it]);
+            if (tid == 0) {
+                orl[0] = (double)status; orl[1] = (double)info; orl[2] = kld; orl[3] = min_gap; orl[4] = (double)n_new; orl[5] = 0.0;
+                for (int e = 0; e < n_new; e++) {
+                    orl[SPG_OUT_HDR + 4 * e + 0] = (double)SPG_EDGE_BINARY;
+                    orl[SPG_OUT_HDR + 4 * e + 1] = (double)(e * REC);
+                    orl[SPG_OUT_HDR + 4 * e + 2] = (double)REC;
+                    orl[SPG_OUT_HDR + 4 * e + 3] = 2.0;
+                    orl[SPG_OUT_HDR + 4 * bd.n_new_max + 2 * e + 0] = (double)(m + pairs[2 * e]);
+                    orl[SPG_OUT_HDR + 4 * bd.n_new_max + 2 * e + 1] = (double)(m + pairs[2 * e + 1]);
+                }
+            }
+            wait_stores();   // this lane's record stores have been acknowledged
+            T.sync();        // ... everybody's; orl is complete
+            const int olen = SPG_OUT_HDR + 4 * bd.n_new_max + 2 * n_new;
+            if (tid < 64) {   // (wave 0; olen <= 42 for the blankets a worker takes)
+                for (int t = tid; t < olen; t += 64) if (t != 5) strec<true>(orec + t, orl[t]);
+                wait_stores();   // wave 0's stores are out before its lane 0 raises the ready word
+                if (tid == 0) {
+                    __hip_atomic_store(&orec[5], SPG_READY_WORD(a.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    orl[5] = (double)wall_clock64();   // (SPG_WORKER_STAMP diagnostics: when the ready word left)
+                }
+            }
+            published = true;
+            return;
+        }
         T.sync();  // every lane's new-record stores precede the release below
         if (tid == 0) {
             orec[0] = (double)status; orec[1] = (double)info; orec[2] = kld; orec[3] = min_gap; orec[4] = (double)n_new;
@@ -239,11 +284,11 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
     };
     auto finish = [&]() {
         if (!published) publish();
-        else if (tid == 0) { orec[2] = kld; orec[0] = (double)status; }
+        else if (tid == 0) { strec<COH>(orec + 2, kld); strec<COH>(orec + 0, (double)status); }
         // the record is complete (KLD and a possible SPG_ST_KLD_NOT_PD included): final word, after a release
         if (tid == 0) {
-            __threadfence_system();
-            __hip_atomic_store(&orec[5], SPG_FINAL_WORD(a.tag), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (COH) { wait_stores(); __hip_atomic_store(&orec[5], SPG_FINAL_WORD(a.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+            else { __threadfence_system(); __hip_atomic_store(&orec[5], SPG_FINAL_WORD(a.tag), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
     };
     // diagnostic cycle stamps (flags bit 16, needs tinfo_off >= 0): written only to the debug region
@@ -252,6 +297,13 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
         if (stamping) {
             T.sync();
             if (tid == 0) arena[bd.tinfo_off + idx] = (double)__builtin_amdgcn_s_memtime();
+        }
+    };
+    // inside the two concurrent chains of the two-wavefront variant: no workgroup barrier, lane 0 of each wave stamps
+    auto CSTAMP = [&](int idx) {
+        if (stamping) {
+            if (!split) { T.sync(); if (tid == 0) arena[bd.tinfo_off + idx] = (double)__builtin_amdgcn_s_memtime(); }
+            else if ((tid & 63) == 0) arena[bd.tinfo_off + idx] = (double)__builtin_amdgcn_s_memtime();
         }
     };
     STAMP(0);  //
@@ -767,12 +819,12 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             TT.sync();
             chol_lower(TT, M2, n, ld, ev);
             if ((*TT.flag)) return (int)SPG_ST_TIKHONOV_NOT_PD;
-            if (!split) STAMP(3);  // cl chol
+            CSTAMP(3);  // cl chol
             tri_inverse_lower(TT, M2, M3, n, ld, ev);
-            if (!split) STAMP(4);  // cl triinv
+            CSTAMP(4);  // cl triinv
             gram_lower_inverse(TT, M3, M2, n, ld);
         }
-        if (!split) STAMP(5);  // cl gram
+        CSTAMP(5);  // cl gram
         // per-vertex diagonal blocks: Cholesky + log det
         for (int v = TT.tid; v < k; v += TT.size) {
             double Ab[DD];
@@ -792,7 +844,7 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             ldb[v] = 2.0 * lp.value();
         }
         TT.sync();
-        if (!split) STAMP(6);  // cl vertex chol
+        CSTAMP(6);  // cl vertex chol
         // pair weights w = ld_i + ld_j - ld_{ij}, ld_{ij} = ld_i + logdet(S_jj - S_ji S_ii^-1 S_ij)
         for (int p = TT.tid; p < L.P; p += TT.size) {
             int i = 0, rem = p;
@@ -830,9 +882,9 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
         }
         TT.sync();
         if ((*TT.flag)) return (int)SPG_ST_TIKHONOV_NOT_PD;
-        if (!split) STAMP(7);  // cl pair weights
+        CSTAMP(7);  // cl pair weights
         sort_ascending(TT, w, 1, L.P, sorted);
-        if (!split) STAMP(8);  // cl sort
+        CSTAMP(8);  // cl sort
         if (TT.tid == 0) {
             // Kruskal in pop order (src/pseudo_chow_liu.cpp:253-289); first `ne` of the bin are used
             for (int v = 0; v < k; v++) comp[v] = v;
@@ -861,6 +913,7 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
         TT.sync();
         min_gap = cs[0];
         TT.sync();
+        CSTAMP(29);  // cl kruskal + gap done
         return (int)SPG_OK;
     };
     if constexpr (is_glc) {
@@ -937,7 +990,7 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             }
         }
         TT.sync();
-        if (!split) STAMP(11);  // gauge basis
+        CSTAMP(11);  // gauge basis
         // ---- orthonormalise: N^ = N L^-T with N^T N = L L^T (D x D, one lane, registers)
         if (TT.tid < DD) {
             int rr = TT.tid / D, c = TT.tid - rr * D;
@@ -983,7 +1036,7 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             }
         }
         TT.sync();
-        if (!split) STAMP(12);  // orthonormalised
+        CSTAMP(12);  // orthonormalised
         // ---- C = Lambda_t + N^ N^^T into M3, Cholesky, inverse
         {
             int sh = ceil_log2(n), tot = n << sh;
@@ -999,7 +1052,7 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             }
             TT.sync();
         }
-        if (!split) STAMP(13);  // C formed
+        CSTAMP(13);  // C formed
         if ((use_wave_hw && TT.size == 64)) {
             double ldC, trC;
             bool ok_ = wave_spd_inverse(M3, ld, n, TT.tid, 0.0, M3, ldC, trC);
@@ -1011,18 +1064,19 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             if (!fail && trC < 5e4 && isfinite(trC)) {
                 if (TT.tid == 0) { xch[0] = 1.0; xch[1] = -ldC; }
             }
+            CSTAMP(30);  // gauge inverse done
         } else {
             chol_lower(TT, M3, n, ld, Sv);
-            if (!split) STAMP(14);  // C chol
+            CSTAMP(14);  // C chol
             bool fail = ((*TT.flag) != 0);
             TT.sync();
             if (TT.tid == 0) { (*TT.flag) = 0; }
             TT.sync();
             if (!fail) {
                 double ldC = chol_logdet(TT, M3, n, ld);
-                if (!split) STAMP(15);  // logdet
+                CSTAMP(15);  // logdet
                 tri_inverse_lower(TT, M3, M2, n, ld, Sv);
-                if (!split) STAMP(16);  // triinv
+                CSTAMP(16);  // triinv
                 // C^-1 = Li^T Li into M3 with its Frobenius norm
                 int sh = ceil_log2(n), tot = n << sh;
                 double f2 = 0;
@@ -1078,12 +1132,14 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             double Z[kIso], q[4];
             iso_inv_mul(pose + va * PSZ, pose + vb * PSZ, Z);
             R_to_quat(Z, q);
-            rec[0] = Z[9]; rec[1] = Z[10]; rec[2] = Z[11]; rec[3] = q[0]; rec[4] = q[1]; rec[5] = q[2]; rec[6] = q[3];
+            double *rw = COH ? (recbuf + e * REC) : rec;
+            rw[0] = Z[9]; rw[1] = Z[10]; rw[2] = Z[11]; rw[3] = q[0]; rw[4] = q[1]; rw[5] = q[2]; rw[6] = q[3];
             se3_edge_jac(pose + va * PSZ, pose + vb * PSZ, Z, nJ + e * 2 * DD, nJ + e * 2 * DD + DD, nullptr);
         } else {
             double z[3];
             se2_between(pose + va * PSZ, pose + vb * PSZ, z);
-            rec[0] = z[0]; rec[1] = z[1]; rec[2] = z[2];
+            double *rw = COH ? (recbuf + e * REC) : rec;
+            rw[0] = z[0]; rw[1] = z[1]; rw[2] = z[2];
             se2_edge_jac(pose + va * PSZ, pose + vb * PSZ, z, nJ + e * 2 * DD, nJ + e * 2 * DD + DD, nullptr);
         }
     }
@@ -1200,6 +1256,7 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             Pw[it] = s;
         }
         T.sync();
+        STAMP(31);  // closed form: J Sigma
         for (int it = tid; it < ne * DD; it += NT) {
             int e = it / DD, rc = it - e * DD, rr = rc / D, c = rc - rr * D;
             const double *Ja = nJ + e * 2 * DD, *Jb = Ja + DD;
@@ -1216,6 +1273,7 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             Bk[it] = v;
         }
         T.sync();
+        STAMP(32);  // closed form: B_e
         for (int e = tid; e < ne; e += NT) {
             double Ab[DD], Xr[DD];
 #pragma unroll
@@ -1223,7 +1281,7 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             double trs = 0;
             if (!chol_reg<D>(Ab)) misc[0] = 1;
             chol_inverse_reg<D>(Ab, Xr);
-            double *rec = arena + bd.new_off + (int64_t)e * REC + PS;
+            double *rec = COH ? (recbuf + e * REC + PS) : (arena + bd.new_off + (int64_t)e * REC + PS);
             int pidx = 0;
 #pragma unroll
             for (int i = 0; i < D; i++)
@@ -1236,6 +1294,7 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             tre[e] = trs;
         }
         T.sync();
+        STAMP(33);  // closed form: X_e = B_e^-1, records written
         if (misc[0]) { status = SPG_ST_CLOSED_FORM_NOT_PD; finish(); return; }
     }
     n_new = ne;
@@ -1474,11 +1533,12 @@ __global__ void __launch_bounds__(128) blanket_worker(WorkQ *q, unsigned long lo
         blanket_body<D, 128, false, ALG, true>(a, bd, vpo, er, ev, 0, smem);
         __syncthreads();
         if ((h[12] >> 32) & 0x40000000u) {
-            // diagnostic (SPG_WORKER_STAMP=1): min_gap slot <- staging ticks + 1e-6 * body ticks (100 MHz wall clock); the final
+            // diagnostic (SPG_WORKER_STAMP=1): min_gap slot <- ticks to the ready word + 1e-6 * ticks to the final word, from the pick (100 MHz wall clock); the final
             // word is rewritten after it so that the host's late harvest sees the stamp
             if (tid == 0 && a.mail) {
                 double *orec = a.mail + (bd.out_off - a.mail_base);
-                orec[3] = (double)(t_body - t_pick) + 1e-6 * (double)(wall_clock64() - t_body);   // ticks of 10 ns
+                const double *orl_ = smem + make_layout(D, 128, bd.n_vert - bd.n_remove, bd.n_remove, ALG, a.topology, bd.pad_).o_eO;
+                orec[3] = (double)((long long)orl_[5] - t_pick) + 1e-6 * (double)(wall_clock64() - t_pick);   // ticks of 10 ns: ready, final
                 __threadfence_system();
             }
         }
@@ -1530,7 +1590,7 @@ struct HipBackend {
         double prof_ms = 0, prof_bytes = 0;
         long long prof_launches = 0, prof_blankets = 0;
     };
-    static constexpr int NSLOT = 4;
+    static constexpr int NSLOT = 8;
     Slot slots[NSLOT];
     // the persistent worker kernel (one per backend, alive between the first narrow batch of a marginalisation and
     // the next full synchronisation)
@@ -1919,6 +1979,17 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
             bar_fence();
             W.last_push = std::chrono::steady_clock::now();
             W.bytes += wbytes; W.blankets += (long long)n_push;
+            static const bool echo_test = [] { const char *e = getenv("SPG_WORKER_ECHO_TEST"); return e && e[0] == '1'; }();
+            if (echo_test) {
+                // diagnostic: doorbell -> ready word of the batch's first blanket, on the host clock
+                const volatile double *rw = S.finals.front();
+                const double want_r = SPG_READY_WORD(rd->tag), want_f = SPG_FINAL_WORD(rd->tag);
+                auto t0 = std::chrono::steady_clock::now();
+                while (*rw != want_r && *rw != want_f) { if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 1.0) break; }
+                static double acc = 0; static long cnt = 0;
+                acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); cnt++;
+                if (cnt % 252 == 0) { fprintf(stderr, "worker echo test: doorbell -> first blanket ready %.1f us (avg over %ld batches of ~%zu)\n", acc / cnt, cnt, n_push); acc = 0; cnt = 0; }
+            }
             return 0;                                                      // the whole batch is with the worker
         }
     }

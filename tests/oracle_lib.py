@@ -182,7 +182,7 @@ class OracleBackend:
     product's multi-batch-in-flight path (scheduling against uncommitted batches, batch splitting,
     mailbox polling, late KLD harvest) without a GPU."""
 
-    NSLOT = 4
+    NSLOT = 8
 
     def __init__(self, slots=False, threads=1):
         self.L = lib()

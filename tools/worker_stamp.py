@@ -1,5 +1,4 @@
-"""Diagnostic: device-side time per blanket inside the persistent worker (SPG_WORKER_STAMP=1): staging (ticket taken ->
-descriptors in LDS) and body (-> final word), from the 100 MHz wall clock, on the bench workload."""
+"""Diagnostic: device-side time per blanket inside the persistent worker (SPG_WORKER_STAMP=1): ticket taken -> ready word and -> final word, from the 100 MHz wall clock, on the bench workload."""
 import os, sys
 os.environ["SPG_WORKER_STAMP"] = "1"
 import numpy as np
@@ -14,8 +13,8 @@ for rep in range(2):
     hg = GraphWrapperHIP.from_dict(g, ctx=ctx)
     st = hg.marginalizeNoOptimize(which, abi.make_options(6))
 mg = hg.blankets()["min_gap"]
-stage = np.floor(mg) * 0.01
-body = (mg - np.floor(mg)) * 1e6 * 0.01
-ok = (mg >= 1) & (body > 1)
-print(f"blankets {len(mg)} stamped {ok.sum()}  staging us: median {np.median(stage[ok]):.2f} p90 {np.percentile(stage[ok],90):.2f}  body us: median {np.median(body[ok]):.2f} p90 {np.percentile(body[ok],90):.2f}")
+ready = np.floor(mg) * 0.01
+final = (mg - np.floor(mg)) * 1e6 * 0.01
+ok = (mg >= 1) & (final > 1) & (ready > 1) & (ready < 1e4)
+print(f"blankets {len(mg)} stamped {ok.sum()}  pick -> ready us: median {np.median(ready[ok]):.2f} p90 {np.percentile(ready[ok],90):.2f}  pick -> final us: median {np.median(final[ok]):.2f} p90 {np.percentile(final[ok],90):.2f}")
 print(st)
