@@ -646,41 +646,6 @@ struct BigArrow {
     double *meas;      // n: reparametrised measurement
 };
 
-// partial-pivot Gauss-Jordan inverse of a D x D block in registers (Eigen PartialPivLU::inverse on the full J reduces to
-// these blocks for a block-arrow matrix)
-template <int D>
-__device__ __forceinline__ bool small_inverse(const double *A, double *X) {
-    double a[D * D], x[D * D];
-#pragma unroll
-    for (int i = 0; i < D * D; i++) { a[i] = A[i]; x[i] = ((i / D) == (i % D)) ? 1.0 : 0.0; }
-    bool ok = true;
-#pragma unroll
-    for (int c = 0; c < D; c++) {
-        int p = c;
-        double best = fabs(a[c * D + c]);
-#pragma unroll
-        for (int r = 0; r < D; r++) if (r > c && fabs(a[r * D + c]) > best) { best = fabs(a[r * D + c]); p = r; }
-        if (!(best > 0.0)) ok = false;
-#pragma unroll
-        for (int r = 0; r < D; r++) if (r == p && p != c) {
-#pragma unroll
-            for (int j = 0; j < D; j++) { double t = a[c * D + j]; a[c * D + j] = a[r * D + j]; a[r * D + j] = t; t = x[c * D + j]; x[c * D + j] = x[r * D + j]; x[r * D + j] = t; }
-        }
-        double ip = 1.0 / a[c * D + c];
-#pragma unroll
-        for (int j = 0; j < D; j++) { a[c * D + j] *= ip; x[c * D + j] *= ip; }
-#pragma unroll
-        for (int r = 0; r < D; r++) if (r != c) {
-            double f = a[r * D + c];
-#pragma unroll
-            for (int j = 0; j < D; j++) { a[r * D + j] -= f * a[c * D + j]; x[r * D + j] -= f * x[c * D + j]; }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < D * D; i++) X[i] = x[i];
-    return ok;
-}
-
 // GLCReparamBinary (src/glc_reparam_binary.hpp:35-127) for the k kept vertices (arena poses at vpo[m + i]): the
 // measurement and the blocks of T = J^-1. One lane per vertex.
 template <int D>
