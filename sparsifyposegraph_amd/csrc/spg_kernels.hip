@@ -1797,80 +1797,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     const spg_options &o = *rd->opts;
     const int D = o.pose_dim;
     if (D != 3 && D != 6) return SPG_EINVAL;
-    // ---- bin this rank's blankets by the LDS their tiles need
-    struct Bin { std::vector<int32_t> &list; int kmax = 0, mmax = 0, smax = 0; double bytes = 0; };
-    const int NB = 5;
-    const size_t lim[NB - 1] = {24 * 1024, 40 * 1024, 80 * 1024, (size_t)hb->lds_limit};
-    for (auto &v : S.bin_lists) v.clear();   // per-slot scratch: no allocation per launch
-    Bin bins[NB] = {{S.bin_lists[0]}, {S.bin_lists[1]}, {S.bin_lists[2]}, {S.bin_lists[3]}, {S.bin_lists[4]}};
-    for (int b = rd->first; b < rd->first + rd->count; b++) {
-        const spg_blanket_desc &bd = rd->blankets[b];
-        int k = bd.n_vert - bd.n_remove, m = bd.n_remove;
-        Layout L = make_layout(D, 64, k, m, o.algorithm, o.topology, bd.pad_);
-        size_t need = (size_t)(L.small_doubles + L.mat_doubles) * 8;
-        int bi = NB - 1;
-        for (int i = 0; i < NB - 1; i++) if (need <= lim[i]) { bi = i; break; }
-        bins[bi].list.push_back(b);
-        if (hb->profiling) {
-            // algorithmic HBM bytes of this blanket (SURVEY.md 8d): poses + (2 x i32 + record) per edge
-            // + new records + (kld f64 + status i32)
-            const int ps = (D == 6) ? 7 : 3;
-            double by = 8.0 * ps * bd.n_vert + 12.0;
-            for (int e = bd.edge_begin; e < bd.edge_begin + bd.n_edge; e++) by += 4.0 * rd->edges[e].nv + 8.0 * rd->edges[e].len;
-            by += 8.0 * bd.new_len;
-            bins[bi].bytes += by;
-        }
-        bins[bi].kmax = std::max(bins[bi].kmax, k);
-        bins[bi].mmax = std::max(bins[bi].mmax, m);
-        bins[bi].smax = std::max(bins[bi].smax, (int)bd.pad_);
-    }
-    // Blankets whose side buffers (Chow-Liu pair tables, GLC batch buffers) exceed LDS even with the tiles in the L2
-    // workspace: GLC Dense ones go through the dense HBM pipeline on the matrix cores (spg_dense.hip) after the
-    // launches below, one at a time; for the others there is no path (SPG_ECAPACITY, as before).
-    std::vector<int32_t> big_list;
-    static const bool force_big = [] { const char *e = getenv("SPG_FORCE_BIG"); return e && e[0] == '1'; }();   // diagnostic / tests
-    if (force_big && o.algorithm == SPG_ALG_GLC && o.topology == SPG_TOPO_DENSE && o.lin_point == SPG_LIN_GLOBAL) {
-        // every blanket with at least one kept vertex takes the dense pipeline (parity of that path on small blankets)
-        for (int i = 0; i < NB; i++) {
-            size_t keep = 0;
-            for (int32_t b : bins[i].list) {
-                if (rd->blankets[b].n_vert - rd->blankets[b].n_remove >= 2 && rd->blankets[b].n_edge > 0) big_list.push_back(b);
-                else bins[i].list[keep++] = b;
-            }
-            bins[i].list.resize(keep);
-        }
-        std::sort(big_list.begin(), big_list.end());
-    } else {
-        Bin &bb = bins[NB - 1];
-        size_t keep = 0;
-        int kmax = 0, mmax = 0, smax = 0;
-        for (int32_t b : bb.list) {
-            const spg_blanket_desc &bd = rd->blankets[b];
-            const int k = bd.n_vert - bd.n_remove, m = bd.n_remove;
-            Layout Lb = make_layout(D, 256, k, m, o.algorithm, o.topology, bd.pad_);
-            if ((size_t)Lb.small_doubles * 8 <= (size_t)hb->lds_limit) {
-                bb.list[keep++] = b;
-                kmax = std::max(kmax, k); mmax = std::max(mmax, m); smax = std::max(smax, (int)bd.pad_);
-                continue;
-            }
-            if (!(o.algorithm == SPG_ALG_GLC && o.topology == SPG_TOPO_DENSE && o.lin_point == SPG_LIN_GLOBAL)) {
-                snprintf(err, sizeof hb->err, "blanket too large for LDS side buffers: k=%d m=%d (only GLC Dense blankets have a large-blanket path)", k, m);
-                return SPG_ECAPACITY;
-            }
-            big_list.push_back(b);
-        }
-        if (!big_list.empty()) { bb.list.resize(keep); bb.kmax = kmax; bb.mmax = mmax; bb.smax = smax; }
-    }
-    LP(0);
-    // ---- upload the round's descriptors (one pinned staging buffer, async copies)
-    size_t s_blk = sizeof(spg_blanket_desc) * (size_t)rd->n_blankets;
-    size_t s_vpo = sizeof(int64_t) * (size_t)rd->n_vert_total;
-    size_t s_er = sizeof(spg_edge_ref) * (size_t)rd->n_edge_total;
-    size_t s_ev = sizeof(int32_t) * (size_t)rd->n_edge_vert_total;
-    size_t s_list = sizeof(int32_t) * (size_t)rd->count;
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t o_blk = 0, o_vpo = o_blk + al(s_blk), o_er = o_vpo + al(s_vpo), o_ev = o_er + al(s_er), o_list = o_ev + al(s_ev);
-    size_t tot = o_list + al(s_list);
+    // (the worker decision comes first: a batch that goes to the worker needs neither bins nor launch descriptors)
     {
         int cur = -1;   // (a thread-local read; hipSetDevice costs a microsecond per launch)
         if (hipGetDevice(&cur) != hipSuccess || cur != hb->device) HIPCHK(hipSetDevice(hb->device));
@@ -1994,6 +1921,81 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         }
     }
     if (int rcw = hb->worker_stop()) return rcw;                           // a launch follows: the worker must not be in its way
+    // ---- bin this rank's blankets by the LDS their tiles need
+    struct Bin { std::vector<int32_t> &list; int kmax = 0, mmax = 0, smax = 0; double bytes = 0; };
+    const int NB = 5;
+    const size_t lim[NB - 1] = {24 * 1024, 40 * 1024, 80 * 1024, (size_t)hb->lds_limit};
+    for (auto &v : S.bin_lists) v.clear();   // per-slot scratch: no allocation per launch
+    Bin bins[NB] = {{S.bin_lists[0]}, {S.bin_lists[1]}, {S.bin_lists[2]}, {S.bin_lists[3]}, {S.bin_lists[4]}};
+    for (int b = rd->first; b < rd->first + rd->count; b++) {
+        const spg_blanket_desc &bd = rd->blankets[b];
+        int k = bd.n_vert - bd.n_remove, m = bd.n_remove;
+        // (binned with the carve-up of the widest team any LDS variant uses, so that no variant outgrows its bin)
+        Layout L = make_layout(D, 256, k, m, o.algorithm, o.topology, bd.pad_);
+        size_t need = (size_t)(L.small_doubles + L.mat_doubles) * 8;
+        int bi = NB - 1;
+        for (int i = 0; i < NB - 1; i++) if (need <= lim[i]) { bi = i; break; }
+        bins[bi].list.push_back(b);
+        if (hb->profiling) {
+            // algorithmic HBM bytes of this blanket (SURVEY.md 8d): poses + (2 x i32 + record) per edge
+            // + new records + (kld f64 + status i32)
+            const int ps = (D == 6) ? 7 : 3;
+            double by = 8.0 * ps * bd.n_vert + 12.0;
+            for (int e = bd.edge_begin; e < bd.edge_begin + bd.n_edge; e++) by += 4.0 * rd->edges[e].nv + 8.0 * rd->edges[e].len;
+            by += 8.0 * bd.new_len;
+            bins[bi].bytes += by;
+        }
+        bins[bi].kmax = std::max(bins[bi].kmax, k);
+        bins[bi].mmax = std::max(bins[bi].mmax, m);
+        bins[bi].smax = std::max(bins[bi].smax, (int)bd.pad_);
+    }
+    // Blankets whose side buffers (Chow-Liu pair tables, GLC batch buffers) exceed LDS even with the tiles in the L2
+    // workspace: GLC Dense ones go through the dense HBM pipeline on the matrix cores (spg_dense.hip) after the
+    // launches below, one at a time; for the others there is no path (SPG_ECAPACITY, as before).
+    std::vector<int32_t> big_list;
+    static const bool force_big = [] { const char *e = getenv("SPG_FORCE_BIG"); return e && e[0] == '1'; }();   // diagnostic / tests
+    if (force_big && o.algorithm == SPG_ALG_GLC && o.topology == SPG_TOPO_DENSE && o.lin_point == SPG_LIN_GLOBAL) {
+        // every blanket with at least one kept vertex takes the dense pipeline (parity of that path on small blankets)
+        for (int i = 0; i < NB; i++) {
+            size_t keep = 0;
+            for (int32_t b : bins[i].list) {
+                if (rd->blankets[b].n_vert - rd->blankets[b].n_remove >= 2 && rd->blankets[b].n_edge > 0) big_list.push_back(b);
+                else bins[i].list[keep++] = b;
+            }
+            bins[i].list.resize(keep);
+        }
+        std::sort(big_list.begin(), big_list.end());
+    } else {
+        Bin &bb = bins[NB - 1];
+        size_t keep = 0;
+        int kmax = 0, mmax = 0, smax = 0;
+        for (int32_t b : bb.list) {
+            const spg_blanket_desc &bd = rd->blankets[b];
+            const int k = bd.n_vert - bd.n_remove, m = bd.n_remove;
+            Layout Lb = make_layout(D, 256, k, m, o.algorithm, o.topology, bd.pad_);
+            if ((size_t)Lb.small_doubles * 8 <= (size_t)hb->lds_limit) {
+                bb.list[keep++] = b;
+                kmax = std::max(kmax, k); mmax = std::max(mmax, m); smax = std::max(smax, (int)bd.pad_);
+                continue;
+            }
+            if (!(o.algorithm == SPG_ALG_GLC && o.topology == SPG_TOPO_DENSE && o.lin_point == SPG_LIN_GLOBAL)) {
+                snprintf(err, sizeof hb->err, "blanket too large for LDS side buffers: k=%d m=%d (only GLC Dense blankets have a large-blanket path)", k, m);
+                return SPG_ECAPACITY;
+            }
+            big_list.push_back(b);
+        }
+        if (!big_list.empty()) { bb.list.resize(keep); bb.kmax = kmax; bb.mmax = mmax; bb.smax = smax; }
+    }
+    LP(0);
+    // ---- upload the round's descriptors (one pinned staging buffer, async copies)
+    size_t s_blk = sizeof(spg_blanket_desc) * (size_t)rd->n_blankets;
+    size_t s_vpo = sizeof(int64_t) * (size_t)rd->n_vert_total;
+    size_t s_er = sizeof(spg_edge_ref) * (size_t)rd->n_edge_total;
+    size_t s_ev = sizeof(int32_t) * (size_t)rd->n_edge_vert_total;
+    size_t s_list = sizeof(int32_t) * (size_t)rd->count;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o_blk = 0, o_vpo = o_blk + al(s_blk), o_er = o_vpo + al(s_vpo), o_ev = o_er + al(s_er), o_list = o_ev + al(s_ev);
+    size_t tot = o_list + al(s_list);
     // Where the descriptors of this launch go:
     //  - small launch, large-BAR system: the host stores them straight into (fine-grained) device memory —
     //    posted writes ahead of the doorbell, no copy engine hop, and the kernel reads local HBM;
@@ -2088,6 +2090,13 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
                 size_t lds2 = std::min((size_t)(L2.small_doubles + L2.mat_doubles) * 8, (size_t)hb->lds_limit);
                 if (lm) rc = (D == 6) ? launch_bin<6, 128, false, SPG_ALG_NFR_LM>(hb, S, ka, nb, lds2, bins[i].bytes) : launch_bin<3, 128, false, SPG_ALG_NFR_LM>(hb, S, ka, nb, lds2, bins[i].bytes);
                 else rc = (D == 6) ? launch_bin<6, 128, false, SPG_ALG_NFR>(hb, S, ka, nb, lds2, bins[i].bytes) : launch_bin<3, 128, false, SPG_ALG_NFR>(hb, S, ka, nb, lds2, bins[i].bytes);
+            } else if ((o.algorithm == SPG_ALG_NFR) && !lm && nb <= 1024 && D * bins[i].kmax > kWaveMax && !hb->force_one_wave) {
+                // tiles beyond the register-resident size (n > 24) run the LDS-cooperative routines: their O(n^2) inner
+                // steps want lanes, and a launch this small leaves the chip empty anyway — four wavefronts per blanket
+                // (parking.g2o: 0.70 -> ms per launch of such blankets)
+                Layout L4 = make_layout(D, 256, bins[i].kmax, bins[i].mmax, o.algorithm, o.topology, bins[i].smax);
+                size_t lds4 = std::min((size_t)(L4.small_doubles + L4.mat_doubles) * 8, (size_t)hb->lds_limit);
+                rc = (D == 6) ? launch_bin<6, 256, false, SPG_ALG_NFR>(hb, S, ka, nb, lds4, bins[i].bytes) : launch_bin<3, 256, false, SPG_ALG_NFR>(hb, S, ka, nb, lds4, bins[i].bytes);
             } else if (o.algorithm == SPG_ALG_GLC)
                 rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_GLC>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_GLC>(hb, S, ka, nb, lds, bins[i].bytes);
             else if (lm)
@@ -2095,7 +2104,11 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
             else
                 rc = (D == 6) ? launch_bin<6, 64, false, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 64, false, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes);
         } else {
-            Layout L = make_layout(D, 256, bins[i].kmax, bins[i].mmax, o.algorithm, o.topology, bins[i].smax);
+            // NFR: eight wavefronts per blanket — the tiles sit in L2, every step of the cooperative routines is a round of
+            // ~1 us accesses, and only lanes hide that (parking.g2o: 3.1 -> ms per launch of such blankets)
+            const bool wide = (o.algorithm == SPG_ALG_NFR) && !lm && !hb->force_one_wave;
+            const int ntg = wide ? 1024 : 256;
+            Layout L = make_layout(D, ntg, bins[i].kmax, bins[i].mmax, o.algorithm, o.topology, bins[i].smax);
             size_t lds = (size_t)L.small_doubles * 8;
             if (lds > (size_t)hb->lds_limit) { snprintf(err, sizeof hb->err, "blanket too large for LDS side buffers: k=%d m=%d", bins[i].kmax, bins[i].mmax); return SPG_ECAPACITY; }
             size_t stride = ((size_t)L.mat_doubles + 31) & ~(size_t)31;
@@ -2106,6 +2119,8 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
                 rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_GLC>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_GLC>(hb, S, ka, nb, lds, bins[i].bytes);
             else if (lm)
                 rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_NFR_LM>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_NFR_LM>(hb, S, ka, nb, lds, bins[i].bytes);
+            else if (wide)
+                rc = (D == 6) ? launch_bin<6, 1024, true, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 1024, true, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes);
             else
                 rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes);
         }
