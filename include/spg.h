@@ -285,26 +285,57 @@ typedef struct {
     int64_t n;               /* variables compared: pose_dim * (kept vertices - fixed) */
     int64_t n_marginalized;  /* baseline variables marginalised out */
     double device_seconds;   /* HIP-event time of assembly + factorisations + solve */
+    int32_t solver;          /* SPG_SOLVER_DENSE or SPG_SOLVER_SPARSE: what ran */
+    int32_t supernodes;      /* sparse: fronts of the two factorisations' assembly trees */
+    double front_bytes;      /* sparse: bytes of fronts in HBM */
+    double factor_flops;     /* sparse: flops of the two factorisations */
 } spg_kld_terms;
 /* baseline->kullbackLeibler(other) (src/graph_wrapper_g2o.cpp:531-548): marginal of the baseline's
  * information onto other's vertices (computeIndices :472-499), estimateDifference (:550-575), then the
- * formula above, all dense on the device. other's vertices must be a subset of the baseline's; both
- * graphs must live on the same device. SPG_ENOTPD if either information matrix is not PD. */
+ * formula above. Dense on the device up to 46 k variables; beyond that (or when the context's linear solver is
+ * SPG_SOLVER_SPARSE) the block-sparse multifrontal path: the baseline is factorised with its marginalised vertices
+ * eliminated first, log det of the marginal from the kept supernodes, trace(maty^-1 infox) from the selected
+ * inverse — the reference's dense n_g x n_g step (720 GB at 100 k poses) is never formed. other's vertices must
+ * be a subset of the baseline's; both graphs must live on the same device. SPG_ENOTPD if either information
+ * matrix is not PD. */
 int spg_graph_kullback_leibler(spg_graph *baseline, spg_graph *other, int32_t fixed_id, spg_kld_terms *out);
 
 /* ---- optimize() -------------------------------------------------------------
  * GraphWrapperG2O::optimize() (src/graph_wrapper_g2o.cpp:250-269): one vertex fixed (fixed_id < 0: the
  * smallest id), g2o's Levenberg-Marquardt for up to `iterations` iterations (the reference uses 50),
- * no robust kernel. Dense on the device (Hessian assembly, blocked fp64-MFMA Cholesky of H + lambda I,
- * triangular solves, pose updates, chi2): for graphs of up to 32k scalar variables. The estimates of
- * the graph are updated in place. */
+ * no robust kernel. On the device (Hessian assembly, Cholesky of H + lambda I, triangular solves, pose updates,
+ * chi2): dense (blocked fp64-MFMA Cholesky) up to 12 k scalar variables, block-sparse multifrontal (nested
+ * dissection on the host, fronts on the matrix cores: CHOLMOD's role) beyond — see spg_ctx_set_linear_solver.
+ * The estimates of the graph are updated in place. */
+enum { SPG_SOLVER_AUTO = 0, SPG_SOLVER_DENSE = 1, SPG_SOLVER_SPARSE = 2 };
+/* Which factorisation spg_graph_optimize / _optimize_fixed / _kullback_leibler of graphs of this context use.
+ * AUTO (default): by size. DENSE beyond its capacity (32 k / 46 k variables) returns SPG_ECAPACITY. */
+int spg_ctx_set_linear_solver(spg_ctx *ctx, int solver);
 typedef struct {
     int32_t iterations, trials;          /* LM iterations run; linear systems solved */
     double chi2_initial, chi2_final, lambda_final;
     int64_t n;                           /* scalar variables */
     double device_seconds;
+    int32_t solver;                      /* SPG_SOLVER_DENSE or SPG_SOLVER_SPARSE: what ran */
+    int32_t supernodes;                  /* sparse: fronts of the assembly tree */
+    double front_bytes;                  /* sparse: bytes of fronts in HBM */
+    double factor_flops;                 /* sparse: flops of one factorisation */
 } spg_optimize_stats;
 int spg_graph_optimize(spg_graph *g, int iterations, int32_t fixed_id, spg_optimize_stats *out);
+/* Symbolic phase of the block-sparse solver on its own (host only; inspection and CPU tests): nested-dissection
+ * elimination order and assembly tree of a block graph given as symmetric CSR adjacency. is_marg (may be NULL): blocks
+ * to eliminate first (the global KLD's marginalised vertices). leaf <= 0: default leaf size. Every output array may be
+ * NULL; rows / rel are written only if rows_cap >= info->n_rows. perm[position] = block; supernode s owns positions
+ * [sn_first[s], sn_first[s+1]); rows[sn_rowptr[s] ..) = its boundary positions (ascending); rel = scalar offset of each
+ * boundary block inside the PARENT's front ([pivot columns padded to 64 | boundary rows]). */
+typedef struct {
+    int32_t n_supernodes, n_marg_supernodes, n_levels, pad_;
+    int64_t n_rows;
+    double front_bytes, flops;
+} spg_sparse_plan_info;
+int spg_sparse_plan(int n_blocks, const int32_t *adj_ptr, const int32_t *adj, int pose_dim, const uint8_t *is_marg, int leaf,
+                    spg_sparse_plan_info *info, int32_t *perm, int32_t *sn_first, int32_t *sn_parent, int32_t *sn_level,
+                    int32_t *sn_rowptr, int32_t *rows, int32_t *rel, int64_t rows_cap);
 /* The same with a set of vertices held fixed at their current estimates — the inner step of
  * GraphWrapperG2O::chi2(other) (src/graph_wrapper_g2o.cpp:503-529): fix other's vertices at other's
  * estimates, optimise the rest, read chi2. n_fixed may cover every vertex (chi2 is evaluated, nothing moves). */

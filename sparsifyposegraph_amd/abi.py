@@ -66,7 +66,8 @@ class MargStats(C.Structure):
 class KldTerms(C.Structure):
     """spg_kld_terms (include/spg.h)"""
     _fields_ = [("kld", C.c_double), ("innerprod", C.c_double), ("mahalanobis", C.c_double), ("logdetx", C.c_double),
-                ("logdety", C.c_double), ("n", C.c_int64), ("n_marginalized", C.c_int64), ("device_seconds", C.c_double)]
+                ("logdety", C.c_double), ("n", C.c_int64), ("n_marginalized", C.c_int64), ("device_seconds", C.c_double),
+                ("solver", C.c_int32), ("supernodes", C.c_int32), ("front_bytes", C.c_double), ("factor_flops", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -75,10 +76,20 @@ class KldTerms(C.Structure):
 class OptimizeStats(C.Structure):
     """spg_optimize_stats (include/spg.h)"""
     _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
-                ("lambda_final", C.c_double), ("n", C.c_int64), ("device_seconds", C.c_double)]
+                ("lambda_final", C.c_double), ("n", C.c_int64), ("device_seconds", C.c_double),
+                ("solver", C.c_int32), ("supernodes", C.c_int32), ("front_bytes", C.c_double), ("factor_flops", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class SparsePlanInfo(C.Structure):
+    """spg_sparse_plan_info (include/spg.h)"""
+    _fields_ = [("n_supernodes", C.c_int32), ("n_marg_supernodes", C.c_int32), ("n_levels", C.c_int32), ("pad_", C.c_int32),
+                ("n_rows", C.c_int64), ("front_bytes", C.c_double), ("flops", C.c_double)]
+
+
+SOLVER_AUTO, SOLVER_DENSE, SOLVER_SPARSE = 0, 1, 2
 
 
 class RoundInfo(C.Structure):

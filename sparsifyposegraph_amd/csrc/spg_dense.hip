@@ -162,10 +162,7 @@ __global__ __launch_bounds__(256, 2) void tile_abt_kernel(TileOp op) {
 // lane i's registers. No barrier and no LDS round trip in either chain — the
 // LDS-cooperative version (chol_lower<256> + tri_inverse_lower) took 119 us per block, the serial
 // critical path of the blocked factorisation.
-__global__ __launch_bounds__(64) void diag_potrf_kernel(double *Ajj, int ld, double *Linv, int *bad, int factor) {
-    __shared__ double Ls[TB * 65];
-    Ajj += (long long)blockIdx.x * TB * ((long long)ld + 1);
-    Linv += (long long)blockIdx.x * TB * TB;
+__device__ __forceinline__ void diag_potrf_body(double *Ls /* LDS, 64 * 65 */, double *Ajj, int ld, double *Linv, int *bad, int factor) {
     const int lane = threadIdx.x;
     // coalesced load of the lower triangle into LDS (row stride 65: row-per-lane reads hit 64 banks)
     // (16 independent loads in flight per step: a rolled loop waits one full memory latency per row)
@@ -218,6 +215,11 @@ __global__ __launch_bounds__(64) void diag_potrf_kernel(double *Ajj, int ld, dou
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int r = 0; r < TB; r++) Linv[r * TB + lane] = Ls[r * 65 + lane];
+}
+
+__global__ __launch_bounds__(64) void diag_potrf_kernel(double *Ajj, int ld, double *Linv, int *bad, int factor) {
+    __shared__ double Ls[TB * 65];
+    diag_potrf_body(Ls, Ajj + (long long)blockIdx.x * TB * ((long long)ld + 1), ld, Linv + (long long)blockIdx.x * TB * TB, bad, factor);
 }
 
 // pad rows [n, N) of an N x N matrix get a unit diagonal
@@ -375,11 +377,20 @@ __global__ __launch_bounds__(64) void glc_weighted_jacobian_kernel(GraphDev g) {
     }
 }
 
+// Where the assembly puts block (row v, column u) of H. pv, pu: the scalar positions of the two vertices (GraphDev::pos).
+struct DenseSink {
+    double *M;
+    int ld;
+    __device__ __forceinline__ void add(int pv, int pu, int r, int c, double val) { M[(long long)(pv + r) * ld + pu + c] += val; }
+    __device__ __forceinline__ void diag(int pv, int r, int c, double val) { M[(long long)(pv + r) * ld + pv + c] = val; }
+    __device__ __forceinline__ void finish(int, int) {}
+};
+
 // H = sum_e J_e^T Omega_e J_e over the live edges, rows of vertex v by workgroup v (one wavefront):
 // deterministic (edges in ascending index), no atomics. Only the lower block triangle (pos(u) <=
 // pos(v)) is written; diagonal blocks are written in full.
-template <int D>
-__global__ __launch_bounds__(64) void dense_assemble_kernel(GraphDev g, double *M, int ld, double *bvec) {
+template <int D, class Sink>
+__global__ __launch_bounds__(64) void dense_assemble_kernel(GraphDev g, Sink sink, double *bvec) {
     constexpr int DD = D * D, PS = (D == 6) ? 7 : 3, PSZ = (D == 6) ? kIso : 3;
     __shared__ double Jv[DD], Ju[DD], Om[DD], Tv[DD], Tu[DD], Er[D];
     double bacc = 0;   // lanes < D: b_v[lane] = -sum_e (J_v^T Omega e)[lane]  (g2o's right-hand side)
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(64) void dense_assemble_kernel(GraphDev g, double *
 #pragma unroll
                 for (int p = 0; p < D; p++) { sd += Jv[p * D + r] * Tv[p * D + c]; so += Jv[p * D + r] * Tu[p * D + c]; }
                 diag += sd;
-                if (pu >= 0 && pu < pv) M[(long long)(pv + r) * ld + pu + c] += so;
+                if (pu >= 0 && pu < pv) sink.add(pv, pu, r, c, so);
             }
             if (tid < D) {
 #pragma unroll
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(64) void dense_assemble_kernel(GraphDev g, double *
                     double s = 0;
                     for (int p = 0; p < rr; p++) s += Aw[(int64_t)p * dq + iv * D + r] * Aw[(int64_t)p * dq + iu * D + c];
                     if (u == v) diag += s;
-                    else M[(long long)(pv + r) * ld + pu + c] += s;
+                    else sink.add(pv, pu, r, c, s);
                 }
             }
             if (tid < D) {
@@ -455,8 +466,9 @@ __global__ __launch_bounds__(64) void dense_assemble_kernel(GraphDev g, double *
             }
         }
     }
-    if (act) M[(long long)(pv + r) * ld + pv + c] = diag;
+    if (act) sink.diag(pv, r, c, diag);
     if (bvec && tid < D) bvec[pv + tid] = bacc;
+    sink.finish(v, tid);
 }
 
 // chi2 per edge (binary: e^T Omega e; GLC: ||W e||^2 from glc_weighted_jacobian_kernel), one lane per edge
@@ -893,13 +905,22 @@ int stage_graph(const spg::DenseGraphIn &in, GraphBufs &gb, hipStream_t s) {
 }
 
 template <int D>
+void launch_glc_jacobians(const GraphBufs &gb, hipStream_t s) {
+    if (!gb.has_glc) return;
+    size_t sh = (size_t)gb.max_q * (2 * D * D + D) * sizeof(double);
+    if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(glc_weighted_jacobian_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((glc_weighted_jacobian_kernel<D>), dim3(gb.dev.ne), dim3(64), sh, s, gb.dev);
+}
+
+template <int D, class Sink>
+void launch_assemble_into(const GraphBufs &gb, Sink sink, hipStream_t s, double *bvec = nullptr) {
+    launch_glc_jacobians<D>(gb, s);
+    hipLaunchKernelGGL((dense_assemble_kernel<D, Sink>), dim3(gb.dev.nv), dim3(64), 0, s, gb.dev, sink, bvec);
+}
+
+template <int D>
 void launch_assemble(const GraphBufs &gb, double *M, int ld, hipStream_t s, double *bvec = nullptr) {
-    if (gb.has_glc) {
-        size_t sh = (size_t)gb.max_q * (2 * D * D + D) * sizeof(double);
-        if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(glc_weighted_jacobian_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL((glc_weighted_jacobian_kernel<D>), dim3(gb.dev.ne), dim3(64), sh, s, gb.dev);
-    }
-    hipLaunchKernelGGL((dense_assemble_kernel<D>), dim3(gb.dev.nv), dim3(64), 0, s, gb.dev, M, ld, bvec);
+    launch_assemble_into<D>(gb, DenseSink{M, ld}, s, bvec);
 }
 
 void launch_tiles(const TileOp &op, hipStream_t s) {
@@ -1232,44 +1253,47 @@ done:
 }
 
 // GraphWrapperG2O::optimize (src/graph_wrapper_g2o.cpp:250-269) = g2o Levenberg-Marquardt with one
-// vertex fixed, dense on the device. in.pos orders the free vertices by id (no padding between them),
-// n = D * (free vertices). The poses are updated in place in the arena. LM control flow as in g2o's
+// vertex fixed. in.pos gives every free vertex its scalar position in the solution vector. The poses are
+// updated in place in the arena. LM control flow as in g2o's
 // OptimizationAlgorithmLevenberg (an un-vendored dependency of the reference, restated from its
 // published algorithm): lambda_0 = 1e-5 max|diag H|; per iteration up to 10 trials of
 // (H + lambda I) x = b with gain ratio rho = (chi2 - chi2') / (x.(lambda x + b) + 1e-3); good step:
 // lambda *= clamp(1 - (2 rho - 1)^3, 1/3, 2/3), ni = 2; bad step: lambda *= ni, ni *= 2, estimates
 // restored; stop after 10 failed trials, rho == 0 or a non-finite lambda. The host sees four scalars
-// per trial.
-int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iterations, double *stats, double *seconds,
-                       char *err, size_t errlen) {
-    hipStream_t s = (hipStream_t)stream;
+// per trial. The linear algebra behind it is either dense (DenseLM below) or the block-sparse multifrontal
+// solver of spg_sparse.inc (SparseLM).
+}  // namespace spg
+
+namespace {
+
+struct LMLinear {
+    virtual ~LMLinear() {}
+    // H and b = -sum J^T Omega e at the current estimates; scal[1] <- max |diag H|
+    virtual int build(hipStream_t s, const GraphBufs &gb, double *b, double *scal, char *err, size_t errlen) = 0;
+    // (H + lambda I) sol = b, enqueued on s; *bad (device) != 0 afterwards: not positive definite
+    virtual int solve(hipStream_t s, const GraphBufs &gb, double lambda, const double *b, double *sol, int *bad, char *err, size_t errlen) = 0;
+};
+
+// n: number of unknowns; nvec >= n: length of the vectors (b, sol)
+int lm_run(hipStream_t s, const spg::DenseGraphIn &in, GraphBufs &gb, int n, int nvec, int iterations, LMLinear &lin,
+           double *stats, double *seconds, char *err, size_t errlen) {
     int rc = 0;
     const int D = in.D, PS = (D == 6) ? 7 : 3;
-    const int N = round_up(std::max(n, 1)), nt = N / TB;
-    GraphBufs gb;
-    DevBuf H, A, linv, linv_all, bad, b, rhs, sol, chi, scal, backup;
+    DevBuf bad, b, sol, chi, scal, backup;
     double h_s[4] = {0, 0, 0, 0};
     int h_bad = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0;
     double lambda = 0, ni = 2, chi_first = 0, chi_last = 0;
     int it = 0, trials = 0;
-    if (hipMalloc(&H.p, (size_t)N * N * 8) != hipSuccess || hipMalloc(&A.p, (size_t)N * N * 8) != hipSuccess) {
-        snprintf(err, errlen, "hipMalloc of two %d x %d matrices failed", N, N);
-        return SPG_ENOMEM;
-    }
-    HIPCHK(hipMalloc(&linv.p, TB * TB * 8));
-    HIPCHK(hipMalloc(&linv_all.p, (size_t)nt * TB * TB * 8));
     HIPCHK(hipMalloc(&bad.p, sizeof(int)));
-    HIPCHK(hipMalloc(&b.p, (size_t)N * 8));
-    HIPCHK(hipMalloc(&rhs.p, (size_t)N * 8));
-    HIPCHK(hipMalloc(&sol.p, (size_t)N * 8));
+    HIPCHK(hipMalloc(&b.p, (size_t)nvec * 8));
+    HIPCHK(hipMalloc(&sol.p, (size_t)nvec * 8));
     HIPCHK(hipMalloc(&chi.p, (size_t)std::max(in.ne, 1) * 8));
     HIPCHK(hipMalloc(&scal.p, 4 * 8));
     HIPCHK(hipMalloc(&backup.p, (size_t)std::max(in.nv, 1) * PS * 8));
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    if ((rc = stage_graph(in, gb, s))) { snprintf(err, errlen, "staging the graph for the optimiser failed (%d)", rc); goto done; }
     HIPCHK(hipEventRecord(e0, s));
     {
         double *arena = (double *)const_cast<void *>(in.dev_arena);
@@ -1279,10 +1303,9 @@ int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iteratio
         };
         // chi2 of the current estimates into scal[slot] (the GLC kernel refreshes the weighted errors)
         auto chi2_into = [&](int slot, bool refresh_glc) {
-            if (refresh_glc && gb.has_glc) {
-                size_t sh = (size_t)gb.max_q * (2 * D * D + D) * sizeof(double);
-                if (D == 6) hipLaunchKernelGGL((glc_weighted_jacobian_kernel<6>), dim3(in.ne), dim3(64), sh, s, gb.dev);
-                else hipLaunchKernelGGL((glc_weighted_jacobian_kernel<3>), dim3(in.ne), dim3(64), sh, s, gb.dev);
+            if (refresh_glc) {
+                if (D == 6) launch_glc_jacobians<6>(gb, s);
+                else launch_glc_jacobians<3>(gb, s);
             }
             if (in.ne > 0) {
                 if (D == 6) hipLaunchKernelGGL((edge_chi2_kernel<6>), dim3((in.ne + 63) / 64), dim3(64), 0, s, gb.dev, (double *)chi.p);
@@ -1293,13 +1316,9 @@ int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iteratio
         bool terminate = false;
         for (; it < iterations && !terminate; it++) {
             // buildSystem: H, b and chi2 at the current estimates
-            HIPCHK(hipMemsetAsync(H.p, 0, (size_t)N * N * 8, s));
-            HIPCHK(hipMemsetAsync(b.p, 0, (size_t)N * 8, s));
-            if (D == 6) launch_assemble<6>(gb, (double *)H.p, N, s, (double *)b.p);
-            else launch_assemble<3>(gb, (double *)H.p, N, s, (double *)b.p);
-            if (N > n) hipLaunchKernelGGL(pad_identity_kernel, dim3((N - n + 255) / 256), dim3(256), 0, s, (double *)H.p, N, n, N);
+            HIPCHK(hipMemsetAsync(b.p, 0, (size_t)nvec * 8, s));
+            if ((rc = lin.build(s, gb, (double *)b.p, (double *)scal.p, err, errlen))) goto done;
             chi2_into(0, false);
-            hipLaunchKernelGGL(max_diag_kernel, dim3(1), dim3(256), 0, s, (const double *)H.p, N, n, (double *)scal.p, 1);
             HIPCHK(hipMemcpyAsync(h_s, scal.p, 2 * 8, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             double currentChi = h_s[0];
@@ -1310,21 +1329,12 @@ int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iteratio
             bool lambda_ok = true;
             do {
                 poses(1);                                                        // push()
-                HIPCHK(hipMemcpyAsync(A.p, H.p, (size_t)N * N * 8, hipMemcpyDeviceToDevice, s));
-                if (n > 0) hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (double *)A.p, N, n, lambda);
                 HIPCHK(hipMemsetAsync(bad.p, 0, sizeof(int), s));
-                potrf_lower((double *)A.p, N, (double *)linv.p, (int *)bad.p, s);
-                hipLaunchKernelGGL(diag_potrf_kernel, dim3(nt), dim3(64), 0, s, (double *)A.p, N, (double *)linv_all.p, (int *)bad.p, 0);
-                HIPCHK(hipMemcpyAsync(rhs.p, b.p, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
-                for (int j = 0; j < nt; j++)
-                    hipLaunchKernelGGL(trsv_forward_step, dim3(nt - j), dim3(64), 0, s, (const double *)A.p, N, (const double *)linv_all.p, (double *)rhs.p, (double *)sol.p, j);
-                HIPCHK(hipMemcpyAsync(rhs.p, sol.p, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
-                for (int j = nt - 1; j >= 0; j--)
-                    hipLaunchKernelGGL(trsv_backward_step, dim3(j + 1), dim3(64), 0, s, (const double *)A.p, N, (const double *)linv_all.p, (double *)rhs.p, (double *)sol.p, j);
+                if ((rc = lin.solve(s, gb, lambda, (const double *)b.p, (double *)sol.p, (int *)bad.p, err, errlen))) goto done;
                 HIPCHK(hipMemcpyAsync(&h_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
                 const bool ok2 = h_bad == 0;
-                if (!ok2) HIPCHK(hipMemsetAsync(sol.p, 0, (size_t)N * 8, s));   // x = 0: the trial is rejected below
+                if (!ok2) HIPCHK(hipMemsetAsync(sol.p, 0, (size_t)nvec * 8, s));   // x = 0: the trial is rejected below
                 poses(0);                                                        // update(x)
                 chi2_into(2, true);
                 hipLaunchKernelGGL(lm_scale_kernel, dim3(1), dim3(256), 0, s, (const double *)sol.p, (const double *)b.p, n, lambda, (double *)scal.p, 3);
@@ -1363,4 +1373,63 @@ done:
     return rc;
 }
 
+// Dense linear algebra for LM: H and a working copy A in HBM, the blocked fp64-MFMA Cholesky, two blocked
+// triangular solves (one launch per 64-block). n <= 32 k unknowns (2 x 8 GB).
+struct DenseLM : LMLinear {
+    int D, n, N, nt;
+    DevBuf H, A, linv, linv_all, rhs;
+    int init(int D_, int n_, char *err, size_t errlen) {
+        D = D_; n = n_; N = round_up(std::max(n, 1)); nt = N / TB;
+        if (hipMalloc(&H.p, (size_t)N * N * 8) != hipSuccess || hipMalloc(&A.p, (size_t)N * N * 8) != hipSuccess) {
+            snprintf(err, errlen, "hipMalloc of two %d x %d matrices failed", N, N);
+            return SPG_ENOMEM;
+        }
+        if (hipMalloc(&linv.p, TB * TB * 8) != hipSuccess || hipMalloc(&linv_all.p, (size_t)nt * TB * TB * 8) != hipSuccess ||
+            hipMalloc(&rhs.p, (size_t)N * 8) != hipSuccess) return SPG_ENOMEM;
+        return 0;
+    }
+    int build(hipStream_t s, const GraphBufs &gb, double *b, double *scal, char *err, size_t errlen) override {
+        int rc = 0;
+        HIPCHK(hipMemsetAsync(H.p, 0, (size_t)N * N * 8, s));
+        if (D == 6) launch_assemble<6>(gb, (double *)H.p, N, s, b);
+        else launch_assemble<3>(gb, (double *)H.p, N, s, b);
+        if (N > n) hipLaunchKernelGGL(pad_identity_kernel, dim3((N - n + 255) / 256), dim3(256), 0, s, (double *)H.p, N, n, N);
+        hipLaunchKernelGGL(max_diag_kernel, dim3(1), dim3(256), 0, s, (const double *)H.p, N, n, scal, 1);
+    done:
+        return rc;
+    }
+    int solve(hipStream_t s, const GraphBufs &, double lambda, const double *b, double *sol, int *bad, char *err, size_t errlen) override {
+        int rc = 0;
+        HIPCHK(hipMemcpyAsync(A.p, H.p, (size_t)N * N * 8, hipMemcpyDeviceToDevice, s));
+        if (n > 0) hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (double *)A.p, N, n, lambda);
+        potrf_lower((double *)A.p, N, (double *)linv.p, bad, s);
+        hipLaunchKernelGGL(diag_potrf_kernel, dim3(nt), dim3(64), 0, s, (double *)A.p, N, (double *)linv_all.p, bad, 0);
+        HIPCHK(hipMemcpyAsync(rhs.p, b, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+        for (int j = 0; j < nt; j++)
+            hipLaunchKernelGGL(trsv_forward_step, dim3(nt - j), dim3(64), 0, s, (const double *)A.p, N, (const double *)linv_all.p, (double *)rhs.p, sol, j);
+        HIPCHK(hipMemcpyAsync(rhs.p, sol, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+        for (int j = nt - 1; j >= 0; j--)
+            hipLaunchKernelGGL(trsv_backward_step, dim3(j + 1), dim3(64), 0, s, (const double *)A.p, N, (const double *)linv_all.p, (double *)rhs.p, sol, j);
+    done:
+        return rc;
+    }
+};
+
+}  // namespace
+
+namespace spg {
+
+int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iterations, double *stats, double *seconds,
+                       char *err, size_t errlen) {
+    hipStream_t s = (hipStream_t)stream;
+    GraphBufs gb;
+    DenseLM lin;
+    int rc = lin.init(in.D, n, err, errlen);
+    if (rc) return rc;
+    if ((rc = stage_graph(in, gb, s))) { snprintf(err, errlen, "staging the graph for the optimiser failed (%d)", rc); return rc; }
+    return lm_run(s, in, gb, n, lin.N, iterations, lin, stats, seconds, err, errlen);
+}
+
 }  // namespace spg
+
+#include "spg_sparse.inc"

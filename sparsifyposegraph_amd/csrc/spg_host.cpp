@@ -34,6 +34,7 @@
 #include <vector>
 #include "../../include/spg.h"
 #include "spg_internal.h"
+#include "spg_sparse_plan.hpp"
 
 namespace {
 inline int pose_stride(int d) { return d == 3 ? 3 : 7; }
@@ -126,6 +127,7 @@ struct spg_ctx {
     int rank = 0, nranks = 1;
     void *rccl = nullptr;         // communicator handle of csrc/spg_rccl.cpp (nullptr: single rank / no id given)
     int tag_counter = 0;          // ready tags are unique per context (its mailboxes are shared by all graphs)
+    int linear_solver = 0;        // SPG_SOLVER_*: dense / block-sparse factorisation for optimize() and the global KLD
     char err[768] = {0};
 };
 
@@ -318,6 +320,12 @@ extern "C" int spg_ctx_create_ranks(spg_ctx **out, int device, int rank, int nra
     }
     return 0;
 }
+extern "C" int spg_ctx_set_linear_solver(spg_ctx *c, int solver) {
+    if (!c || solver < SPG_SOLVER_AUTO || solver > SPG_SOLVER_SPARSE) return SPG_EINVAL;
+    c->linear_solver = solver;
+    return 0;
+}
+
 extern "C" int spg_ctx_rank(const spg_ctx *c) { return c ? c->rank : 0; }
 extern "C" int spg_ctx_nranks(const spg_ctx *c) { return c ? c->nranks : 0; }
 
@@ -2281,11 +2289,40 @@ extern "C" int spg_graph_kullback_leibler(spg_graph *base, spg_graph *other, int
     if (kept_b.empty()) return set_err(ctx, SPG_EINVAL, "spg_graph_kullback_leibler: no common free vertex");
     const int64_t n_marg = (int64_t)d * marg_b.size(), n_keep = (int64_t)d * kept_b.size();
     const int64_t Nm = (n_marg + 63) / 64 * 64, Ng = (n_keep + 63) / 64 * 64;
-    if (Nm + Ng > 46000) return set_err(ctx, SPG_ECAPACITY, "spg_graph_kullback_leibler: dense formulation limited to 46k variables (16 GB)");
+    const bool sparse = ctx->linear_solver == SPG_SOLVER_SPARSE || (ctx->linear_solver == SPG_SOLVER_AUTO && Nm + Ng > 46000);
+    if (!sparse && Nm + Ng > 46000) return set_err(ctx, SPG_ECAPACITY, "spg_graph_kullback_leibler: dense formulation limited to 46k variables (16 GB)");
     if (int rc = sync_device(base)) return rc;
     if (int rc = sync_device(other)) return rc;
     if (int rc = ctx->be.synchronize(ctx->be.user)) return rc;
     if (other->ctx != ctx) if (int rc = other->ctx->be.synchronize(other->ctx->be.user)) return rc;
+    if (sparse) {
+        // block-sparse multifrontal path: positions only number the blocks, the elimination order is the plan's
+        DenseStage sb, so;
+        sb.pos.assign(base->vid.size(), -1);
+        so.pos.assign(other->vid.size(), -1);
+        std::vector<uint8_t> is_marg(base->vid.size(), 0);
+        std::vector<int64_t> kvb, kvo;
+        int p = 0;
+        for (int32_t v : ob) if (v != fb) sb.pos[v] = p++;
+        for (int32_t v : marg_b) is_marg[v] = 1;
+        p = 0;
+        for (size_t i = 0; i < kept_b.size(); i++) {
+            so.pos[kept_o[i]] = p++;
+            kvb.push_back(base->vpose[kept_b[i]]);
+            kvo.push_back(other->vpose[kept_o[i]]);
+        }
+        build_dense_stage(base, sb);
+        build_dense_stage(other, so);
+        double terms[6] = {0, 0, 0, 0, 0, 0}, secs = 0, info[4] = {0, 0, 0, 0};
+        ctx->err[0] = 0;
+        int rc = spg::hip_sparse_kld(spg::hip_backend_stream(&ctx->be), sb.in, so.in, is_marg.data(), kept_b.data(), kept_o.data(), (int)kept_b.size(),
+                                     kvb.data(), kvo.data(), terms, &secs, info, ctx->err, sizeof ctx->err);
+        if (rc) return rc;
+        out->kld = terms[0]; out->innerprod = terms[1]; out->mahalanobis = terms[2]; out->logdetx = terms[3];
+        out->logdety = terms[4]; out->n = (int64_t)terms[5]; out->n_marginalized = n_marg; out->device_seconds = secs;
+        out->solver = SPG_SOLVER_SPARSE; out->supernodes = (int32_t)info[0]; out->front_bytes = info[2]; out->factor_flops = info[3];
+        return 0;
+    }
     DenseStage sb, so;
     sb.pos.assign(base->vid.size(), -1);
     so.pos.assign(other->vid.size(), -1);
@@ -2311,6 +2348,7 @@ extern "C" int spg_graph_kullback_leibler(spg_graph *base, spg_graph *other, int
     if (rc) return rc;
     out->kld = terms[0]; out->innerprod = terms[1]; out->mahalanobis = terms[2]; out->logdetx = terms[3];
     out->logdety = terms[4]; out->n = (int64_t)terms[5]; out->n_marginalized = n_marg; out->device_seconds = secs;
+    out->solver = SPG_SOLVER_DENSE; out->supernodes = 0; out->front_bytes = 0; out->factor_flops = 0;
     return 0;
 }
 
@@ -2322,7 +2360,9 @@ static int optimize_with_fixed(spg_graph *g, int iterations, const std::vector<i
     for (int32_t v : fixed_vertices) is_fixed[v] = 1;
     int64_t n = 0;
     for (int32_t v : order) if (!is_fixed[v]) n += g->d;
-    if (n > 32000) return set_err(ctx, SPG_ECAPACITY, "spg_graph_optimize: dense formulation limited to 32k variables (2 x 8 GB)");
+    // dense up to 12 k unknowns (two n^2 matrices, an n^3 / 3 factorisation per trial), block-sparse beyond
+    const bool sparse = ctx->linear_solver == SPG_SOLVER_SPARSE || (ctx->linear_solver == SPG_SOLVER_AUTO && n > 12000);
+    if (!sparse && n > 32000) return set_err(ctx, SPG_ECAPACITY, "spg_graph_optimize: dense formulation limited to 32k variables (2 x 8 GB)");
     if (int rc = sync_device(g)) return rc;
     if (int rc = ctx->be.synchronize(ctx->be.user)) return rc;
     DenseStage st;
@@ -2330,9 +2370,11 @@ static int optimize_with_fixed(spg_graph *g, int iterations, const std::vector<i
     int p = 0;
     for (int32_t v : order) if (!is_fixed[v]) { st.pos[v] = p; p += g->d; }
     build_dense_stage(g, st);
-    double stats[5] = {0, 0, 0, 0, 0}, secs = 0;
+    double stats[5] = {0, 0, 0, 0, 0}, secs = 0, info[4] = {0, 0, 0, 0};
     ctx->err[0] = 0;
-    int rc = spg::hip_dense_optimize(spg::hip_backend_stream(&ctx->be), st.in, (int)n, iterations, stats, &secs, ctx->err, sizeof ctx->err);
+    int rc = (sparse && n > 0)
+                 ? spg::hip_sparse_optimize(spg::hip_backend_stream(&ctx->be), st.in, (int)n, iterations, stats, &secs, info, ctx->err, sizeof ctx->err)
+                 : spg::hip_dense_optimize(spg::hip_backend_stream(&ctx->be), st.in, (int)n, iterations, stats, &secs, ctx->err, sizeof ctx->err);
     // the estimates changed on the device: refresh the host mirror's copies
     if (int rc2 = sync_host(g)) return rc2;
     for (int32_t v : order) {
@@ -2344,6 +2386,33 @@ static int optimize_with_fixed(spg_graph *g, int iterations, const std::vector<i
         out->iterations = (int32_t)stats[0]; out->trials = (int32_t)stats[1];
         out->chi2_initial = stats[2]; out->chi2_final = stats[3]; out->lambda_final = stats[4]; out->device_seconds = secs;
         out->n = n;
+        out->solver = (sparse && n > 0) ? SPG_SOLVER_SPARSE : SPG_SOLVER_DENSE;
+        out->supernodes = (int32_t)info[0]; out->front_bytes = info[2]; out->factor_flops = info[3];
+    }
+    return 0;
+}
+
+extern "C" int spg_sparse_plan(int n, const int32_t *ptr, const int32_t *adj, int pose_dim, const uint8_t *is_marg, int leaf,
+                               spg_sparse_plan_info *info, int32_t *perm, int32_t *sn_first, int32_t *sn_parent, int32_t *sn_level,
+                               int32_t *sn_rowptr, int32_t *rows, int32_t *rel, int64_t rows_cap) {
+    if (n < 0 || !ptr || (!adj && n > 0 && ptr[n] > 0) || (pose_dim != 3 && pose_dim != 6) || !info) return SPG_EINVAL;
+    spg::sparse::BlockGraph bg;
+    bg.n = n;
+    bg.ptr.assign(ptr, ptr + n + 1);
+    bg.adj.assign(adj, adj + ptr[n]);
+    for (int32_t u : bg.adj) if (u < 0 || u >= n) return SPG_EINVAL;
+    spg::sparse::Plan P;
+    spg::sparse::build_plan(bg, pose_dim, is_marg, leaf > 0 ? leaf : (pose_dim == 6 ? 32 : 64), P);
+    info->n_supernodes = P.nsn; info->n_marg_supernodes = P.n_marg_sn; info->n_levels = P.nlevels; info->pad_ = 0;
+    info->n_rows = (int64_t)P.rows.size(); info->front_bytes = 8.0 * (double)P.pool; info->flops = P.flops;
+    if (perm) std::copy(P.perm.begin(), P.perm.end(), perm);
+    if (sn_first) std::copy(P.first.begin(), P.first.end(), sn_first);
+    if (sn_parent) std::copy(P.parent.begin(), P.parent.end(), sn_parent);
+    if (sn_level) std::copy(P.level.begin(), P.level.end(), sn_level);
+    if (sn_rowptr) std::copy(P.rowptr.begin(), P.rowptr.end(), sn_rowptr);
+    if (rows_cap >= (int64_t)P.rows.size()) {
+        if (rows) std::copy(P.rows.begin(), P.rows.end(), rows);
+        if (rel) std::copy(P.rel.begin(), P.rel.end(), rel);
     }
     return 0;
 }

@@ -43,6 +43,14 @@ int hip_big_glc_dense(void *stream, const DenseGraphIn &local_graph, int m, int 
 int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iterations, double *stats, double *seconds,
                        char *err, size_t errlen);
 
+// Block-sparse multifrontal path of the same two calls (spg_sparse.inc, symbolic phase in spg_sparse_plan.hpp).
+// info[4]: supernodes, levels of the assembly tree, bytes of fronts, flops of one factorisation.
+int hip_sparse_optimize(void *stream, const DenseGraphIn &in, int n, int iterations, double *stats, double *seconds, double *info,
+                        char *err, size_t errlen);
+int hip_sparse_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &other, const uint8_t *is_marg_vertex,
+                   const int32_t *kept_b, const int32_t *kept_o, int nk, const int64_t *kept_vpo_base, const int64_t *kept_vpo_other,
+                   double *terms, double *seconds, double *info, char *err, size_t errlen);
+
 // RCCL binding (spg_rccl.cpp): librccl.so.1 is bound with dlopen when the first multi-rank context is created
 int rccl_get_unique_id(void *id_out, char *err, size_t errlen);
 int rccl_comm_create(int device, int rank, int nranks, const void *unique_id, void **handle, char *err, size_t errlen);

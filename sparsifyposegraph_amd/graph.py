@@ -134,8 +134,8 @@ class GraphWrapperHIP:
         return self.last_stats
 
     def marginalize(self, which, options, flags=0):
-        """src/graph_wrapper_g2o.cpp:455-463: marginalizeNoOptimize followed by optimize(). The dense
-        optimiser takes graphs of up to 32k scalar variables; beyond that call marginalizeNoOptimize."""
+        """src/graph_wrapper_g2o.cpp:455-463: marginalizeNoOptimize followed by optimize() (dense LM up to 12 k
+        variables, the block-sparse multifrontal solver beyond: `last_optimize_stats["solver"]`)."""
         st = self.marginalizeNoOptimize(which, options, flags)
         self.optimize()
         return st
@@ -152,7 +152,8 @@ class GraphWrapperHIP:
 
     def optimize(self, iterations=50, fixed_id=-1):
         """GraphWrapperG2O::optimize (src/graph_wrapper_g2o.cpp:250-269): g2o Levenberg-Marquardt with
-        the first vertex fixed, dense on the device. Returns the stats dict."""
+        the first vertex fixed, on the device (dense or block-sparse factorisation, see
+        Context.set_linear_solver). Returns the stats dict."""
         st = abi.OptimizeStats()
         check(self.L.spg_graph_optimize(self.h, int(iterations), int(fixed_id), C.byref(st)), self.ctx.h, "optimize")
         self.last_optimize_stats = st.asdict()

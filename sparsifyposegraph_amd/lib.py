@@ -65,6 +65,9 @@ SYMBOLS = {
     "spg_graph_substitute_edge": (C.c_int, [C.c_void_p, _i32p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _f64p, _f64p]),
     "spg_graph_information": (C.c_int64, [C.c_void_p, C.c_int32, _f64p, C.c_int64]),
     "spg_graph_kullback_leibler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(abi.KldTerms)]),
+    "spg_ctx_set_linear_solver": (C.c_int, [C.c_void_p, C.c_int]),
+    "spg_sparse_plan": (C.c_int, [C.c_int, _i32p, _i32p, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.POINTER(abi.SparsePlanInfo),
+                                  _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, C.c_int64]),
     "spg_graph_optimize": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.POINTER(abi.OptimizeStats)]),
     "spg_graph_optimize_fixed": (C.c_int, [C.c_void_p, C.c_int, _i32p, C.c_int, C.POINTER(abi.OptimizeStats)]),
     "spg_graph_chi2": (C.c_int, [C.c_void_p, _f64p]),
@@ -154,6 +157,10 @@ class Context:
     def stream(self):
         return self.L.spg_ctx_stream(self.h)
 
+    def set_linear_solver(self, solver):
+        """abi.SOLVER_AUTO / SOLVER_DENSE / SOLVER_SPARSE for optimize() and the global KLD of this context's graphs."""
+        check(self.L.spg_ctx_set_linear_solver(self.h, int(solver)), self.h, "spg_ctx_set_linear_solver")
+
     def synchronize(self):
         check(self.L.spg_ctx_synchronize(self.h), self.h, "spg_ctx_synchronize")
 
@@ -191,3 +198,31 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def sparse_plan(adj_ptr, adj, pose_dim, is_marg=None, leaf=0):
+    """spg_sparse_plan (include/spg.h): the symbolic phase of the block-sparse solver (host only, no GPU needed)."""
+    import numpy as np
+    L = load()
+    adj_ptr = np.ascontiguousarray(adj_ptr, np.int32)
+    adj = np.ascontiguousarray(adj, np.int32)
+    n = len(adj_ptr) - 1
+    im = None if is_marg is None else np.ascontiguousarray(is_marg, np.uint8)
+    imp = None if im is None else im.ctypes.data_as(C.POINTER(C.c_uint8))
+    i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+    info = abi.SparsePlanInfo()
+    rc = L.spg_sparse_plan(n, i32(adj_ptr), i32(adj), pose_dim, imp, leaf, C.byref(info), None, None, None, None, None, None, None, 0)
+    if rc:
+        raise SpgError(f"spg_sparse_plan failed: {rc}")
+    nsn = info.n_supernodes
+    out = {"perm": np.zeros(n, np.int32), "first": np.zeros(nsn + 1, np.int32), "parent": np.zeros(nsn, np.int32),
+           "level": np.zeros(nsn, np.int32), "rowptr": np.zeros(nsn + 1, np.int32),
+           "rows": np.zeros(max(info.n_rows, 1), np.int32), "rel": np.zeros(max(info.n_rows, 1), np.int32)}
+    rc = L.spg_sparse_plan(n, i32(adj_ptr), i32(adj), pose_dim, imp, leaf, C.byref(info), i32(out["perm"]), i32(out["first"]),
+                           i32(out["parent"]), i32(out["level"]), i32(out["rowptr"]), i32(out["rows"]), i32(out["rel"]), max(info.n_rows, 1))
+    if rc:
+        raise SpgError(f"spg_sparse_plan failed: {rc}")
+    out["rows"] = out["rows"][:info.n_rows]
+    out["rel"] = out["rel"][:info.n_rows]
+    out.update(n_marg_supernodes=info.n_marg_supernodes, n_levels=info.n_levels, front_bytes=info.front_bytes, flops=info.flops)
+    return out
