@@ -476,6 +476,171 @@ inline double kld_value(const Mat &A, const Spectrum &sp) {
     return 0.5 * (tr - ld - sp.logdet - r);
 }
 
+// ---- interior-point NFR: optimizeInformation without a closed form (src/optimizer.cpp:38-79) ----
+// LogdetFunctionWithConstraints (src/logdet_function.cpp:87-214,348-427) over x = the measurement blocks X_e
+// (d x d each, all d^2 entries are variables; decondense reads the LOWER triangle of the column-major block), the
+// "dirty interior point" loop over rho and PQNOptimizer::optimize with useHessian = true and
+// LineSearchSimpleBacktracking (src/pqn/pqn_optimizer.cpp:29-126, src/pqn/line_search.cpp:12-37), literally — the
+// Hessian without the factor 1/2 of the gradient, optcond taken from the gradient BEFORE the step, and the line
+// search accepting any non-increase included. Eigen's LLT of the Hessian is restated as a plain Cholesky; where
+// Eigen would go on with an indefinite matrix this returns "line search failed" (infinity).
+struct IpFunction {
+    const JacMapping &mapping;
+    const Spectrum &sp;
+    int n, d, E, nx, q;
+    double rho = 0;
+    // state left behind by value() / gradient(), as the reference's members _chol / _xinv / _invXblocks
+    bool chol_ok = false;
+    Mat Mchol, xinv;
+    std::vector<Mat> invX;
+    Mat JU;   // sparseJacobian() * U, constant
+    IpFunction(const JacMapping &m, const Spectrum &s, int n_) : mapping(m), sp(s), n(n_) {
+        d = mapping.front().front().J.r; E = (int)mapping.size(); nx = d * d * E; q = d * E;
+        JU = matmul(sparse_jacobian(mapping, n), sp.U);
+    }
+    std::vector<Mat> decondense(const std::vector<double> &x) const {   // selfadjointView<Lower> of a column-major block
+        std::vector<Mat> X;
+        for (int e = 0; e < E; e++) {
+            Mat B(d, d);
+            for (int i = 0; i < d; i++) for (int j = 0; j <= i; j++) { double v = x[(size_t)e * d * d + (size_t)j * d + i]; B(i, j) = v; B(j, i) = v; }
+            X.push_back(B);
+        }
+        return X;
+    }
+    double base_value(const std::vector<double> &x) {   // LogdetFunction::value
+        Mat M = matmul(transpose(sp.U), matmul(information_product(mapping, decondense(x), n), sp.U));
+        mirror_upper(M);
+        int r = (int)sp.S.size();
+        double tr = 0;
+        for (int i = 0; i < r; i++) tr += M(i, i) * sp.S[i];
+        Mchol = M;
+        chol_ok = chol_lower(Mchol);
+        if (!chol_ok) return std::numeric_limits<double>::infinity();
+        double ld = 0;
+        for (int i = 0; i < r; i++) ld += std::log(Mchol(i, i));
+        return 0.5 * (tr - 2.0 * ld - sp.logdet - r);
+    }
+    double value(const std::vector<double> &x) {        // LogdetFunctionWithConstraints::value
+        double f = base_value(x);
+        for (const Mat &B : decondense(x)) {
+            bool ok;
+            double ld = spd_logdet(B, ok);
+            if (!ok) return std::numeric_limits<double>::infinity();
+            f -= rho * ld;
+        }
+        return f;
+    }
+    void gradient(const std::vector<double> &x, std::vector<double> &g) {
+        g.assign((size_t)nx, 0.0);
+        if (!chol_ok) return;
+        int r = (int)sp.S.size();
+        xinv = Mat::identity(r);
+        chol_solve(Mchol, xinv);
+        Mat mid(r, r);
+        for (int i = 0; i < r; i++) for (int j = 0; j < r; j++) mid(i, j) = -xinv(i, j) + (i == j ? sp.S[i] : 0.0);
+        Mat Y = matmul(sp.U, matmul(mid, transpose(sp.U)));
+        for (int e = 0; e < E; e++) {
+            const MeasJac &mj = mapping[e];
+            Mat blk(d, d);
+            for (size_t s1 = 0; s1 < mj.size(); s1++) {
+                int m1 = mj[s1].J.c;
+                Mat tb = matmul(mj[s1].J, matmul(block(Y, mj[s1].off, mj[s1].off, m1, m1), transpose(mj[s1].J)));
+                for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) blk(i, j) += 0.5 * (tb(i, j) + tb(j, i));
+                for (size_t s2 = s1 + 1; s2 < mj.size(); s2++) {
+                    int m2 = mj[s2].J.c;
+                    Mat t2 = matmul(mj[s1].J, matmul(block(Y, mj[s1].off, mj[s2].off, m1, m2), transpose(mj[s2].J)));
+                    for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) blk(i, j) += t2(i, j) + t2(j, i);
+                }
+            }
+            for (int j = 0; j < d; j++) for (int i = 0; i < d; i++) g[(size_t)e * d * d + (size_t)j * d + i] = 0.5 * blk(i, j);
+        }
+        // constraint part (src/logdet_function.cpp:372-397)
+        invX.clear();
+        std::vector<Mat> X = decondense(x);
+        for (int e = 0; e < E; e++) {
+            bool ok;
+            Mat inv = spd_inverse(X[e], ok);
+            if (!ok) { g.assign((size_t)nx, 0.0); return; }
+            invX.push_back(inv);
+            for (int j = 0; j < d; j++) for (int i = 0; i < d; i++) g[(size_t)e * d * d + (size_t)j * d + i] -= rho * inv(i, j);
+        }
+    }
+    void hessian(Mat &H) {   // uses xinv / invX of the last gradient()
+        Mat P = matmul(JU, matmul(xinv, transpose(JU)));
+        for (int i = 0; i < q; i++) for (int j = i + 1; j < q; j++) { double v = 0.5 * (P(i, j) + P(j, i)); P(i, j) = v; P(j, i) = v; }
+        H = Mat(nx, nx);
+        for (int e = 0; e < E; e++)
+            for (int jj = 0; jj < d; jj++) for (int ii = 0; ii < d; ii++) {
+                const int s = e * d * d + jj * d + ii, i = e * d + ii, j = e * d + jj;
+                for (int e2 = 0; e2 < E; e2++)
+                    for (int vv = 0; vv < d; vv++) for (int uu = 0; uu < d; uu++)
+                        H(s, e2 * d * d + vv * d + uu) = P(e2 * d + uu, i) * P(j, e2 * d + vv);
+            }
+        if (!chol_ok) return;
+        for (int e = 0; e < (int)invX.size(); e++)
+            for (int j = 0; j < d; j++) for (int i = 0; i < d; i++) {
+                const int s = e * d * d + j * d + i;
+                for (int v = 0; v < d; v++) for (int u = 0; u < d; u++) H(s, e * d * d + v * d + u) += rho * invX[e](u, i) * invX[e](j, v);
+            }
+    }
+};
+
+// PQNOptimizer::optimize (useHessian, maxIters = 0) + LineSearchSimpleBacktracking. Returns the function value,
+// infinity when the line search (or the Hessian factorisation) fails; iters counts Newton steps (diagnostic).
+inline double pqn_newton(IpFunction &fun, std::vector<double> &x, double tol, long &iters) {
+    const int nx = fun.nx;
+    std::vector<double> g, gn, xn((size_t)nx), dvec((size_t)nx);
+    double f = fun.value(x);
+    fun.gradient(x, g);
+    for (;;) {
+        Mat H;
+        fun.hessian(H);
+        if (!chol_lower(H)) return std::numeric_limits<double>::infinity();
+        Mat rhs(nx, 1);
+        for (int i = 0; i < nx; i++) rhs(i, 0) = -g[i];
+        chol_solve(H, rhs);
+        double gdotd = 0, dabs = 0;
+        for (int i = 0; i < nx; i++) { dvec[i] = rhs(i, 0); gdotd += g[i] * dvec[i]; dabs += std::fabs(dvec[i]); }
+        if (std::fabs(gdotd) < tol) return f;
+        const double f_old = f;
+        double step = 1, f_new = f;
+        for (;;) {
+            for (int i = 0; i < nx; i++) xn[i] = x[i] + step * dvec[i];
+            f_new = fun.value(xn);      // (the reference also re-evaluates value(x) here; it has no effect on the result)
+            if (step < 1e-12) return std::numeric_limits<double>::infinity();
+            if (!std::isfinite(f_new) || f_new > f) { step /= 2; continue; }
+            fun.gradient(xn, gn);
+            break;
+        }
+        double optcond = 0;
+        for (int i = 0; i < nx; i++) optcond += std::fabs(g[i]);   // the gradient before the step, as in the reference
+        x = xn; f = f_new; g = gn;
+        iters++;
+        if (optcond < tol) return f;
+        if (step * dabs < tol) return f;
+        if (std::fabs(f - f_old) < tol) return f;
+    }
+}
+
+// the interior-point branch of optimizeInformation (src/optimizer.cpp:38-79)
+inline bool interior_point(const JacMapping &mapping, const Spectrum &sp, int n, std::vector<Mat> &X, double &final_value, long &iters) {
+    IpFunction fun(mapping, sp, n);
+    std::vector<double> x((size_t)fun.nx, 0.0);
+    for (int e = 0; e < fun.E; e++) for (int i = 0; i < fun.d; i++) x[(size_t)e * fun.d * fun.d + (size_t)i * fun.d + i] = 1.0;   // educatedGuess
+    const double startRho = 1, endRho = 5e-8, stepRho = std::sqrt(10.0);
+    double tol = 1e-4;
+    iters = 0;
+    for (double rho = startRho; rho >= endRho; rho /= stepRho) {
+        fun.rho = rho;
+        if (rho / stepRho < endRho) tol = 1e-12;
+        pqn_newton(fun, x, tol, iters);
+    }
+    final_value = fun.base_value(x);
+    if (!std::isfinite(final_value)) return false;
+    X = fun.decondense(x);
+    return true;
+}
+
 // PseudoChowLiu::computeSparsityPattern (src/pseudo_chow_liu.cpp:33-87) for the uncorrelated
 // topologies. Returns kept-local pairs. needs_ip is set when the pattern is not a spanning tree.
 inline bool sparsity_pattern(const spg_options &o, const Mat &target, int d, int k,
@@ -506,7 +671,7 @@ inline void run_nfr(const spg_options &o, const BlanketIn &in, BlanketOut &out) 
     std::vector<std::pair<int, int>> pairs;
     if (!sparsity_pattern(o, out.target, d, k, pairs, out)) return;
     // hasClosedFormSolution (src/logdet_function.cpp:83-86): sum of edge dims == rank (n - d)
-    if ((int)pairs.size() * d != n - d) { out.status = SPG_ST_NEEDS_INTERIOR_POINT; return; }
+    const bool has_closed_form = (int)pairs.size() * d == n - d;
     JacMapping mapping;
     std::vector<NewEdge> edges;
     for (auto &pr : pairs) {
@@ -533,7 +698,14 @@ inline void run_nfr(const spg_options &o, const BlanketIn &in, BlanketOut &out) 
     Spectrum sp;
     if (!logdet_spectrum(out.target, mapping, sp, out.info)) { out.status = SPG_ST_EIG_FAIL; return; }
     std::vector<Mat> X;
-    if (!closed_form(mapping, sp, X)) { out.status = SPG_ST_CLOSED_FORM_NOT_PD; return; }
+    if (has_closed_form) {
+        if (!closed_form(mapping, sp, X)) { out.status = SPG_ST_CLOSED_FORM_NOT_PD; return; }
+    } else {
+        double fin = 0;
+        long iters = 0;
+        if (!interior_point(mapping, sp, n, X, fin, iters)) { out.status = SPG_ST_KLD_NOT_PD; return; }   // the reference exit(0)s here
+        out.info |= (int)std::min<long>(iters, 32767) << 8;   // Newton steps taken (diagnostic, bits 8..)
+    }
     for (size_t e = 0; e < edges.size(); e++) {
         int p = ps;
         for (int i = 0; i < d; i++) for (int j = i; j < d; j++) edges[e].data[p++] = X[e](i, j);

@@ -923,7 +923,12 @@ static void collect_edges(spg_graph *g, const int32_t *verts, int nverts, const 
 static void new_edge_budget(const spg_options &o, int d, int k, int32_t &n_new_max, int32_t &n_new_vert_max, int64_t &new_len) {
     int ps = pose_stride(d);
     if (o.algorithm == SPG_ALG_NFR) {
+        // pattern size (src/pseudo_chow_liu.cpp:33-87): a tree, or up to all pairs for Dense / Subgraph
         n_new_max = std::max(k - 1, 0);
+        if (k > 2 && (o.topology == SPG_TOPO_DENSE || o.topology == SPG_TOPO_SUBGRAPH)) {
+            const int msub = (int)((1 + o.chord_ratio) * (k - 1)), all = k * (k - 1) / 2;
+            n_new_max = (o.topology == SPG_TOPO_DENSE || msub >= all) ? all : std::max(msub, k - 1);
+        }
         n_new_vert_max = 2 * n_new_max;
         new_len = (int64_t)n_new_max * (ps + info_len(d));
     } else if (o.topology == SPG_TOPO_DENSE || k <= 1) {

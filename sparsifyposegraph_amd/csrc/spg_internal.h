@@ -51,6 +51,26 @@ int hip_sparse_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &o
                    const int32_t *kept_b, const int32_t *kept_o, int nk, const int64_t *kept_vpo_base, const int64_t *kept_vpo_other,
                    double *terms, double *seconds, double *info, char *err, size_t errlen);
 
+// Interior-point NFR (spg_nfr_ip.hip): blankets of the Dense / Subgraph patterns without a closed form, one workgroup
+// each, everything in a per-blanket slice of a global workspace.
+struct IpArgs {
+    double *arena;
+    const spg_blanket_desc *blk;
+    const int64_t *vpo;
+    const spg_edge_ref *er;
+    const int32_t *ev;
+    const int32_t *list;      // blanket indices of this launch (blockIdx.x -> list[blockIdx.x])
+    double *ws;               // workspace, ws_stride doubles per blanket of the launch
+    int64_t ws_stride;
+    double *mail;             // pinned host mailbox for out records (or nullptr)
+    int64_t mail_base;
+    int topology, lin_point, tag, pad_;
+    double chord_ratio;
+};
+int nfr_ip_pattern_size(int topology, double chord_ratio, int k);   // new edges of a blanket with k kept vertices (-1: correlated patterns)
+int64_t nfr_ip_workspace(int D, int k, int m, int E);               // doubles of workspace one such blanket needs
+int hip_nfr_ip_launch(void *stream, int D, const IpArgs &a, int count);
+
 // RCCL binding (spg_rccl.cpp): librccl.so.1 is bound with dlopen when the first multi-rank context is created
 int rccl_get_unique_id(void *id_out, char *err, size_t errlen);
 int rccl_comm_create(int device, int rank, int nranks, const void *unique_id, void **handle, char *err, size_t errlen);

@@ -1561,8 +1561,8 @@ struct HipBackend {
     // previous one is still running.
     struct Slot {
         hipStream_t stream = nullptr;
-        void *d_desc = nullptr, *d_gws = nullptr;
-        size_t c_desc = 0, c_gws = 0;
+        void *d_desc = nullptr, *d_gws = nullptr, *d_ipws = nullptr;
+        size_t c_desc = 0, c_gws = 0, c_ipws = 0;
         void *h_mail = nullptr, *d_mail = nullptr;   // pinned host mailbox the kernel writes out records into
         size_t c_mail = 0;
         void *h_stage = nullptr;                      // pinned host staging for the descriptor upload
@@ -1817,7 +1817,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     // (not for the first two batches after a synchronisation: a call that removes a handful of vertices, e.g. online
     //  decimation, is cheaper as a plain launch than as worker start + stop)
     hb->batches_in_call++;
-    bool to_worker = worker_env && hb->large_bar && !hb->worker.disabled && rd->mail_len > 0 && o.algorithm == SPG_ALG_NFR &&
+    bool to_worker = worker_env && hb->large_bar && !hb->worker.disabled && rd->mail_len > 0 && o.algorithm == SPG_ALG_NFR && o.topology == SPG_TOPO_TREE &&
                      o.lin_point == SPG_LIN_GLOBAL && o.flags == 0 && rd->count <= 512 && !hb->force_one_wave &&
                      hb->worker_cooldown == 0 && (hb->batches_in_call > 2 || hb->worker.running);
     if (hb->worker_cooldown > 0) hb->worker_cooldown--;
@@ -1949,6 +1949,33 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         bins[bi].mmax = std::max(bins[bi].mmax, m);
         bins[bi].smax = std::max(bins[bi].smax, (int)bd.pad_);
     }
+    // NFR blankets whose pattern (Dense / Subgraph with more than k-1 edges) has no closed form: interior point, its own
+    // kernel (spg_nfr_ip.hip), one workgroup per blanket after the launches below
+    std::vector<int32_t> ip_list;
+    int64_t ip_stride = 0;
+    if (o.algorithm == SPG_ALG_NFR && (o.topology == SPG_TOPO_DENSE || o.topology == SPG_TOPO_SUBGRAPH)) {
+        for (int i = 0; i < NB; i++) {
+            size_t keep = 0;
+            int kmax = 0, mmax = 0, smax = 0;
+            for (int32_t b : bins[i].list) {
+                const spg_blanket_desc &bd = rd->blankets[b];
+                const int k = bd.n_vert - bd.n_remove, m = bd.n_remove;
+                const int E = spg::nfr_ip_pattern_size(o.topology, o.chord_ratio, k);
+                if (k >= 3 && E > k - 1) {
+                    if ((int64_t)D * D * E > 2048 || k > 64) {
+                        snprintf(err, sizeof hb->err, "interior-point NFR: a blanket with k=%d kept vertices and %d new edges needs a %d^2 Hessian (limit 2048^2)", k, E, D * D * E);
+                        return SPG_ECAPACITY;
+                    }
+                    ip_list.push_back(b);
+                    ip_stride = std::max(ip_stride, spg::nfr_ip_workspace(D, k, m, E));
+                    continue;
+                }
+                bins[i].list[keep++] = b;
+                kmax = std::max(kmax, k); mmax = std::max(mmax, m); smax = std::max(smax, (int)bd.pad_);
+            }
+            if (keep != bins[i].list.size()) { bins[i].list.resize(keep); bins[i].kmax = kmax; bins[i].mmax = mmax; bins[i].smax = smax; }
+        }
+    }
     // Blankets whose side buffers (Chow-Liu pair tables, GLC batch buffers) exceed LDS even with the tiles in the L2
     // workspace: GLC Dense ones go through the dense HBM pipeline on the matrix cores (spg_dense.hip) after the
     // launches below, one at a time; for the others there is no path (SPG_ECAPACITY, as before).
@@ -2027,6 +2054,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         int32_t *lst = (int32_t *)(st + o_list);
         size_t p = 0;
         for (int i = 0; i < NB; i++) for (int32_t b : bins[i].list) lst[p++] = b;
+        for (int32_t b : ip_list) lst[p++] = b;      // (the lists together never exceed rd->count entries)
     }
     char *desc_base;
     if (via_bar) {
@@ -2125,6 +2153,18 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
                 rc = (D == 6) ? launch_bin<6, 256, true, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes) : launch_bin<3, 256, true, SPG_ALG_NFR>(hb, S, ka, nb, lds, bins[i].bytes);
         }
         if (rc) return rc;
+    }
+    // ---- interior-point NFR blankets
+    if (!ip_list.empty()) {
+        if (int rc2 = hb->ensure(S, &S.d_ipws, &S.c_ipws, (size_t)ip_stride * 8 * ip_list.size())) return rc2;
+        spg::IpArgs ia{};
+        ia.arena = (double *)arena; ia.blk = ka.blk; ia.vpo = ka.vpo; ia.er = ka.er; ia.ev = ka.ev;
+        ia.list = (const int32_t *)(desc_base + o_list) + list_off;
+        ia.ws = (double *)S.d_ipws; ia.ws_stride = ip_stride; ia.mail = mail_dev; ia.mail_base = rd->mail_base;
+        ia.topology = o.topology; ia.lin_point = o.lin_point; ia.tag = rd->tag; ia.chord_ratio = o.chord_ratio;
+        if (int rc2 = spg::hip_nfr_ip_launch((void *)S.stream, D, ia, (int)ip_list.size())) { snprintf(err, sizeof hb->err, "launch of the interior-point kernel failed"); return rc2; }
+        S.stream_dirty = true;
+        S.busy = true;
     }
     // ---- large GLC Dense blankets: dense in HBM, O(n^3) parts on the fp64 matrix cores
     for (int32_t b : big_list) {

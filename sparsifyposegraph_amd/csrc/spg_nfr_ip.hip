@@ -1,0 +1,641 @@
+// csrc/spg_nfr_ip.hip — interior-point NFR on the device: the blankets whose sparsity pattern has
+// no closed form — SparsityOptions::Dense and ::Subgraph with more than k-1 uncorrelated pose-pose edges.
+//
+// Reference: optimizeInformation's "dirty interior point" (src/optimizer.cpp:38-79) over
+// LogdetFunctionWithConstraints (src/logdet_function.cpp:87-214,348-427) with PQNOptimizer::optimize in its
+// useHessian form and LineSearchSimpleBacktracking (src/pqn/pqn_optimizer.cpp:29-126, src/pqn/line_search.cpp:12-37);
+// pattern selection PseudoChowLiu::computeSparsityPattern (src/pseudo_chow_liu.cpp:33-87, doKruskal :253-289). The
+// control flow is the reference's, quirks included (oracle/ref_blanket.hpp IpFunction / pqn_newton restate the same):
+// 15 barrier weights rho = 1 ... 5.6e-8, per rho Newton steps H d = -g with the reference's Hessian (P (x) P without the
+// 1/2 of the gradient), step halving until the value does not increase, three termination tests with tolerance 1e-4
+// (1e-12 for the last rho).
+//
+// One workgroup (256 threads) per blanket, every matrix in a per-blanket slice of a global workspace (L2-resident): a
+// blanket is ~50-100 dependent Newton steps whose largest object is the (d^2 E)^2 Hessian (k = 4, SE3, Dense: 216^2),
+// i.e. a latency chain like the closed-form kernel's but ~1000 x longer; the blankets of a batch run side by side.
+// The kernel does the whole blanket itself — gather, Hessian of the blanket's pose-pose edges, Schur complement,
+// pattern, spectrum, interior point, records — and hands the result over exactly as blanket_kernel does (new edge
+// records in the arena, out record + ready / final word in the mailbox or the arena).
+// Scope: pose-pose edges in, Global linearisation point, the `smalleigs <= dim` branch of the spectrum
+// (src/logdet_function.cpp:36-39); anything else reports a status and writes no edges.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+
+#include "spg_dev_geom.hpp"
+#include "spg_dev_la.hpp"
+#include "spg_internal.h"
+
+using namespace spgdev;
+
+namespace {
+
+constexpr int NT = 256;
+
+struct IpLayout {   // offsets (doubles) into one blanket's workspace
+    int n, nm, N, r, E, q, nx;
+    int64_t H, Lam, A1, V, S, U, J, JU, Ai, T1, M, Mc, Mi, Li, Y, P, T2, Hx, x, xn, g, gn, dv, Xi, pose, w, total;
+};
+
+__host__ __device__ inline IpLayout ip_layout(int D, int k, int m, int E) {
+    IpLayout L;
+    L.n = D * k; L.nm = D * m; L.N = L.n + L.nm; L.r = L.n - D; L.E = E; L.q = D * E; L.nx = D * D * E;
+    int64_t o = 0;
+    auto take = [&](int64_t len) { int64_t at = o; o += (len + 7) & ~(int64_t)7; return at; };
+    const int64_t n = L.n, N = L.N, r = L.r > 0 ? L.r : 1, q = L.q, nx = L.nx, P2 = (int64_t)k * (k - 1) / 2;
+    L.H = take(N * N); L.Lam = take(n * n); L.A1 = take(n * n); L.V = take(n * n); L.S = take(n); L.U = take(n * r);
+    L.J = take(2 * (int64_t)D * D * E); L.JU = take(q * r); L.Ai = take(n * n); L.T1 = take(n * r);
+    L.M = take(r * r); L.Mc = take(r * r); L.Mi = take(r * r); L.Li = take(r * r); L.Y = take(n * n);
+    L.P = take(q * q); L.T2 = take(q * r); L.Hx = take(nx * nx);
+    L.x = take(nx); L.xn = take(nx); L.g = take(nx); L.gn = take(nx); L.dv = take(nx); L.Xi = take(nx);
+    L.pose = take(12 * (int64_t)(k + m)); L.w = take(4 * P2 + 8);
+    L.total = o;
+    return L;
+}
+
+__host__ __device__ inline int ip_pattern_size(int topology, double chord_ratio, int k) {
+    if (k < 2) return 0;
+    if (k == 2) return 1;
+    const int msub = (int)((1 + chord_ratio) * (k - 1));
+    const bool full = msub >= k * (k - 1) / 2;
+    if (topology == SPG_TOPO_TREE) return k - 1;
+    if (topology == SPG_TOPO_DENSE || (topology == SPG_TOPO_SUBGRAPH && full)) return k * (k - 1) / 2;
+    if (topology == SPG_TOPO_SUBGRAPH) return msub;
+    return -1;
+}
+
+// lower Cholesky of a small matrix by ONE thread (IEEE divide / sqrt: this is the control path of the line search)
+__device__ inline bool chol_serial(double *A, int n, int ld) {
+    for (int j = 0; j < n; j++) {
+        double d = A[j * ld + j];
+        for (int k = 0; k < j; k++) d -= A[j * ld + k] * A[j * ld + k];
+        if (!(d > 0.0) || !isfinite(d)) return false;
+        const double l = sqrt(d);
+        A[j * ld + j] = l;
+        for (int i = j + 1; i < n; i++) {
+            double s = A[i * ld + j];
+            for (int k = 0; k < j; k++) s -= A[i * ld + k] * A[j * ld + k];
+            A[i * ld + j] = s / l;
+        }
+    }
+    return true;
+}
+
+template <int D>
+__global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
+    constexpr int DD = D * D, PS = (D == 6) ? 7 : 3, PSZ = (D == 6) ? 12 : 3, REC = PS + D * (D + 1) / 2;
+    __shared__ double red[NT];
+    __shared__ int flag_s;
+    __shared__ double sc[8];      // scalars broadcast by thread 0
+    __shared__ int si[8];
+    const int tid = threadIdx.x;
+    const int b = a.list[blockIdx.x];
+    const spg_blanket_desc bd = a.blk[b];
+    const int nv = bd.n_vert, m = bd.n_remove, k = nv - m;
+    const int E = ip_pattern_size(a.topology, a.chord_ratio, k);
+    const IpLayout L = ip_layout(D, k, m, E > 0 ? E : 1);
+    const int n = L.n, nm = L.nm, N = L.N, r = L.r, q = L.q, nx = L.nx;
+    double *ws = a.ws + (int64_t)blockIdx.x * a.ws_stride;
+    double *arena = a.arena;
+    double *orec = a.mail ? (a.mail + (bd.out_off - a.mail_base)) : (arena + bd.out_off);
+    if (tid == 0) flag_s = 0;
+    __syncthreads();
+    Team<NT> T{tid, red, &flag_s};
+    int status = SPG_OK, info = 0, n_new = 0;
+    double kld = __builtin_nan(""), min_gap = __builtin_inf();
+    // L.w: [0, P2) pair weights | [P2, 2 P2) pair (i, j) ints | [2 P2, 3 P2) pop order + rejected bin (ints) | 3 P2 + 2: the pattern (2 E ints)
+    int *pairs = reinterpret_cast<int *>(ws + L.w + 3 * ((int64_t)k * (k - 1) / 2) + 2);
+
+    auto finish = [&]() {
+        __syncthreads();
+        if (tid == 0) {
+            orec[0] = (double)status; orec[1] = (double)info; orec[2] = kld; orec[3] = min_gap; orec[4] = (double)n_new;
+            for (int e = 0; e < n_new; e++) {
+                orec[SPG_OUT_HDR + 4 * e + 0] = (double)SPG_EDGE_BINARY;
+                orec[SPG_OUT_HDR + 4 * e + 1] = (double)(e * REC);
+                orec[SPG_OUT_HDR + 4 * e + 2] = (double)REC;
+                orec[SPG_OUT_HDR + 4 * e + 3] = 2.0;
+                orec[SPG_OUT_HDR + 4 * bd.n_new_max + 2 * e + 0] = (double)(m + pairs[2 * e]);
+                orec[SPG_OUT_HDR + 4 * bd.n_new_max + 2 * e + 1] = (double)(m + pairs[2 * e + 1]);
+            }
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&orec[5], SPG_FINAL_WORD(a.tag), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    if (k < 2) { finish(); return; }
+    if (E < 0) { status = SPG_ST_UNSUPPORTED; finish(); return; }
+    if (a.lin_point != SPG_LIN_GLOBAL) { status = SPG_ST_NEEDS_LOCAL_OPTIMIZATION; finish(); return; }
+    for (int e = 0; e < bd.n_edge; e++)
+        if (a.er[bd.edge_begin + e].kind != SPG_EDGE_BINARY) { status = SPG_ST_UNSUPPORTED; finish(); return; }
+
+    // ---- gather poses; H = sum_e J^T Omega J over the blanket's edges (one edge at a time: sizes are tiny next to
+    // the Newton iterations below), vertices ordered [removed | kept] as the descriptors list them
+    double *pose = ws + L.pose, *H = ws + L.H;
+    for (int v = tid; v < nv; v += NT) {
+        const double *p = arena + a.vpo[bd.vert_begin + v];
+        if (D == 6) iso_from_tq(p, pose + v * PSZ);
+        else { pose[v * 3] = p[0]; pose[v * 3 + 1] = p[1]; pose[v * 3 + 2] = p[2]; }
+    }
+    for (int it = tid; it < N * N; it += NT) H[it] = 0.0;
+    __syncthreads();
+    {
+        double *Je = ws + L.Ai;    // scratch: Ji, Jj, T = Omega [Ji Jj]   (Ai is free until the interior point)
+        for (int e = 0; e < bd.n_edge; e++) {
+            const spg_edge_ref er = a.er[bd.edge_begin + e];
+            const int vi = a.ev[er.vbegin], vj = a.ev[er.vbegin + 1];
+            const double *rec = arena + er.off;
+            if (vi == vj) continue;
+            if (tid == 0) {
+                if (D == 6) {
+                    double Z[kIso];
+                    iso_from_tq(rec, Z);
+                    se3_edge_jac(pose + vi * PSZ, pose + vj * PSZ, Z, Je, Je + DD, nullptr);
+                } else {
+                    se2_edge_jac(pose + vi * PSZ, pose + vj * PSZ, rec, Je, Je + DD, nullptr);
+                }
+            }
+            __syncthreads();
+            // T[p][c'] = sum_t Omega[p][t] * Jcat[t][c'], Jcat = [Ji | Jj] (D x 2D)
+            for (int it = tid; it < D * 2 * D; it += NT) {
+                const int p = it / (2 * D), c = it - p * 2 * D;
+                const double *Jc = (c < D) ? Je : Je + DD;
+                const int cc = (c < D) ? c : c - D;
+                double s = 0;
+                for (int t = 0; t < D; t++) {
+                    const int lo = p < t ? p : t, hi = p < t ? t : p;
+                    s += rec[PS + lo * D - lo * (lo - 1) / 2 + (hi - lo)] * Jc[t * D + cc];
+                }
+                Je[2 * DD + it] = s;
+            }
+            __syncthreads();
+            for (int it = tid; it < 4 * DD; it += NT) {
+                const int rr = it / (2 * D), c = it - rr * 2 * D;      // entry (rr, c) of Jcat^T T, 2D x 2D
+                const double *Jr = (rr < D) ? Je : Je + DD;
+                const int r2 = (rr < D) ? rr : rr - D;
+                double s = 0;
+                for (int p = 0; p < D; p++) s += Jr[p * D + r2] * Je[2 * DD + p * 2 * D + c];
+                const int gi = ((rr < D) ? vi : vj) * D + r2, gj = ((c < D) ? vi : vj) * D + ((c < D) ? c : c - D);
+                H[gi * N + gj] += s;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- Schur complement onto the kept block (src/vertex_remover.cpp:409-449)
+    double *Lam = ws + L.Lam;
+    if (nm > 0) {
+        chol_lower<NT>(T, H, nm, N);                            // H_mm = L L^T (lower, in place)
+        if (flag_s) { status = SPG_ST_HMM_NOT_PD; finish(); return; }
+        // W = L^-1 H_mk (nm x n), stored over the upper right block
+        for (int c = tid; c < n; c += NT)
+            for (int i = 0; i < nm; i++) {
+                double s = H[i * N + nm + c];
+                for (int t = 0; t < i; t++) s -= H[i * N + t] * H[t * N + nm + c];
+                H[i * N + nm + c] = s / H[i * N + i];
+            }
+        __syncthreads();
+    }
+    for (int it = tid; it < n * n; it += NT) {
+        const int i = it / n, j = it - i * n;
+        double s = H[(nm + i) * N + nm + j];
+        for (int t = 0; t < nm; t++) s -= H[t * N + nm + i] * H[t * N + nm + j];
+        Lam[it] = s;
+    }
+    __syncthreads();
+    for (int it = tid; it < n * n; it += NT) { const int i = it / n, j = it - i * n; if (j > i) Lam[it] = 0.5 * (Lam[it] + Lam[j * n + i]); }
+    __syncthreads();
+    for (int it = tid; it < n * n; it += NT) { const int i = it / n, j = it - i * n; if (j < i) Lam[it] = Lam[j * n + i]; }
+    __syncthreads();
+    {
+        double bad = 0;
+        for (int it = tid; it < n * n; it += NT) if (!isfinite(Lam[it])) bad = 1;
+        if (T.sum(bad) > 0) { status = SPG_ST_NONFINITE; finish(); return; }
+    }
+
+    // ---- sparsity pattern (src/pseudo_chow_liu.cpp:33-87)
+    if (k == 2) {
+        if (tid == 0) { pairs[0] = 0; pairs[1] = 1; }
+    } else if (E == k * (k - 1) / 2) {
+        if (tid == 0) { int e = 0; for (int i = 0; i < k - 1; i++) for (int j = i + 1; j < k; j++) { pairs[2 * e] = i; pairs[2 * e + 1] = j; e++; } }
+    } else {
+        // pseudo-Chow-Liu weights from Sigma~ = (Lambda_t + I)^-1 (:169-196), Kruskal in pop order, accepted edges first,
+        // then the rejected ones (:253-289); the pattern is the first E of that bin
+        double *A1 = ws + L.A1, *Vv = ws + L.V, *Sg = ws + L.Y;
+        for (int it = tid; it < n * n; it += NT) { const int i = it / n, j = it - i * n; A1[it] = Lam[it] + (i == j ? 1.0 : 0.0); }
+        __syncthreads();
+        chol_lower<NT>(T, A1, n, n);
+        if (flag_s) { status = SPG_ST_TIKHONOV_NOT_PD; finish(); return; }
+        tri_inverse_lower<NT>(T, A1, Vv, n, n);
+        gram_lower_inverse<NT>(T, Vv, Sg, n, n);
+        const int P2 = k * (k - 1) / 2;
+        double *w = ws + L.w;               // w[p], then (after P2) scratch
+        int *pij = reinterpret_cast<int *>(ws + L.w + P2);    // 2 P2 ints
+        for (int p = tid; p < P2; p += NT) {
+            int i = 0, rem = p;
+            while (rem >= k - 1 - i) { rem -= k - 1 - i; i++; }
+            const int j = i + 1 + rem;
+            pij[2 * p] = i; pij[2 * p + 1] = j;
+            // log det of the marginal covariance blocks: ld_i + ld_j - ld_ij
+            double B[4 * DD];
+            auto ld_of = [&](const int *vs, int cnt) {
+                const int s = cnt * D;
+                for (int x = 0; x < s; x++) for (int y = 0; y < s; y++) B[x * s + y] = Sg[(vs[x / D] * D + x % D) * n + vs[y / D] * D + y % D];
+                if (!chol_serial(B, s, s)) return __builtin_nan("");
+                double l = 0;
+                for (int x = 0; x < s; x++) l += log(B[x * s + x]);
+                return 2.0 * l;
+            };
+            const int vi[1] = {i}, vj[1] = {j}, vij[2] = {i, j};
+            const double li = ld_of(vi, 1), lj = ld_of(vj, 1), lij = ld_of(vij, 2);
+            w[p] = (li + lj) - lij;
+            if (!isfinite(w[p])) flag_s = 1;
+        }
+        __syncthreads();
+        if (flag_s) { status = SPG_ST_TIKHONOV_NOT_PD; finish(); return; }
+        if (tid == 0) {
+            // pop order: weight descending, ties by (i, j) ascending = index ascending
+            int *order = pij + 2 * P2;     // P2 ints (inside the 4 P2 + 8 doubles reserved at L.w)
+            for (int p = 0; p < P2; p++) order[p] = p;
+            for (int x = 1; x < P2; x++) {
+                const int v = order[x];
+                int y = x - 1;
+                while (y >= 0 && (w[order[y]] < w[v] || (w[order[y]] == w[v] && order[y] > v))) { order[y + 1] = order[y]; y--; }
+                order[y + 1] = v;
+            }
+            int comp[64];
+            for (int v = 0; v < k; v++) comp[v] = v;
+            int nacc = 0, nrej = 0, last = 0;
+            int *rej = order + P2;         // rejected pair indices, in pop order (P2 more ints)
+            for (int s = 0; s < P2; s++) {
+                const int p = order[s], i = pij[2 * p], j = pij[2 * p + 1];
+                if (comp[i] != comp[j]) {
+                    pairs[2 * nacc] = i; pairs[2 * nacc + 1] = j;
+                    nacc++;
+                    const int ci = comp[i], cj = comp[j];
+                    for (int v = 0; v < k; v++) if (comp[v] == cj) comp[v] = ci;
+                    last = s;
+                } else rej[nrej++] = p;
+            }
+            for (int t = 0; nacc + t < E && t < nrej; t++) { pairs[2 * (nacc + t)] = pij[2 * rej[t]]; pairs[2 * (nacc + t) + 1] = pij[2 * rej[t] + 1]; }
+            const int upto = min(last + 1, P2 - 1);
+            double g = __builtin_inf();
+            for (int s = 0; s < upto; s++) {
+                const double x = w[order[s]], y = w[order[s + 1]];
+                const double den = fmax(fmax(fabs(x), fabs(y)), 1e-300);
+                g = fmin(g, (x - y) / den);
+            }
+            sc[0] = g;
+        }
+        __syncthreads();
+        min_gap = sc[0];
+    }
+    __syncthreads();
+
+    // ---- new edge skeleton: measurement from the state, Jacobians (src/topology_provider_binary.hpp:38-47)
+    double *Jb = ws + L.J;
+    for (int e = tid; e < E; e += NT) {
+        const int va = m + pairs[2 * e], vb = m + pairs[2 * e + 1];
+        double *rec = arena + bd.new_off + (int64_t)e * REC;
+        if (D == 6) {
+            double Z[kIso], qd[4];
+            iso_inv_mul(pose + va * PSZ, pose + vb * PSZ, Z);
+            R_to_quat(Z, qd);
+            rec[0] = Z[9]; rec[1] = Z[10]; rec[2] = Z[11]; rec[3] = qd[0]; rec[4] = qd[1]; rec[5] = qd[2]; rec[6] = qd[3];
+            se3_edge_jac(pose + va * PSZ, pose + vb * PSZ, Z, Jb + e * 2 * DD, Jb + e * 2 * DD + DD, nullptr);
+        } else {
+            double z[3];
+            se2_between(pose + va * PSZ, pose + vb * PSZ, z);
+            rec[0] = z[0]; rec[1] = z[1]; rec[2] = z[2];
+            se2_edge_jac(pose + va * PSZ, pose + vb * PSZ, z, Jb + e * 2 * DD, Jb + e * 2 * DD + DD, nullptr);
+        }
+    }
+    __syncthreads();
+    // sparseJacobian() drops entries below epsilon (src/logdet_function.cpp:335); it feeds J U of the Hessian
+    // ---- spectrum of the target (src/logdet_function.cpp:14-64)
+    double *A1 = ws + L.A1, *Vv = ws + L.V, *Sv = ws + L.S, *U = ws + L.U;
+    for (int it = tid; it < n * n; it += NT) A1[it] = Lam[it];
+    __syncthreads();
+    if (!jacobi_eigh<NT>(T, A1, Vv, n, n, ws + L.T1)) { status = SPG_ST_EIG_FAIL; finish(); return; }
+    {
+        int *perm = reinterpret_cast<int *>(ws + L.T1);     // n ints
+        sort_ascending<NT>(T, A1, n + 1, n, perm);
+        __syncthreads();
+        double small = 0;
+        for (int i = tid; i < n; i += NT) if (A1[i * (n + 1)] < 1e-5) small += 1;
+        const int smalleigs = (int)T.sum(small);
+        if (smalleigs > D) { status = SPG_ST_UNSUPPORTED; info |= SPG_INFO_RANK_DEFICIENT; finish(); return; }   // chooseDimensions branch
+        for (int j = tid; j < r; j += NT) Sv[j] = 1.0 / A1[perm[D + j] * (n + 1)];
+        for (int it = tid; it < n * r; it += NT) { const int i = it / r, j = it - i * r; U[it] = Vv[i * n + perm[D + j]]; }
+        __syncthreads();
+    }
+    double logdetS = 0;
+    {
+        double l = 0;
+        for (int j = tid; j < r; j += NT) l += log(Sv[j]);
+        logdetS = T.sum(l);
+    }
+    // JU = sparseJacobian * U  (q x r): row (e, p) = Ja[p,:] U[a-block,:] + Jb[p,:] U[b-block,:]
+    double *JU = ws + L.JU;
+    for (int it = tid; it < q * r; it += NT) {
+        const int row = it / r, c = it - row * r, e = row / D, p = row - e * D;
+        const int oa = pairs[2 * e] * D, ob = pairs[2 * e + 1] * D;
+        const double *Ja = Jb + e * 2 * DD, *Jbb = Ja + DD;
+        double s = 0;
+        for (int t = 0; t < D; t++) {
+            const double ja = Ja[p * D + t], jb = Jbb[p * D + t];
+            if (fabs(ja) >= 2.220446049250313e-16) s += ja * U[(oa + t) * r + c];
+            if (fabs(jb) >= 2.220446049250313e-16) s += jb * U[(ob + t) * r + c];
+        }
+        JU[it] = s;
+    }
+    __syncthreads();
+
+    // ---- the function: value(xv) leaves chol(M) in Mc; gradient(xv, gv) leaves M^-1 in Mi and the X_e^-1 in Xi
+    double *Ai = ws + L.Ai, *T1 = ws + L.T1, *M = ws + L.M, *Mc = ws + L.Mc, *Mi = ws + L.Mi, *Li = ws + L.Li, *Y = ws + L.Y;
+    double *P = ws + L.P, *T2 = ws + L.T2, *Hx = ws + L.Hx, *Xi = ws + L.Xi;
+    double *x = ws + L.x, *xn = ws + L.xn, *g = ws + L.g, *gn = ws + L.gn, *dv = ws + L.dv;
+    double rho = 0;
+    // symmetric view of block e of xv from its lower triangle (column-major): X(i, j), i >= j, at xv[e DD + j D + i]
+    auto Xat = [&](const double *xv, int e, int i, int j) { return (i >= j) ? xv[e * DD + j * D + i] : xv[e * DD + i * D + j]; };
+    auto base_value = [&](const double *xv, bool &ok) -> double {
+        // A = J^T X J (upper triangle accumulated, then mirrored), one (edge, block pair) product at a time
+        for (int it = tid; it < n * n; it += NT) Ai[it] = 0.0;
+        __syncthreads();
+        for (int e = 0; e < E; e++) {
+            const int oa = pairs[2 * e] * D, ob = pairs[2 * e + 1] * D;
+            const double *Ja = Jb + e * 2 * DD, *Jbb = Ja + DD;
+            // T = X [Ja | Jb] (D x 2D) in T2, then [Ja | Jb]^T T into A
+            for (int it = tid; it < D * 2 * D; it += NT) {
+                const int p = it / (2 * D), c = it - p * 2 * D;
+                const double *Jc = (c < D) ? Ja : Jbb;
+                const int cc = (c < D) ? c : c - D;
+                double s = 0;
+                for (int t = 0; t < D; t++) s += Xat(xv, e, p, t) * Jc[t * D + cc];
+                T2[it] = s;
+            }
+            __syncthreads();
+            for (int it = tid; it < 4 * DD; it += NT) {
+                const int rr = it / (2 * D), c = it - rr * 2 * D;
+                const double *Jr = (rr < D) ? Ja : Jbb;
+                const int r2 = (rr < D) ? rr : rr - D;
+                double s = 0;
+                for (int p = 0; p < D; p++) s += Jr[p * D + r2] * T2[p * 2 * D + c];
+                const int gi = ((rr < D) ? oa : ob) + r2, gj = ((c < D) ? oa : ob) + ((c < D) ? c : c - D);
+                // the reference accumulates block (lower offset, higher offset) only and mirrors the upper triangle:
+                // an entry below the diagonal of the whole matrix is the transpose of one above
+                if (gi <= gj) Ai[gi * n + gj] += s;
+            }
+            __syncthreads();
+        }
+        for (int it = tid; it < n * n; it += NT) { const int i = it / n, j = it - i * n; if (j < i) Ai[it] = Ai[j * n + i]; }
+        __syncthreads();
+        // M = U^T A U, symmetric from the upper triangle
+        for (int it = tid; it < n * r; it += NT) {
+            const int i = it / r, c = it - i * r;
+            double s = 0;
+            for (int t = 0; t < n; t++) s += Ai[i * n + t] * U[t * r + c];
+            T1[it] = s;
+        }
+        __syncthreads();
+        for (int it = tid; it < r * r; it += NT) {
+            const int i = it / r, j = it - i * r;
+            if (j >= i) {
+                double s = 0;
+                for (int t = 0; t < n; t++) s += U[t * r + i] * T1[t * r + j];
+                M[i * r + j] = s; M[j * r + i] = s;
+            }
+        }
+        __syncthreads();
+        double tr = 0;
+        for (int i = tid; i < r; i += NT) tr += M[i * r + i] * Sv[i];
+        tr = T.sum(tr);
+        for (int it = tid; it < r * r; it += NT) Mc[it] = M[it];
+        if (tid == 0) flag_s = 0;
+        __syncthreads();
+        chol_lower<NT>(T, Mc, r, r);
+        ok = flag_s == 0;
+        __syncthreads();
+        if (!ok) { if (tid == 0) flag_s = 0; __syncthreads(); return __builtin_inf(); }
+        double l = 0;
+        for (int i = tid; i < r; i += NT) l += log(Mc[i * r + i]);
+        l = T.sum(l);
+        return 0.5 * (tr - 2.0 * l - logdetS - r);
+    };
+    bool chol_ok = false;
+    auto value = [&](const double *xv) -> double {
+        double f = base_value(xv, chol_ok);
+        // barrier: - rho * sum_e log det X_e, +inf when a block is not positive definite
+        double pen = 0;
+        for (int e = tid; e < E; e += NT) {
+            double B[DD];
+            for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) B[i * D + j] = Xat(xv, e, i, j);
+            if (!chol_serial(B, D, D)) pen = __builtin_inf();
+            else { double l = 0; for (int i = 0; i < D; i++) l += log(B[i * D + i]); pen += 2.0 * l; }
+        }
+        // deterministic: per-edge terms summed in edge order by thread 0
+        red[tid] = pen;
+        __syncthreads();
+        if (tid == 0) { double s = 0; for (int e = 0; e < E && e < NT; e++) s += red[e]; sc[1] = s; }
+        __syncthreads();
+        const double ps = sc[1];
+        __syncthreads();
+        if (!isfinite(f)) return __builtin_inf();
+        if (!isfinite(ps)) return __builtin_inf();
+        return f - rho * ps;
+    };
+    auto gradient = [&](const double *xv, double *gv) {
+        if (!chol_ok) { for (int it = tid; it < nx; it += NT) gv[it] = 0.0; __syncthreads(); return; }
+        tri_inverse_lower<NT>(T, Mc, Li, r, r);
+        gram_lower_inverse<NT>(T, Li, Mi, r, r);           // xinv = M^-1
+        // Y = U (diag(S) - xinv) U^T
+        for (int it = tid; it < n * r; it += NT) {
+            const int i = it / r, c = it - i * r;
+            double s = 0;
+            for (int t = 0; t < r; t++) s += U[i * r + t] * ((t == c ? Sv[t] : 0.0) - Mi[t * r + c]);
+            T1[it] = s;
+        }
+        __syncthreads();
+        for (int it = tid; it < n * n; it += NT) {
+            const int i = it / n, j = it - i * n;
+            double s = 0;
+            for (int t = 0; t < r; t++) s += T1[i * r + t] * U[j * r + t];
+            Y[it] = s;
+        }
+        __syncthreads();
+        // per edge: block = sym(Ja Yaa Ja^T) + sym(Jb Ybb Jb^T) + (Ja Yab Jb^T + its transpose); g_e = block / 2
+        for (int it = tid; it < nx; it += NT) {
+            const int e = it / DD, jj = (it - e * DD) / D, ii = it - e * DD - jj * D;      // column-major (ii, jj)
+            const int oa = pairs[2 * e] * D, ob = pairs[2 * e + 1] * D;
+            const double *Ja = Jb + e * 2 * DD, *Jbb = Ja + DD;
+            auto quad = [&](const double *J1, int o1, const double *J2, int o2, int i1, int i2) {
+                double s = 0;
+                for (int u = 0; u < D; u++) {
+                    double t = 0;
+                    for (int v = 0; v < D; v++) t += Y[(o1 + u) * n + o2 + v] * J2[i2 * D + v];
+                    s += J1[i1 * D + u] * t;
+                }
+                return s;
+            };
+            const double aa = 0.5 * (quad(Ja, oa, Ja, oa, ii, jj) + quad(Ja, oa, Ja, oa, jj, ii));
+            const double bb = 0.5 * (quad(Jbb, ob, Jbb, ob, ii, jj) + quad(Jbb, ob, Jbb, ob, jj, ii));
+            const double ab = quad(Ja, oa, Jbb, ob, ii, jj) + quad(Ja, oa, Jbb, ob, jj, ii);
+            gv[it] = 0.5 * (aa + bb + ab);
+        }
+        __syncthreads();
+        // constraint part: X_e^-1, g_e -= rho X_e^-1
+        if (tid == 0) si[0] = 0;
+        __syncthreads();
+        for (int e = tid; e < E; e += NT) {
+            double B[DD], Inv[DD];
+            for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) B[i * D + j] = Xat(xv, e, i, j);
+            if (!chol_serial(B, D, D)) { si[0] = 1; continue; }
+            // solve L L^T Inv = I column by column
+            for (int c = 0; c < D; c++) {
+                double y[D];
+                for (int i = 0; i < D; i++) { double s = (i == c) ? 1.0 : 0.0; for (int t = 0; t < i; t++) s -= B[i * D + t] * y[t]; y[i] = s / B[i * D + i]; }
+                for (int i = D - 1; i >= 0; i--) { double s = y[i]; for (int t = i + 1; t < D; t++) s -= B[t * D + i] * Inv[t * D + c]; Inv[i * D + c] = s / B[i * D + i]; }
+            }
+            for (int i = 0; i < DD; i++) Xi[e * DD + i] = Inv[i];      // row-major (u, v)
+        }
+        __syncthreads();
+        if (si[0]) { for (int it = tid; it < nx; it += NT) gv[it] = 0.0; __syncthreads(); return; }
+        for (int it = tid; it < nx; it += NT) {
+            const int e = it / DD, jj = (it - e * DD) / D, ii = it - e * DD - jj * D;
+            gv[it] -= rho * Xi[e * DD + ii * D + jj];
+        }
+        __syncthreads();
+    };
+    auto hessian = [&]() {
+        // P = sym(JU xinv JU^T)
+        for (int it = tid; it < q * r; it += NT) {
+            const int i = it / r, c = it - i * r;
+            double s = 0;
+            for (int t = 0; t < r; t++) s += JU[i * r + t] * Mi[t * r + c];
+            T2[it] = s;
+        }
+        __syncthreads();
+        for (int it = tid; it < q * q; it += NT) {
+            const int i = it / q, j = it - i * q;
+            double s = 0;
+            for (int t = 0; t < r; t++) s += T2[i * r + t] * JU[j * r + t];
+            P[it] = s;
+        }
+        __syncthreads();
+        for (int it = tid; it < q * q; it += NT) { const int i = it / q, j = it - i * q; if (j > i) { const double v = 0.5 * (P[it] + P[j * q + i]); P[it] = v; } }
+        __syncthreads();
+        for (int it = tid; it < q * q; it += NT) { const int i = it / q, j = it - i * q; if (j < i) P[it] = P[j * q + i]; }
+        __syncthreads();
+        // H[(e, ii, jj)][(e2, uu, vv)] = P(e2 D + uu, e D + ii) P(e D + jj, e2 D + vv)  (+ rho Xinv(uu, ii) Xinv(jj, vv) on e2 = e)
+        for (long long it = tid; it < (long long)nx * nx; it += NT) {
+            const int s = (int)(it / nx), t = (int)(it - (long long)s * nx);
+            const int e = s / DD, jj = (s - e * DD) / D, ii = s - e * DD - jj * D;
+            const int e2 = t / DD, vv = (t - e2 * DD) / D, uu = t - e2 * DD - vv * D;
+            double v = P[(e2 * D + uu) * q + e * D + ii] * P[(e * D + jj) * q + e2 * D + vv];
+            if (e2 == e && chol_ok) v += rho * Xi[e * DD + uu * D + ii] * Xi[e * DD + jj * D + vv];
+            Hx[it] = v;
+        }
+        __syncthreads();
+    };
+    // PQNOptimizer::optimize with useHessian (src/pqn/pqn_optimizer.cpp:29-126)
+    int newton_steps = 0;
+    auto optimize = [&](double tol) {
+        double f = value(x);
+        gradient(x, g);
+        for (;;) {
+            hessian();
+            if (tid == 0) flag_s = 0;
+            __syncthreads();
+            chol_lower<NT>(T, Hx, nx, nx);
+            const bool hok = flag_s == 0;
+            __syncthreads();
+            if (!hok) { if (tid == 0) flag_s = 0; __syncthreads(); return; }
+            // d = -(L L^T)^-1 g: forward then backward substitution, one column => serial in i, parallel over the dot products
+            for (int it = tid; it < nx; it += NT) dv[it] = -g[it];
+            __syncthreads();
+            for (int i = 0; i < nx; i++) {
+                double s = 0;
+                for (int t = tid; t < i; t += NT) s += Hx[(long long)i * nx + t] * dv[t];
+                s = T.sum(s);
+                if (tid == 0) dv[i] = (dv[i] - s) / Hx[(long long)i * nx + i];
+                __syncthreads();
+            }
+            for (int i = nx - 1; i >= 0; i--) {
+                double s = 0;
+                for (int t = i + 1 + tid; t < nx; t += NT) s += Hx[(long long)t * nx + i] * dv[t];
+                s = T.sum(s);
+                if (tid == 0) dv[i] = (dv[i] - s) / Hx[(long long)i * nx + i];
+                __syncthreads();
+            }
+            double gd = 0, da = 0;
+            for (int it = tid; it < nx; it += NT) { gd += g[it] * dv[it]; da += fabs(dv[it]); }
+            gd = T.sum(gd); da = T.sum(da);
+            if (fabs(gd) < tol) return;
+            const double f_old = f;
+            double step = 1, f_new = f;
+            for (;;) {
+                for (int it = tid; it < nx; it += NT) xn[it] = x[it] + step * dv[it];
+                __syncthreads();
+                f_new = value(xn);
+                if (step < 1e-12) return;                       // line search failed: x stays
+                if (!isfinite(f_new) || f_new > f) { step /= 2; continue; }
+                gradient(xn, gn);
+                break;
+            }
+            double oc = 0;
+            for (int it = tid; it < nx; it += NT) oc += fabs(g[it]);   // the gradient BEFORE the step, as in the reference
+            oc = T.sum(oc);
+            for (int it = tid; it < nx; it += NT) { x[it] = xn[it]; g[it] = gn[it]; }
+            __syncthreads();
+            f = f_new;
+            newton_steps++;
+            if (oc < tol) return;
+            if (step * da < tol) return;
+            if (fabs(f - f_old) < tol) return;
+        }
+    };
+    // ---- the interior point (src/optimizer.cpp:38-79)
+    for (int it = tid; it < nx; it += NT) { const int o = it % DD; x[it] = (o / D == o % D) ? 1.0 : 0.0; }   // educatedGuess
+    __syncthreads();
+    {
+        const double endRho = 5e-8, stepRho = sqrt(10.0);
+        double tol = 1e-4;
+        for (rho = 1; rho >= endRho; rho /= stepRho) {
+            if (rho / stepRho < endRho) tol = 1e-12;
+            optimize(tol);
+        }
+    }
+    bool okf = false;
+    const double fin = base_value(x, okf);
+    if (!okf || !isfinite(fin)) { status = SPG_ST_KLD_NOT_PD; finish(); return; }    // the reference exit(0)s here
+    kld = fin;
+    info |= min(newton_steps, 32767) << 8;
+    // information of the new edges: upper triangle of the symmetric view of x
+    for (int it = tid; it < E * (D * (D + 1) / 2); it += NT) {
+        const int e = it / (D * (D + 1) / 2);
+        int o = it - e * (D * (D + 1) / 2), i = 0;
+        while (o >= D - i) { o -= D - i; i++; }
+        const int j = i + o;
+        arena[bd.new_off + (int64_t)e * REC + PS + (it - e * (D * (D + 1) / 2))] = Xat(x, e, i, j);
+    }
+    n_new = E;
+    finish();
+}
+
+}  // namespace
+
+namespace spg {
+
+int nfr_ip_pattern_size(int topology, double chord_ratio, int k) { return ip_pattern_size(topology, chord_ratio, k); }
+
+int64_t nfr_ip_workspace(int D, int k, int m, int E) { return ip_layout(D, k, m, E > 0 ? E : 1).total; }
+
+int hip_nfr_ip_launch(void *stream, int D, const IpArgs &a, int count) {
+    if (count <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 6) hipLaunchKernelGGL((nfr_ip_kernel<6>), dim3(count), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((nfr_ip_kernel<3>), dim3(count), dim3(NT), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : SPG_EHIP;
+}
+
+}  // namespace spg
