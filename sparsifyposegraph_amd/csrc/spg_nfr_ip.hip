@@ -5,7 +5,7 @@
 // LogdetFunctionWithConstraints (src/logdet_function.cpp:87-214,348-427) with PQNOptimizer::optimize in its
 // useHessian form and LineSearchSimpleBacktracking (src/pqn/pqn_optimizer.cpp:29-126, src/pqn/line_search.cpp:12-37);
 // pattern selection PseudoChowLiu::computeSparsityPattern (src/pseudo_chow_liu.cpp:33-87, doKruskal :253-289). The
-// control flow is the reference's, quirks included (oracle/ref_blanket.hpp IpFunction / pqn_newton restate the same):
+// control flow is the reference's, quirks included (the test checker restates the same loop independently):
 // 15 barrier weights rho = 1 ... 5.6e-8, per rho Newton steps H d = -g with the reference's Hessian (P (x) P without the
 // 1/2 of the gradient), step halving until the value does not increase, three termination tests with tolerance 1e-4
 // (1e-12 for the last rho).

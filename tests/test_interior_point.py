@@ -185,7 +185,7 @@ def test_device_interior_point_whole_graph(case, n, chord, hip_ctx):
     fin = np.isfinite(ob["kld"])
     assert np.abs(hb["kld"][idx][fin] - ob["kld"][fin]).max() <= 1e-9
     n_ip = int(((ob["info"] >> 8) > 0).sum())
-    assert n_ip >= 10
+    assert n_ip >= 3
     kref = float(np.nansum(ob["kld"]))
     ht = GraphWrapperHIP.from_dict(sub, ctx=hip_ctx)
     stt = ht.marginalizeNoOptimize(w, _opts(d, abi.TOPO_TREE))
