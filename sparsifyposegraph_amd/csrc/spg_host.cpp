@@ -2382,9 +2382,16 @@ static int optimize_with_fixed(spg_graph *g, int iterations, const std::vector<i
                  : spg::hip_dense_optimize(spg::hip_backend_stream(&ctx->be), st.in, (int)n, iterations, stats, &secs, ctx->err, sizeof ctx->err);
     // the estimates changed on the device: refresh the host mirror's copies
     if (int rc2 = sync_host(g)) return rc2;
-    for (int32_t v : order) {
-        if (is_fixed[v]) continue;
-        if (int rc2 = ctx->be.download(ctx->be.user, g->host.data() + g->vpose[v], (char *)g->dev + g->vpose[v] * 8, g->ps)) return rc2;
+    {
+        // one download of the arena range that holds the free vertices' poses (a copy per vertex costs ~30 us each:
+        // 3 s for a 100 k-pose graph), then only the pose slots are taken over
+        int64_t lo = INT64_MAX, hi = -1;
+        for (int32_t v : order) if (!is_fixed[v]) { lo = std::min(lo, g->vpose[v]); hi = std::max(hi, g->vpose[v] + g->ps); }
+        if (hi > lo) {
+            std::vector<double> tmp((size_t)(hi - lo));
+            if (int rc2 = ctx->be.download(ctx->be.user, tmp.data(), (char *)g->dev + lo * 8, hi - lo)) return rc2;
+            for (int32_t v : order) if (!is_fixed[v]) memcpy(g->host.data() + g->vpose[v], tmp.data() + (g->vpose[v] - lo), (size_t)g->ps * 8);
+        }
     }
     if (rc) return rc;
     if (out) {

@@ -19,4 +19,7 @@ python tools/throughput_bench.py 64 512 16384 131072 > $OUT/prof_throughput.log 
 fi
 # large-blanket path (GLC Dense on sphere.g2o at full size): kernel stats of the dense pipeline
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_big -o run -- python3 tools/big_bench.py > $OUT/prof_big.log 2>&1 || true
+# block-sparse path at the headline size (optimize after marginalisation, global KLD) and the interior-point kernel
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sparse -o run -- python3 tools/sparse_bench.py 100000 400 all > $OUT/prof_sparse.log 2>&1 || true
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_ip -o run -- python3 tools/ip_bench.py > $OUT/prof_ip.log 2>&1 || true
 find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -name '*.csv' | head -20

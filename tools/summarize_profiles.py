@@ -99,3 +99,13 @@ except SystemExit as e:
 print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}, indent=1))
 for k, v in kernels.items():
     print(k[:90], v)
+
+
+# block-sparse path at the headline size and the interior-point kernel (tools/sparse_bench.py, tools/ip_bench.py)
+for d, name in (("prof_sparse", "sparse_100k"), ("prof_ip", "interior_point")):
+    try:
+        shutil.copy(one(f"{d}/**/*kernel_stats.csv"), os.path.join(prof, f"{tag}_{name}_kernel_stats.csv"))
+        lines = [l for l in open(os.path.join(out, f"{d}.log")) if l.startswith("{")]
+        open(os.path.join(prof, f"{tag}_{name}_bench.jsonl"), "w").writelines(lines)
+    except SystemExit:
+        pass
