@@ -64,12 +64,13 @@ struct IpArgs {
     int64_t ws_stride;
     double *mail;             // pinned host mailbox for out records (or nullptr)
     int64_t mail_base;
-    int topology, lin_point, tag, pad_;
+    int topology, lin_point, tag;
+    int lds_doubles;          // dynamic LDS of the launch: a blanket whose hot buffers fit keeps them there
     double chord_ratio;
 };
 int nfr_ip_pattern_size(int topology, double chord_ratio, int k);   // new edges of a blanket with k kept vertices (-1: correlated patterns)
-int64_t nfr_ip_workspace(int D, int k, int m, int E);               // doubles of workspace one such blanket needs
-int hip_nfr_ip_launch(void *stream, int D, const IpArgs &a, int count);
+int64_t nfr_ip_workspace(int D, int k, int m, int E, int64_t *hot);  // doubles of workspace one such blanket needs (*hot: its LDS-eligible part)
+int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int64_t hot_max);
 
 // RCCL binding (spg_rccl.cpp): librccl.so.1 is bound with dlopen when the first multi-rank context is created
 int rccl_get_unique_id(void *id_out, char *err, size_t errlen);

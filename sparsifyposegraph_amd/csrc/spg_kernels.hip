@@ -1952,7 +1952,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     // NFR blankets whose pattern (Dense / Subgraph with more than k-1 edges) has no closed form: interior point, its own
     // kernel (spg_nfr_ip.hip), one workgroup per blanket after the launches below
     std::vector<int32_t> ip_list;
-    int64_t ip_stride = 0;
+    int64_t ip_stride = 0, ip_hot = 0;
     if (o.algorithm == SPG_ALG_NFR && (o.topology == SPG_TOPO_DENSE || o.topology == SPG_TOPO_SUBGRAPH)) {
         for (int i = 0; i < NB; i++) {
             size_t keep = 0;
@@ -1967,7 +1967,9 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
                         return SPG_ECAPACITY;
                     }
                     ip_list.push_back(b);
-                    ip_stride = std::max(ip_stride, spg::nfr_ip_workspace(D, k, m, E));
+                    int64_t hot = 0;
+                    ip_stride = std::max(ip_stride, spg::nfr_ip_workspace(D, k, m, E, &hot));
+                    ip_hot = std::max(ip_hot, hot);
                     continue;
                 }
                 bins[i].list[keep++] = b;
@@ -2162,7 +2164,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         ia.list = (const int32_t *)(desc_base + o_list) + list_off;
         ia.ws = (double *)S.d_ipws; ia.ws_stride = ip_stride; ia.mail = mail_dev; ia.mail_base = rd->mail_base;
         ia.topology = o.topology; ia.lin_point = o.lin_point; ia.tag = rd->tag; ia.chord_ratio = o.chord_ratio;
-        if (int rc2 = spg::hip_nfr_ip_launch((void *)S.stream, D, ia, (int)ip_list.size())) { snprintf(err, sizeof hb->err, "launch of the interior-point kernel failed"); return rc2; }
+        if (int rc2 = spg::hip_nfr_ip_launch((void *)S.stream, D, ia, (int)ip_list.size(), ip_hot)) { snprintf(err, sizeof hb->err, "launch of the interior-point kernel failed"); return rc2; }
         S.stream_dirty = true;
         S.busy = true;
     }

@@ -32,10 +32,19 @@ using namespace spgdev;
 namespace {
 
 constexpr int NT = 256;
+#ifdef SPG_IP_PROF
+#define IPT(k) do { long long t_ = (long long)__builtin_amdgcn_s_memtime(); ipt[k] += t_ - ipt_last; ipt_last = t_; } while (0)
+#else
+#define IPT(k) do { } while (0)
+#endif
+constexpr int kPanelDoubles = 8192;   // 64 KB: 16 columns of a panel up to 480 rows tall, fewer columns for taller ones
 
-struct IpLayout {   // offsets (doubles) into one blanket's workspace
+struct IpLayout {   // offsets (doubles) of one blanket's buffers: a cold part in the global workspace, a hot part (everything the
+                    // Newton iterations touch except the Hessian) relative to its own base — LDS when it fits, else behind the cold part
     int n, nm, N, r, E, q, nx;
-    int64_t H, Lam, A1, V, S, U, J, JU, Ai, T1, M, Mc, Mi, Li, Y, P, T2, Hx, x, xn, g, gn, dv, Xi, pose, w, total;
+    int64_t H, Lam, A1, V, Hx, pose, w, cold_total;
+    int64_t S, U, J, JU, Ai, T1, M, Mc, Mi, Li, Y, P, T2, x, xn, g, gn, dv, Xi, hot_total;
+    int64_t total;
 };
 
 __host__ __device__ inline IpLayout ip_layout(int D, int k, int m, int E) {
@@ -44,13 +53,16 @@ __host__ __device__ inline IpLayout ip_layout(int D, int k, int m, int E) {
     int64_t o = 0;
     auto take = [&](int64_t len) { int64_t at = o; o += (len + 7) & ~(int64_t)7; return at; };
     const int64_t n = L.n, N = L.N, r = L.r > 0 ? L.r : 1, q = L.q, nx = L.nx, P2 = (int64_t)k * (k - 1) / 2;
-    L.H = take(N * N); L.Lam = take(n * n); L.A1 = take(n * n); L.V = take(n * n); L.S = take(n); L.U = take(n * r);
-    L.J = take(2 * (int64_t)D * D * E); L.JU = take(q * r); L.Ai = take(n * n); L.T1 = take(n * r);
-    L.M = take(r * r); L.Mc = take(r * r); L.Mi = take(r * r); L.Li = take(r * r); L.Y = take(n * n);
-    L.P = take(q * q); L.T2 = take(q * r); L.Hx = take(nx * nx);
-    L.x = take(nx); L.xn = take(nx); L.g = take(nx); L.gn = take(nx); L.dv = take(nx); L.Xi = take(nx);
+    L.H = take(N * N); L.Lam = take(n * n); L.A1 = take(n * n); L.V = take(n * n); L.Hx = take(nx * nx);
     L.pose = take(12 * (int64_t)(k + m)); L.w = take(4 * P2 + 8);
-    L.total = o;
+    L.cold_total = o;
+    o = 0;
+    L.S = take(n); L.U = take(n * r); L.J = take(2 * (int64_t)D * D * E); L.JU = take(q * r); L.Ai = take(n * n); L.T1 = take(n * r);
+    L.M = take(r * r); L.Mc = take(r * r); L.Mi = take(r * r); L.Li = take(r * r); L.Y = take(n * n);
+    L.P = take(q * q); L.T2 = take(q * r);
+    L.x = take(nx); L.xn = take(nx); L.g = take(nx); L.gn = take(nx); L.dv = take(nx); L.Xi = take(nx);
+    L.hot_total = o;
+    L.total = L.cold_total + L.hot_total;
     return L;
 }
 
@@ -85,10 +97,13 @@ __device__ inline bool chol_serial(double *A, int n, int ld) {
 template <int D>
 __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     constexpr int DD = D * D, PS = (D == 6) ? 7 : 3, PSZ = (D == 6) ? 12 : 3, REC = PS + D * (D + 1) / 2;
+    extern __shared__ double lds_pool[];
     __shared__ double red[NT];
     __shared__ int flag_s;
     __shared__ double sc[8];      // scalars broadcast by thread 0
     __shared__ int si[8];
+    __shared__ double colbuf[2048];   // running vector of the Newton solve (d^2 E <= 2048)
+    __shared__ double panel[kPanelDoubles];   // panel of the Hessian's Cholesky
     const int tid = threadIdx.x;
     const int b = a.list[blockIdx.x];
     const spg_blanket_desc bd = a.blk[b];
@@ -97,6 +112,9 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     const IpLayout L = ip_layout(D, k, m, E > 0 ? E : 1);
     const int n = L.n, nm = L.nm, N = L.N, r = L.r, q = L.q, nx = L.nx;
     double *ws = a.ws + (int64_t)blockIdx.x * a.ws_stride;
+    // hot buffers in LDS when this blanket's fit into what the launch reserved (latency per dependent phase ~0.1 us
+    // instead of ~1 us out of L2: a Newton step is a few hundred such phases)
+    double *hot = (L.hot_total <= (int64_t)a.lds_doubles) ? lds_pool : ws + L.cold_total;
     double *arena = a.arena;
     double *orec = a.mail ? (a.mail + (bd.out_off - a.mail_base)) : (arena + bd.out_off);
     if (tid == 0) flag_s = 0;
@@ -141,7 +159,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     for (int it = tid; it < N * N; it += NT) H[it] = 0.0;
     __syncthreads();
     {
-        double *Je = ws + L.Ai;    // scratch: Ji, Jj, T = Omega [Ji Jj]   (Ai is free until the interior point)
+        double *Je = hot + L.Ai;    // scratch: Ji, Jj, T = Omega [Ji Jj]   (Ai is free until the interior point)
         for (int e = 0; e < bd.n_edge; e++) {
             const spg_edge_ref er = a.er[bd.edge_begin + e];
             const int vi = a.ev[er.vbegin], vj = a.ev[er.vbegin + 1];
@@ -221,7 +239,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     } else {
         // pseudo-Chow-Liu weights from Sigma~ = (Lambda_t + I)^-1 (:169-196), Kruskal in pop order, accepted edges first,
         // then the rejected ones (:253-289); the pattern is the first E of that bin
-        double *A1 = ws + L.A1, *Vv = ws + L.V, *Sg = ws + L.Y;
+        double *A1 = ws + L.A1, *Vv = ws + L.V, *Sg = hot + L.Y;
         for (int it = tid; it < n * n; it += NT) { const int i = it / n, j = it - i * n; A1[it] = Lam[it] + (i == j ? 1.0 : 0.0); }
         __syncthreads();
         chol_lower<NT>(T, A1, n, n);
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     __syncthreads();
 
     // ---- new edge skeleton: measurement from the state, Jacobians (src/topology_provider_binary.hpp:38-47)
-    double *Jb = ws + L.J;
+    double *Jb = hot + L.J;
     for (int e = tid; e < E; e += NT) {
         const int va = m + pairs[2 * e], vb = m + pairs[2 * e + 1];
         double *rec = arena + bd.new_off + (int64_t)e * REC;
@@ -313,12 +331,12 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     __syncthreads();
     // sparseJacobian() drops entries below epsilon (src/logdet_function.cpp:335); it feeds J U of the Hessian
     // ---- spectrum of the target (src/logdet_function.cpp:14-64)
-    double *A1 = ws + L.A1, *Vv = ws + L.V, *Sv = ws + L.S, *U = ws + L.U;
+    double *A1 = ws + L.A1, *Vv = ws + L.V, *Sv = hot + L.S, *U = hot + L.U;
     for (int it = tid; it < n * n; it += NT) A1[it] = Lam[it];
     __syncthreads();
-    if (!jacobi_eigh<NT>(T, A1, Vv, n, n, ws + L.T1)) { status = SPG_ST_EIG_FAIL; finish(); return; }
+    if (!jacobi_eigh<NT>(T, A1, Vv, n, n, hot + L.T1)) { status = SPG_ST_EIG_FAIL; finish(); return; }
     {
-        int *perm = reinterpret_cast<int *>(ws + L.T1);     // n ints
+        int *perm = reinterpret_cast<int *>(hot + L.T1);     // n ints
         sort_ascending<NT>(T, A1, n + 1, n, perm);
         __syncthreads();
         double small = 0;
@@ -336,7 +354,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         logdetS = T.sum(l);
     }
     // JU = sparseJacobian * U  (q x r): row (e, p) = Ja[p,:] U[a-block,:] + Jb[p,:] U[b-block,:]
-    double *JU = ws + L.JU;
+    double *JU = hot + L.JU;
     for (int it = tid; it < q * r; it += NT) {
         const int row = it / r, c = it - row * r, e = row / D, p = row - e * D;
         const int oa = pairs[2 * e] * D, ob = pairs[2 * e + 1] * D;
@@ -352,9 +370,9 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     __syncthreads();
 
     // ---- the function: value(xv) leaves chol(M) in Mc; gradient(xv, gv) leaves M^-1 in Mi and the X_e^-1 in Xi
-    double *Ai = ws + L.Ai, *T1 = ws + L.T1, *M = ws + L.M, *Mc = ws + L.Mc, *Mi = ws + L.Mi, *Li = ws + L.Li, *Y = ws + L.Y;
-    double *P = ws + L.P, *T2 = ws + L.T2, *Hx = ws + L.Hx, *Xi = ws + L.Xi;
-    double *x = ws + L.x, *xn = ws + L.xn, *g = ws + L.g, *gn = ws + L.gn, *dv = ws + L.dv;
+    double *Ai = hot + L.Ai, *T1 = hot + L.T1, *M = hot + L.M, *Mc = hot + L.Mc, *Mi = hot + L.Mi, *Li = hot + L.Li, *Y = hot + L.Y;
+    double *P = hot + L.P, *T2 = hot + L.T2, *Hx = ws + L.Hx, *Xi = hot + L.Xi;
+    double *x = hot + L.x, *xn = hot + L.xn, *g = hot + L.g, *gn = hot + L.gn, *dv = hot + L.dv;
     double rho = 0;
     // symmetric view of block e of xv from its lower triangle (column-major): X(i, j), i >= j, at xv[e DD + j D + i]
     auto Xat = [&](const double *xv, int e, int i, int j) { return (i >= j) ? xv[e * DD + j * D + i] : xv[e * DD + i * D + j]; };
@@ -537,36 +555,139 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
         __syncthreads();
     };
+    // Cholesky of the Hessian (Eigen::LLT in the reference, src/pqn/pqn_optimizer.cpp:52-53), lower, in place, out of L2.
+    // Blocked right-looking: a panel of PB columns is factorised in LDS, then the trailing matrix takes ONE pass of
+    // read-modify-writes per panel (rows are walked, four rows in flight per wavefront so that the L2 round trips overlap:
+    // a column-at-a-time version spent ~1 us of load latency per row and column, 5 ms per factorisation at 216^2).
+    // Every entry still has its products subtracted one by one in column order, as the unblocked algorithm does.
+    // Returns false (uniformly) on a non-positive pivot.
+    auto chol_rows = [&](double *A, int nn) -> bool {
+        const int PB = max(1, min(16, kPanelDoubles / nn - 1));   // panel columns: nn rows of PB + 1 doubles fit the LDS panel
+        const int PBS = PB + 1;                                     // row stride (odd for the usual PB = 16: column walks conflict-free)
+        bool okc = true;
+        for (int j0 = 0; j0 < nn; j0 += PB) {
+            const int pb = min(PB, nn - j0), nrows = nn - j0;
+            for (int it = tid; it < nrows * pb; it += NT) {          // panel rows j0.., columns j0..j0+pb (lower part)
+                const int rr = it / pb, pc = it - rr * pb;
+                panel[rr * PBS + pc] = (pc <= rr) ? A[(long long)(j0 + rr) * nn + j0 + pc] : 0.0;
+            }
+            __syncthreads();
+            for (int pc = 0; pc < pb; pc++) {
+                double dpiv = panel[pc * PBS + pc];
+                if (!(dpiv > 0.0) || !isfinite(dpiv)) { okc = false; dpiv = 1.0; }
+                const double l = sqrt(dpiv);
+                __syncthreads();                                     // everybody has read the pivot
+                for (int rr = pc + 1 + tid; rr < nrows; rr += NT) panel[rr * PBS + pc] /= l;
+                if (tid == 0) panel[pc * PBS + pc] = l;
+                __syncthreads();
+                const int rest = pb - pc - 1;
+                for (int it = tid; it < (nrows - pc - 1) * rest; it += NT) {
+                    const int rr = pc + 1 + it / rest, p2 = pc + 1 + it % rest;
+                    if (rr >= p2) panel[rr * PBS + p2] -= panel[rr * PBS + pc] * panel[p2 * PBS + pc];
+                }
+                __syncthreads();
+            }
+            for (int it = tid; it < nrows * pb; it += NT) {
+                const int rr = it / pb, pc = it - rr * pb;
+                if (pc <= rr) A[(long long)(j0 + rr) * nn + j0 + pc] = panel[rr * PBS + pc];
+            }
+            // trailing update: rows i >= j0 + pb, columns j0 + pb <= c <= i
+            const int t0 = j0 + pb, wv = tid >> 6, lane = tid & 63;
+            for (int ib = t0 + 4 * wv; ib < nn; ib += 16) {
+                for (int cb = t0 + lane; cb <= min(ib + 3, nn - 1); cb += 64) {
+                    double v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int i = ib + u; v[u] = (i < nn && cb <= i) ? A[(long long)i * nn + cb] : 0.0; }
+                    const double *pcv = panel + (cb - j0) * PBS;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int i = ib + u;
+                        if (i < nn && cb <= i) {
+                            const double *piv = panel + (i - j0) * PBS;
+                            double acc = v[u];
+                            for (int pc = 0; pc < pb; pc++) acc -= piv[pc] * pcv[pc];
+                            A[(long long)i * nn + cb] = acc;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return okc;
+    };
+    // out = -(L L^T)^-1 rhs by ONE wavefront without barriers: the running vector lives in LDS, a row of L is one
+    // coalesced read (the next row is fetched while the current one is reduced); forward by rows (dot products, wave
+    // reduction), backward right-looking (x_i, then y_t -= L[i][t] x_i over the row).
+    auto solve_rows = [&](const double *Lc, int nn, const double *rhs, double *out) {
+        if (tid < 64) {
+            const int lane = tid;
+            constexpr int CH = 4;                       // columns [0, 256) of a row travel in registers
+            double cur[CH], nxt[CH];
+            auto fetch = [&](int i, double *dst) {
+                const double *row = Lc + (long long)i * nn;
+#pragma unroll
+                for (int c = 0; c < CH; c++) { const int t = lane + 64 * c; dst[c] = (t <= i && t < nn) ? row[t] : 0.0; }
+            };
+            fetch(0, cur);
+            for (int i = 0; i < nn; i++) {
+                if (i + 1 < nn) fetch(i + 1, nxt);
+                const double *row = Lc + (long long)i * nn;
+                double sacc = 0;
+#pragma unroll
+                for (int c = 0; c < CH; c++) { const int t = lane + 64 * c; if (t < i) sacc += cur[c] * colbuf[t]; }
+                for (int t = 64 * CH + lane; t < i; t += 64) sacc += row[t] * colbuf[t];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+                const int owner = i & 63, slot = i >> 6;
+                double dii = (slot < CH) ? 0.0 : row[i];
+#pragma unroll
+                for (int c = 0; c < CH; c++) if (slot == c) dii = __shfl(cur[c], owner, 64);
+                if (lane == 0) colbuf[i] = (-rhs[i] - sacc) / dii;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int c = 0; c < CH; c++) cur[c] = nxt[c];
+            }
+            fetch(nn - 1, cur);
+            for (int i = nn - 1; i >= 0; i--) {
+                if (i > 0) fetch(i - 1, nxt);
+                const double *row = Lc + (long long)i * nn;
+                const int owner = i & 63, slot = i >> 6;
+                double dii = (slot < CH) ? 0.0 : row[i];
+#pragma unroll
+                for (int c = 0; c < CH; c++) if (slot == c) dii = __shfl(cur[c], owner, 64);
+                const double xi = colbuf[i] / dii;
+#pragma unroll
+                for (int c = 0; c < CH; c++) { const int t = lane + 64 * c; if (t < i) colbuf[t] -= cur[c] * xi; }
+                for (int t = 64 * CH + lane; t < i; t += 64) colbuf[t] -= row[t] * xi;
+                if (lane == 0) colbuf[i] = xi;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int c = 0; c < CH; c++) cur[c] = nxt[c];
+            }
+        }
+        __syncthreads();
+        for (int it = tid; it < nn; it += NT) out[it] = colbuf[it];
+        __syncthreads();
+    };
     // PQNOptimizer::optimize with useHessian (src/pqn/pqn_optimizer.cpp:29-126)
     int newton_steps = 0;
+#ifdef SPG_IP_PROF
+    long long ipt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ipt_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
     auto optimize = [&](double tol) {
         double f = value(x);
         gradient(x, g);
         for (;;) {
+            IPT(0);
             hessian();
-            if (tid == 0) flag_s = 0;
-            __syncthreads();
-            chol_lower<NT>(T, Hx, nx, nx);
-            const bool hok = flag_s == 0;
-            __syncthreads();
-            if (!hok) { if (tid == 0) flag_s = 0; __syncthreads(); return; }
-            // d = -(L L^T)^-1 g: forward then backward substitution, one column => serial in i, parallel over the dot products
-            for (int it = tid; it < nx; it += NT) dv[it] = -g[it];
-            __syncthreads();
-            for (int i = 0; i < nx; i++) {
-                double s = 0;
-                for (int t = tid; t < i; t += NT) s += Hx[(long long)i * nx + t] * dv[t];
-                s = T.sum(s);
-                if (tid == 0) dv[i] = (dv[i] - s) / Hx[(long long)i * nx + i];
-                __syncthreads();
-            }
-            for (int i = nx - 1; i >= 0; i--) {
-                double s = 0;
-                for (int t = i + 1 + tid; t < nx; t += NT) s += Hx[(long long)t * nx + i] * dv[t];
-                s = T.sum(s);
-                if (tid == 0) dv[i] = (dv[i] - s) / Hx[(long long)i * nx + i];
-                __syncthreads();
-            }
+            IPT(1);
+            const bool hok = chol_rows(Hx, nx);
+            IPT(2);
+            if (!hok) return;
+            solve_rows(Hx, nx, g, dv);     // d = -(L L^T)^-1 g
+            IPT(3);
             double gd = 0, da = 0;
             for (int it = tid; it < nx; it += NT) { gd += g[it] * dv[it]; da += fabs(dv[it]); }
             gd = T.sum(gd); da = T.sum(da);
@@ -576,10 +697,13 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             for (;;) {
                 for (int it = tid; it < nx; it += NT) xn[it] = x[it] + step * dv[it];
                 __syncthreads();
+                IPT(0);
                 f_new = value(xn);
+                IPT(4);
                 if (step < 1e-12) return;                       // line search failed: x stays
                 if (!isfinite(f_new) || f_new > f) { step /= 2; continue; }
                 gradient(xn, gn);
+                IPT(5);
                 break;
             }
             double oc = 0;
@@ -605,6 +729,9 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             optimize(tol);
         }
     }
+#ifdef SPG_IP_PROF
+    if (tid == 0 && blockIdx.x == 0) printf("ip prof k=%d E=%d nx=%d steps=%d: other %lld hessian %lld chol %lld solve %lld value %lld gradient %lld (x100MHz ticks)\n", k, E, nx, newton_steps, ipt[0], ipt[1], ipt[2], ipt[3], ipt[4], ipt[5]);
+#endif
     bool okf = false;
     const double fin = base_value(x, okf);
     if (!okf || !isfinite(fin)) { status = SPG_ST_KLD_NOT_PD; finish(); return; }    // the reference exit(0)s here
@@ -628,13 +755,23 @@ namespace spg {
 
 int nfr_ip_pattern_size(int topology, double chord_ratio, int k) { return ip_pattern_size(topology, chord_ratio, k); }
 
-int64_t nfr_ip_workspace(int D, int k, int m, int E) { return ip_layout(D, k, m, E > 0 ? E : 1).total; }
+int64_t nfr_ip_workspace(int D, int k, int m, int E, int64_t *hot) {
+    const IpLayout L = ip_layout(D, k, m, E > 0 ? E : 1);
+    if (hot) *hot = L.hot_total;
+    return L.total;
+}
 
-int hip_nfr_ip_launch(void *stream, int D, const IpArgs &a, int count) {
+int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int64_t hot_max) {
     if (count <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (D == 6) hipLaunchKernelGGL((nfr_ip_kernel<6>), dim3(count), dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((nfr_ip_kernel<3>), dim3(count), dim3(NT), 0, s, a);
+    // dynamic LDS for the hot buffers of the largest blanket that fits next to the 84 KB of static LDS (panel, solve vector)
+    const size_t lds = (size_t)std::min<int64_t>(hot_max * 8, 72 * 1024);
+    a.lds_doubles = (int)(lds / 8);
+    const void *fn = D == 6 ? reinterpret_cast<const void *>(nfr_ip_kernel<6>) : reinterpret_cast<const void *>(nfr_ip_kernel<3>);
+    if (lds > 40 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); a.lds_doubles = 0; }
+    const size_t use = a.lds_doubles ? lds : 0;
+    if (D == 6) hipLaunchKernelGGL((nfr_ip_kernel<6>), dim3(count), dim3(NT), use, s, a);
+    else hipLaunchKernelGGL((nfr_ip_kernel<3>), dim3(count), dim3(NT), use, s, a);
     return hipGetLastError() == hipSuccess ? 0 : SPG_EHIP;
 }
 
