@@ -170,3 +170,28 @@ def test_marginalize_with_optimize_and_kld_at_20k(hip_ctx):
     assert t["solver"] == abi.SOLVER_SPARSE and np.isfinite(kld) and kld > 0
     print(f"20k lattice: optimize {st['iterations']} it / {st['trials']} solves in {st['device_seconds']:.2f} s; "
           f"KLD {kld:.6g} in {t['device_seconds']:.2f} s ({t['front_bytes'] / 1e9:.1f} GB of fronts, {t['factor_flops'] / 1e12:.2f} TFLOP)")
+
+
+def test_global_kld_at_headline_size(hip_ctx):
+    """BASELINE config 5 (100 000 SE3 poses, 49 998 removals): baseline.kullbackLeibler(sparsified) — 300 006 kept
+    variables, where the reference's dense marginal would take 720 GB — through the block-sparse path, checked through
+    properties: a graph against itself gives 0 (300 k-variable selected inverse), the sparsified graph's KLD is finite
+    and positive, estimates unchanged => no Mahalanobis term, the trace term stays near n (it is exactly n for a
+    single tree blanket), and the per-term identity kld = (innerprod + mahalanobis - logdetx - logdety - n) / 2."""
+    g = g2o_io.synth_sphere(100000, 400)
+    which = np.array([i for i in range(4, 100000) if i % 2], np.int32)
+    base = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+    sp = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+    st = sp.marginalizeNoOptimize(which, abi.make_options(6))
+    assert st["n_bad_status"] == 0 and st["n_removed"] == len(which)
+    kld = base.kullbackLeibler(sp)
+    t = dict(base.last_kld_terms)
+    assert t["solver"] == abi.SOLVER_SPARSE and t["n"] == 6 * (100000 - len(which) - 1) and t["n_marginalized"] == 6 * len(which)
+    assert np.isfinite(kld) and kld > 0 and abs(t["mahalanobis"]) <= 1e-12
+    assert kld == pytest.approx(0.5 * (t["innerprod"] + t["mahalanobis"] - t["logdetx"] - t["logdety"] - t["n"]), rel=1e-12)
+    assert abs(t["innerprod"] / t["n"] - 1) < 0.5
+    kself = sp.kullbackLeibler(sp)
+    ts = sp.last_kld_terms
+    assert ts["solver"] == abi.SOLVER_SPARSE and abs(kself) <= 1e-9 * ts["n"] and abs(ts["innerprod"] - ts["n"]) <= 1e-9 * ts["n"]
+    print(f"100k poses: global KLD {kld:.6g} (per-blanket sum {st['kld_sum']:.6g}) in {t['device_seconds']:.2f} s, {t['front_bytes'] / 1e9:.1f} GB of fronts, "
+          f"{t['factor_flops'] / 1e12:.2f} TFLOP; self-KLD {kself:.2e} in {ts['device_seconds']:.2f} s")
