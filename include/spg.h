@@ -30,7 +30,14 @@ enum { SPG_TOPO_TREE = 0, SPG_TOPO_SUBGRAPH = 1, SPG_TOPO_CLIQUEY_SUBGRAPH = 2, 
 enum { SPG_LIN_LOCAL = 0, SPG_LIN_GLOBAL = 1 };
 /* edge kinds: pose-pose edge (EdgeSE2ISAM / EdgeSE3ISAM, src/se2_compatibility.h:20, src/se3_compatibility.h:25)
  * and n-ary GLC edge (GLCEdge, src/glc_edge.h:14) */
-enum { SPG_EDGE_BINARY = 0, SPG_EDGE_GLC = 1 };
+enum { SPG_EDGE_BINARY = 0, SPG_EDGE_GLC = 1, SPG_EDGE_MULTI = 2 };
+/* SPG_EDGE_MULTI = MultiEdgeCorrelated<EdgeSE2 | EdgeSE3> (src/multi_edge_correlated.hpp:28-140): nm pose-pose measurements
+ * between pairs of the edge's q vertices with ONE joint information matrix Omega (d nm x d nm), what the CliqueySubgraph /
+ * CliqueyDense patterns emit (src/topology_provider_binary.hpp:48-67). Record (doubles):
+ *   [0] nm | [1 + 2 i], [2 + 2 i]: the two vertices of measurement i as indices into the edge's vertex list |
+ *   nm measurements (3 | 7 each) | W (r x r row-major, r = d nm) with Omega = W^T W.
+ * The error is the stack of the pose-pose errors; chi2 = || W e ||^2. */
+#define SPG_MULTI_LEN(d, nm) (1 + 2 * (nm) + (nm) * ((d) == 3 ? 3 : 7) + (int64_t)(d) * (nm) * (d) * (nm))
 
 /* per-blanket status (replaces the reference's assert / exit(0) / NULL-edge failure modes,
  * src/vertex_remover.cpp:291,461, src/optimizer.cpp:75-77, src/topology_provider_glc.cpp:46-49,85-89) */
@@ -207,6 +214,9 @@ int spg_graph_add_vertices(spg_graph *g, int n, const int32_t *ids, const double
 int spg_graph_add_edges(spg_graph *g, int n, const int32_t *ij, const double *records);
 /* n-ary GLC edge (GLCEdge::read, src/glc_edge.cpp:64-93) */
 int spg_graph_add_glc_edge(spg_graph *g, int q, const int32_t *ids, int r, const double *meas, const double *W);
+/* MultiEdgeCorrelated over q vertices (src/multi_edge_correlated.hpp:28-63): `record` in the SPG_EDGE_MULTI layout above,
+ * len = SPG_MULTI_LEN(pose_dim, nm). */
+int spg_graph_add_multi_edge(spg_graph *g, int q, const int32_t *ids, const double *record, int64_t len);
 int spg_graph_pose_dim(const spg_graph *g);
 int spg_graph_num_vertices(const spg_graph *g);
 int spg_graph_num_edges(const spg_graph *g);

@@ -129,6 +129,39 @@ inline Mat glc_weighted_jacobian(int d, int q, const double *const *poses, const
     return matmul(W, Jr);
 }
 
+// MultiEdgeCorrelated (src/multi_edge_correlated.hpp:65-140): stacked pose-pose errors of nm measurements between pairs
+// of the edge's q vertices, Jacobian (d nm x d q) with two d x d blocks per measurement row block, W from the record
+// (include/spg.h, SPG_EDGE_MULTI). Returns A = W J; *werr = W e.
+inline Mat multi_weighted_jacobian(int d, int q, const double *const *poses, const double *data, std::vector<double> *werr) {
+    const int ps = pose_stride(d), nm = (int)data[0], r = d * nm;
+    const double *meas = data + 1 + 2 * nm, *Wd = meas + (size_t)nm * ps;
+    Mat J(r, d * q);
+    std::vector<double> err((size_t)r, 0.0);
+    for (int i = 0; i < nm; i++) {
+        const int a = (int)data[1 + 2 * i], b = (int)data[2 + 2 * i];
+        Mat Ja, Jb;
+        binary_edge_jac(d, poses[a], poses[b], meas + (size_t)i * ps, Ja, Jb, err.data() + (size_t)i * d);
+        for (int x = 0; x < d; x++) for (int y = 0; y < d; y++) { J(i * d + x, a * d + y) += Ja(x, y); J(i * d + x, b * d + y) += Jb(x, y); }
+    }
+    Mat W(r, r);
+    for (int i = 0; i < r; i++) for (int j = 0; j < r; j++) W(i, j) = Wd[(size_t)i * r + j];
+    if (werr) { werr->assign((size_t)r, 0.0); for (int i = 0; i < r; i++) for (int j = 0; j < r; j++) (*werr)[i] += W(i, j) * err[j]; }
+    return matmul(W, J);
+}
+
+// weighted Jacobian of any n-ary edge kind
+inline Mat nary_weighted_jacobian(int kind, int d, int q, const double *const *poses, const double *data, int64_t len, std::vector<double> *werr) {
+    if (kind == SPG_EDGE_MULTI) return multi_weighted_jacobian(d, q, poses, data, werr);
+    int n = d * q, r = (int)((len - n) / n);
+    std::vector<double> rerr;
+    Mat Jr;
+    glc_reparam(d, q, poses, data, werr ? &rerr : nullptr, &Jr);
+    Mat W(r, n);
+    for (int i = 0; i < r; i++) for (int j = 0; j < n; j++) W(i, j) = data[n + (int64_t)i * n + j];
+    if (werr) { werr->assign((size_t)r, 0.0); for (int i = 0; i < r; i++) for (int j = 0; j < n; j++) (*werr)[i] += W(i, j) * rerr[j]; }
+    return matmul(W, Jr);
+}
+
 // a6 + a14: H = sum_e J_e^T Omega_e J_e over the blanket edges, order [removed..., kept asc].
 inline Mat assemble_hessian(const BlanketIn &in) {
     int d = in.d, ps = pose_stride(d), N = in.nv * d;
@@ -153,7 +186,7 @@ inline Mat assemble_hessian(const BlanketIn &in) {
             int q = (int)e.v.size();
             std::vector<const double *> poses(q);
             for (int i = 0; i < q; i++) poses[i] = in.pose + (size_t)e.v[i] * ps;
-            Mat A = glc_weighted_jacobian(d, q, poses.data(), e.data, e.len);  // r x dq, information = I
+            Mat A = nary_weighted_jacobian(e.kind, d, q, poses.data(), e.data, e.len, nullptr);  // r x dq, information = I
             Mat AtA = matmul(transpose(A), A);
             for (int a = 0; a < q; a++) for (int b = 0; b < q; b++)
                 for (int r = 0; r < d; r++) for (int c = 0; c < d; c++)
@@ -641,26 +674,65 @@ inline bool interior_point(const JacMapping &mapping, const Spectrum &sp, int n,
     return true;
 }
 
-// PseudoChowLiu::computeSparsityPattern (src/pseudo_chow_liu.cpp:33-87) for the uncorrelated
-// topologies. Returns kept-local pairs. needs_ip is set when the pattern is not a spanning tree.
-inline bool sparsity_pattern(const spg_options &o, const Mat &target, int d, int k,
-                             std::vector<std::pair<int, int>> &pairs, BlanketOut &out) {
-    pairs.clear();
+typedef std::vector<std::vector<std::pair<int, int>>> Pattern;   // SparsityPattern: one skeleton tree per new edge
+
+// PseudoChowLiu::fillCliques (src/pseudo_chow_liu.cpp:198-251): the tree edges are merged into cliques while the number
+// of pairwise edges the cliques stand for stays within m; every clique becomes one correlated edge over its tree edges.
+inline void fill_cliques(const std::vector<std::pair<int, int>> &bin, int k, int m, Pattern &pattern) {
+    std::vector<std::set<int>> cliques;
+    for (int i = 0; i < k - 1; i++) cliques.push_back({bin[i].first, bin[i].second});
+    bool joined = true;
+    for (int nedges = k - 1, maxfill = 1; nedges < m && joined; maxfill++) {
+        joined = false;
+        int minfill = std::numeric_limits<int>::max();
+        for (size_t i = 0; i < cliques.size(); i++)
+            for (size_t j = i + 1; j < cliques.size(); j++) {
+                bool meet = false;
+                for (int v : cliques[j]) if (cliques[i].count(v)) { meet = true; break; }
+                if (!meet) continue;
+                int thisfill = ((int)cliques[i].size() - 1) * ((int)cliques[j].size() - 1);
+                minfill = std::min(thisfill, minfill);
+                if (thisfill <= maxfill && nedges + thisfill <= m) {
+                    cliques[i].insert(cliques[j].begin(), cliques[j].end());
+                    nedges += thisfill;
+                    cliques.erase(cliques.begin() + (long)j);
+                    joined = true;
+                    j--;
+                }
+            }
+        if (!joined && minfill > maxfill) { joined = true; maxfill = minfill - 1; }
+    }
+    pattern.assign(cliques.size(), {});
+    for (int i = 0; i < k - 1; i++)
+        for (size_t j = 0; j < cliques.size(); j++)
+            if (cliques[j].count(bin[i].first) && cliques[j].count(bin[i].second)) pattern[j].push_back(bin[i]);
+}
+
+// PseudoChowLiu::computeSparsityPattern (src/pseudo_chow_liu.cpp:33-87). Kept-local pairs; an entry with more than one
+// pair is a MultiEdgeCorrelated over those measurements.
+inline bool sparsity_pattern(const spg_options &o, const Mat &target, int d, int k, Pattern &pattern, BlanketOut &out) {
+    pattern.clear();
     int m = int((1 + o.chord_ratio) * (k - 1));
     bool full = (m >= k * (k - 1) / 2);
     if (k == 2) {
-        pairs.push_back({0, 1});
+        pattern.push_back({{0, 1}});
     } else if (o.topology == SPG_TOPO_DENSE || (o.topology == SPG_TOPO_SUBGRAPH && full)) {
-        for (int i = 0; i < k - 1; i++) for (int j = i + 1; j < k; j++) pairs.push_back({i, j});
-    } else if (o.topology == SPG_TOPO_TREE || o.topology == SPG_TOPO_SUBGRAPH) {
+        for (int i = 0; i < k - 1; i++) for (int j = i + 1; j < k; j++) pattern.push_back({{i, j}});
+    } else {
         ChowLiu cl = chow_liu(target, d, k);
         if (!cl.ok) { out.status = SPG_ST_TIKHONOV_NOT_PD; return false; }
         out.min_gap = cl.min_gap;
-        int ne = (o.topology == SPG_TOPO_TREE) ? k - 1 : m;
-        for (int i = 0; i < ne; i++) pairs.push_back(cl.bin[i]);
-    } else {
-        out.status = SPG_ST_UNSUPPORTED;  // correlated (Cliquey*) patterns: MultiEdgeCorrelated, out of scope
-        return false;
+        if (o.topology == SPG_TOPO_TREE || o.topology == SPG_TOPO_SUBGRAPH) {
+            int ne = (o.topology == SPG_TOPO_TREE) ? k - 1 : m;
+            for (int i = 0; i < ne; i++) pattern.push_back({cl.bin[i]});
+        } else if (o.topology == SPG_TOPO_CLIQUEY_DENSE || (o.topology == SPG_TOPO_CLIQUEY_SUBGRAPH && full)) {
+            pattern.push_back(std::vector<std::pair<int, int>>(cl.bin.begin(), cl.bin.begin() + (k - 1)));
+        } else if (o.topology == SPG_TOPO_CLIQUEY_SUBGRAPH) {
+            fill_cliques(cl.bin, k, m, pattern);
+        } else {
+            out.status = SPG_ST_UNSUPPORTED;
+            return false;
+        }
     }
     return true;
 }
@@ -668,31 +740,62 @@ inline bool sparsity_pattern(const spg_options &o, const Mat &target, int d, int
 inline void run_nfr(const spg_options &o, const BlanketIn &in, BlanketOut &out) {
     int d = in.d, ps = pose_stride(d), k = in.nv - in.m, n = d * k;
     if (k < 2) return;  // src/topology_provider_binary.hpp:28
-    std::vector<std::pair<int, int>> pairs;
-    if (!sparsity_pattern(o, out.target, d, k, pairs, out)) return;
+    Pattern pattern;
+    if (!sparsity_pattern(o, out.target, d, k, pattern, out)) return;
     // hasClosedFormSolution (src/logdet_function.cpp:83-86): sum of edge dims == rank (n - d)
-    const bool has_closed_form = (int)pairs.size() * d == n - d;
+    int jacsize = 0;
+    for (auto &tree : pattern) jacsize += d * (int)tree.size();
+    const bool has_closed_form = jacsize == n - d;
     JacMapping mapping;
     std::vector<NewEdge> edges;
-    for (auto &pr : pairs) {
-        int a = in.m + pr.first, b = in.m + pr.second;
-        const double *xa = in.pose + (size_t)a * ps, *xb = in.pose + (size_t)b * ps;
+    for (auto &tree : pattern) {
+        const int nm = (int)tree.size();
         NewEdge ne;
-        ne.kind = SPG_EDGE_BINARY;
-        ne.v = {a, b};
-        ne.data.assign(ps + info_len(d), 0.0);
-        Mat Ja, Jb;
-        if (d == 3) {
-            se2_between(xa, xb, ne.data.data());  // setMeasurementFromState
-            binary_edge_jac(3, xa, xb, ne.data.data(), Ja, Jb);
-        } else {
-            Iso3 Xa = iso_from_tq(xa), Xb = iso_from_tq(xb);
-            Iso3 Z = iso_mul(iso_inv(Xa), Xb);
-            iso_to_tq(Z, ne.data.data());
-            Ja = Mat(6, 6); Jb = Mat(6, 6);
-            se3_edge(Xa, Xb, Z, nullptr, Ja.a.data(), Jb.a.data());
+        std::vector<int> lv;      // the edge's vertices (kept-local) in order of first appearance (addMeasurement, :28-63)
+        std::vector<std::pair<int, int>> idx;
+        for (auto &pr : tree) {
+            int ia = -1, ib = -1;
+            for (size_t t = 0; t < lv.size(); t++) { if (lv[t] == pr.first) ia = (int)t; }
+            if (ia < 0) { ia = (int)lv.size(); lv.push_back(pr.first); }
+            for (size_t t = 0; t < lv.size(); t++) { if (lv[t] == pr.second) ib = (int)t; }
+            if (ib < 0) { ib = (int)lv.size(); lv.push_back(pr.second); }
+            idx.push_back({ia, ib});
         }
-        mapping.push_back({{Ja, pr.first * d}, {Jb, pr.second * d}});
+        for (int v : lv) ne.v.push_back(in.m + v);
+        const int q = (int)lv.size(), r = d * nm;
+        std::vector<Mat> Jv((size_t)q, Mat(r, d));
+        std::vector<double> meas((size_t)nm * ps, 0.0);
+        for (int i = 0; i < nm; i++) {
+            int a = in.m + tree[i].first, b = in.m + tree[i].second;
+            const double *xa = in.pose + (size_t)a * ps, *xb = in.pose + (size_t)b * ps;
+            double *z = meas.data() + (size_t)i * ps;
+            Mat Ja, Jb;
+            if (d == 3) {
+                se2_between(xa, xb, z);  // setMeasurementFromState
+                binary_edge_jac(3, xa, xb, z, Ja, Jb);
+            } else {
+                Iso3 Xa = iso_from_tq(xa), Xb = iso_from_tq(xb);
+                Iso3 Z = iso_mul(iso_inv(Xa), Xb);
+                iso_to_tq(Z, z);
+                Ja = Mat(6, 6); Jb = Mat(6, 6);
+                se3_edge(Xa, Xb, Z, nullptr, Ja.a.data(), Jb.a.data());
+            }
+            for (int x = 0; x < d; x++) for (int y = 0; y < d; y++) { Jv[idx[i].first](i * d + x, y) += Ja(x, y); Jv[idx[i].second](i * d + x, y) += Jb(x, y); }
+        }
+        MeasJac mj;
+        for (int t = 0; t < q; t++) mj.push_back({Jv[t], lv[t] * d});
+        mapping.push_back(mj);
+        if (nm == 1) {
+            ne.kind = SPG_EDGE_BINARY;
+            ne.data.assign(ps + info_len(d), 0.0);
+            for (int a = 0; a < ps; a++) ne.data[a] = meas[a];
+        } else {
+            ne.kind = SPG_EDGE_MULTI;
+            ne.data.assign((size_t)SPG_MULTI_LEN(d, nm), 0.0);
+            ne.data[0] = nm;
+            for (int i = 0; i < nm; i++) { ne.data[1 + 2 * i] = idx[i].first; ne.data[2 + 2 * i] = idx[i].second; }
+            for (size_t a = 0; a < meas.size(); a++) ne.data[1 + 2 * nm + a] = meas[a];
+        }
         edges.push_back(ne);
     }
     Spectrum sp;
@@ -701,14 +804,25 @@ inline void run_nfr(const spg_options &o, const BlanketIn &in, BlanketOut &out) 
     if (has_closed_form) {
         if (!closed_form(mapping, sp, X)) { out.status = SPG_ST_CLOSED_FORM_NOT_PD; return; }
     } else {
+        for (auto &tree : pattern) if (tree.size() != 1) { out.status = SPG_ST_UNSUPPORTED; return; }
         double fin = 0;
         long iters = 0;
         if (!interior_point(mapping, sp, n, X, fin, iters)) { out.status = SPG_ST_KLD_NOT_PD; return; }   // the reference exit(0)s here
         out.info |= (int)std::min<long>(iters, 32767) << 8;   // Newton steps taken (diagnostic, bits 8..)
     }
     for (size_t e = 0; e < edges.size(); e++) {
-        int p = ps;
-        for (int i = 0; i < d; i++) for (int j = i; j < d; j++) edges[e].data[p++] = X[e](i, j);
+        if (edges[e].kind == SPG_EDGE_BINARY) {
+            int p = ps;
+            for (int i = 0; i < d; i++) for (int j = i; j < d; j++) edges[e].data[p++] = X[e](i, j);
+        } else {
+            // information X = W^T W with W = chol(X)^T (any factor does: consumers use W^T W)
+            const int nm = (int)edges[e].data[0], r = d * nm;
+            Mat L = X[e];
+            for (int i = 0; i < r; i++) for (int j = i + 1; j < r; j++) { double v = 0.5 * (L(i, j) + L(j, i)); L(i, j) = v; L(j, i) = v; }
+            if (!chol_lower(L)) { out.status = SPG_ST_CLOSED_FORM_NOT_PD; return; }
+            double *W = edges[e].data.data() + 1 + 2 * nm + (size_t)nm * ps;
+            for (int i = 0; i < r; i++) for (int j = 0; j < r; j++) W[(size_t)i * r + j] = (j >= i) ? L(j, i) : 0.0;
+        }
     }
     out.edges = edges;
     out.kld = kld_value(information_product(mapping, X, n), sp);
@@ -734,7 +848,11 @@ inline void run_glc(const spg_options &o, const BlanketIn &in, BlanketOut &out) 
         if (st != SPG_OK) out.status = st;
     } else {
         std::vector<std::pair<int, int>> pairs;
-        if (!sparsity_pattern(o, out.target, d, k, pairs, out)) return;
+        {
+            Pattern pat;
+            if (!sparsity_pattern(o, out.target, d, k, pat, out)) return;
+            for (auto &tree : pat) pairs.push_back(tree.front());
+        }
         // root unary edge from the marginal of the first vertex of the first tree edge
         {
             int root = pairs.front().first;
@@ -782,7 +900,7 @@ inline void run_glc(const spg_options &o, const BlanketIn &in, BlanketOut &out) 
             int q = (int)e.v.size();
             std::vector<const double *> poses(q);
             for (int i = 0; i < q; i++) poses[i] = in.pose + (size_t)e.v[i] * ps;
-            Mat Aw = glc_weighted_jacobian(d, q, poses.data(), e.data.data(), (int64_t)e.data.size());
+            Mat Aw = nary_weighted_jacobian(e.kind, d, q, poses.data(), e.data.data(), (int64_t)e.data.size(), nullptr);
             Mat AtA = matmul(transpose(Aw), Aw);
             for (int a = 0; a < q; a++) for (int b = 0; b < q; b++)
                 for (int r = 0; r < d; r++) for (int c = 0; c < d; c++)
@@ -853,8 +971,8 @@ inline BlanketOut run_blanket(const spg_options &o, const BlanketIn &in) {
 
 inline BlanketOut run_blanket_at(const spg_options &o, const BlanketIn &in) {
     BlanketOut out;
-    if (o.algorithm == SPG_ALG_NFR)  // binary providers reject GLC edges (src/topology_provider_base.h:23-27)
-        for (const EdgeIn &e : in.edges) if (e.kind != SPG_EDGE_BINARY) { out.status = SPG_ST_UNSUPPORTED; return out; }
+    if (o.algorithm == SPG_ALG_NFR)  // binary providers take pose-pose and correlated multi edges, not GLC edges (src/topology_provider_binary.hpp:16-21)
+        for (const EdgeIn &e : in.edges) if (e.kind == SPG_EDGE_GLC) { out.status = SPG_ST_UNSUPPORTED; return out; }
     Mat H = assemble_hessian(in);
     if (!schur_target(H, in.m * in.d, out.target)) { out.status = SPG_ST_HMM_NOT_PD; return out; }
     for (double v : out.target.a) if (!std::isfinite(v)) { out.status = SPG_ST_NONFINITE; return out; }

@@ -503,15 +503,9 @@ LinSys build_system(RGraph *g, const std::set<int> &fixed, bool want_H) {
         } else {
             std::vector<const double *> poses(q);
             for (int i = 0; i < q; i++) poses[i] = g->pose[e.ids[i]].data();
-            int nq = d * q, rdim = (int)((e.data.size() - nq) / nq);
-            std::vector<double> rerr;
-            Mat Jr;
-            glc_reparam(d, q, poses.data(), e.data.data(), &rerr, &Jr);
-            Mat W(rdim, nq);
-            for (int i = 0; i < rdim; i++) for (int j = 0; j < nq; j++) W(i, j) = e.data[nq + (size_t)i * nq + j];
-            Mat Aw = matmul(W, Jr);
-            std::vector<double> wr(rdim, 0.0);
-            for (int i = 0; i < rdim; i++) for (int j = 0; j < nq; j++) wr[i] += W(i, j) * rerr[j];
+            std::vector<double> wr;
+            Mat Aw = nary_weighted_jacobian(e.kind, d, q, poses.data(), e.data.data(), (int64_t)e.data.size(), &wr);   // GLC or MULTI
+            const int rdim = Aw.r;
             for (int i = 0; i < rdim; i++) S.chi2 += wr[i] * wr[i];
             for (int a = 0; a < q; a++) {
                 auto ia = loc.find(e.ids[a]);

@@ -12,7 +12,7 @@ import numpy as np
 ALG_NFR, ALG_GLC = 0, 1
 TOPO_TREE, TOPO_SUBGRAPH, TOPO_CLIQUEY_SUBGRAPH, TOPO_DENSE, TOPO_CLIQUEY_DENSE = range(5)
 LIN_LOCAL, LIN_GLOBAL = 0, 1
-EDGE_BINARY, EDGE_GLC = 0, 1
+EDGE_BINARY, EDGE_GLC, EDGE_MULTI = 0, 1, 2
 ST_OK, ST_HMM_NOT_PD, ST_EIG_FAIL, ST_NONFINITE, ST_TIKHONOV_NOT_PD, ST_CLOSED_FORM_NOT_PD, \
     ST_KLD_NOT_PD, ST_NEEDS_INTERIOR_POINT, ST_MARGINAL_NOT_PD, ST_EMPTY_BLANKET, ST_UNSUPPORTED, \
     ST_NEEDS_LOCAL_OPTIMIZATION = range(12)
@@ -177,7 +177,12 @@ def batch_capacities(b, opts):
         ne = int(np.maximum(k - 1, 0).sum())
         if opts.topology in (TOPO_DENSE, TOPO_SUBGRAPH):
             ne = int((k * (k - 1) // 2).sum())
-        return ne, 2 * ne, ne * binary_record_len(d)
+        nd = ne * binary_record_len(d)
+        if opts.topology in (TOPO_CLIQUEY_SUBGRAPH, TOPO_CLIQUEY_DENSE):
+            # correlated edges (SPG_EDGE_MULTI): at most k - 1 measurements in all, one record may hold all of them
+            nm = np.maximum(k - 1, 0)
+            nd += int((1 + 2 * nm + nm * pose_stride(d) + (d * nm) ** 2).sum())
+        return ne, 2 * ne, nd
     if opts.topology == TOPO_DENSE:
         n = d * k
         return int((k > 0).sum()), int(k.sum()), int((n + n * n).sum())

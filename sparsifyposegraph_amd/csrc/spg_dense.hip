@@ -327,6 +327,13 @@ __device__ __forceinline__ void load_pose(const double *arena, int64_t off, doub
     else { X[0] = arena[off]; X[1] = arena[off + 1]; X[2] = arena[off + 2]; }
 }
 
+// rows of the weighted Jacobian A_e of an n-ary edge: GLC (W is r x dq after the dq measurement doubles) or MULTI (r = d nm)
+__device__ __forceinline__ int nary_rows(const spg_edge_ref &er, const double *arena, int D) {
+    if (er.kind == SPG_EDGE_MULTI) return D * (int)arena[er.off];
+    const int dq = D * er.nv;
+    return (er.len - dq) / dq;
+}
+
 // A_e = W_e * J_reparam (r x dq) of every GLC edge (src/glc_edge.cpp:40-49,
 // src/glc_reparam_binary.hpp:78-127): one workgroup per edge, result in g.aw.
 template <int D>
@@ -335,10 +342,49 @@ __global__ __launch_bounds__(64) void glc_weighted_jacobian_kernel(GraphDev g) {
     extern __shared__ double Jb[];   // q x (Ji0 | Jii), then q x D reparametrisation errors
     const int e = blockIdx.x, tid = threadIdx.x;
     const spg_edge_ref er = g.er[e];
-    if (er.kind != SPG_EDGE_GLC) return;
-    const int q = er.nv, dq = D * q, rr = (er.len - dq) / dq;
+    if (er.kind == SPG_EDGE_BINARY) return;
+    const int q = er.nv, dq = D * q, rr = nary_rows(er, g.arena, D);
     const double *rec = g.arena + er.off;
     double *Aw = g.aw + g.aw_off[e];
+    if (er.kind == SPG_EDGE_MULTI) {
+        // MultiEdgeCorrelated (src/multi_edge_correlated.hpp:65-140): stacked pose-pose errors, two Jacobian blocks per
+        // measurement, W from the record (include/spg.h): A = W J, weighted error W e
+        const int nm = (int)rec[0];
+        const double *meas = rec + 1 + 2 * nm, *Wd = meas + nm * ((D == 6) ? 7 : 3);
+        for (int i = tid; i < nm; i += 64) {
+            const int la = (int)rec[1 + 2 * i], lb = (int)rec[2 + 2 * i];
+            double Xa[PSZ], Xb[PSZ];
+            load_pose<D>(g.arena, g.vpo[g.ev[er.vbegin + la]], Xa);
+            load_pose<D>(g.arena, g.vpo[g.ev[er.vbegin + lb]], Xb);
+            double *er_i = Jb + q * 2 * DD + i * D;
+            if (D == 6) {
+                double Z[kIso];
+                iso_from_tq(meas + 7 * i, Z);
+                se3_edge_jac(Xa, Xb, Z, Jb + i * 2 * DD, Jb + i * 2 * DD + DD, er_i);
+            } else {
+                se2_edge_jac(Xa, Xb, meas + 3 * i, Jb + i * 2 * DD, Jb + i * 2 * DD + DD, er_i);
+            }
+        }
+        __syncthreads();
+        for (int row = tid; row < rr; row += 64) {
+            const double *Wr = Wd + (int64_t)row * rr, *ee = Jb + q * 2 * DD;
+            double s = 0;
+            for (int j = 0; j < rr; j++) s += Wr[j] * ee[j];
+            Aw[(int64_t)rr * dq + row] = s;
+        }
+        for (int it = tid; it < rr * dq; it += 64) {
+            const int row = it / dq, col = it - row * dq, blk = col / D, c = col - blk * D;
+            const double *Wr = Wd + (int64_t)row * rr;
+            double s = 0;
+            for (int i = 0; i < nm; i++) {
+                const int la = (int)rec[1 + 2 * i], lb = (int)rec[2 + 2 * i];
+                if (la == blk) for (int p = 0; p < D; p++) s += Wr[i * D + p] * Jb[i * 2 * DD + p * D + c];
+                if (lb == blk) for (int p = 0; p < D; p++) s += Wr[i * D + p] * Jb[i * 2 * DD + DD + p * D + c];
+            }
+            Aw[it] = s;
+        }
+        return;
+    }
     for (int i = tid; i < q; i += 64) {
         double X0[PSZ], Xi[PSZ];
         load_pose<D>(g.arena, g.vpo[g.ev[er.vbegin]], X0);
@@ -446,7 +492,7 @@ __global__ __launch_bounds__(64) void dense_assemble_kernel(GraphDev g, Sink sin
             }
             __syncthreads();
         } else {
-            const int q = er.nv, dq = D * q, rr = (er.len - dq) / dq;
+            const int q = er.nv, dq = D * q, rr = nary_rows(er, g.arena, D);
             const double *Aw = g.aw + g.aw_off[e];
             int iv = 0;
             for (int i = 0; i < q; i++) if (g.ev[er.vbegin + i] == v) iv = i;
@@ -497,7 +543,7 @@ __global__ void edge_chi2_kernel(GraphDev g, double *chi) {
 #pragma unroll
             for (int j = i; j < D; j++) { s += ((i == j) ? 1.0 : 2.0) * err[i] * rec[p] * err[j]; p++; }
     } else {
-        const int dq = D * er.nv, rr = (er.len - dq) / dq;
+        const int dq = D * er.nv, rr = nary_rows(er, g.arena, D);
         const double *wr = g.aw + g.aw_off[e] + (int64_t)rr * dq;
         for (int p = 0; p < rr; p++) s += wr[p] * wr[p];
     }
@@ -880,8 +926,21 @@ int stage_graph(const spg::DenseGraphIn &in, GraphBufs &gb, hipStream_t s) {
     std::vector<int64_t> awoff((size_t)in.ne, -1);
     int64_t aw_total = 0;
     for (int e = 0; e < in.ne; e++) {
-        if (in.er[e].kind != SPG_EDGE_GLC) continue;
+        if (in.er[e].kind == SPG_EDGE_BINARY) continue;
         int q = in.er[e].nv, dq = in.D * q;
+        if (in.er[e].kind == SPG_EDGE_MULTI) {
+            // r = d nm rows; nm = q - 1 for the patterns that emit such edges, never more than len allows
+            const int ps = in.D == 6 ? 7 : 3;
+            int nm = 1;
+            while (SPG_MULTI_LEN(in.D, nm) < in.er[e].len) nm++;
+            if (q < 2 || SPG_MULTI_LEN(in.D, nm) != in.er[e].len) return SPG_EINVAL;
+            (void)ps;
+            awoff[e] = aw_total;
+            aw_total += (int64_t)in.D * nm * dq + in.D * nm;
+            gb.max_q = std::max(gb.max_q, std::max(q, nm + 1));
+            gb.has_glc = true;
+            continue;
+        }
         if (q <= 0 || in.er[e].len < dq || (in.er[e].len - dq) % dq) return SPG_EINVAL;
         awoff[e] = aw_total;
         aw_total += (int64_t)(in.er[e].len - dq) + (in.er[e].len - dq) / dq;   // A_e (r x dq) + weighted error (r)

@@ -538,6 +538,22 @@ extern "C" int spg_graph_add_glc_edge(spg_graph *g, int q, const int32_t *ids, i
     return 0;
 }
 
+extern "C" int spg_graph_add_multi_edge(spg_graph *g, int q, const int32_t *ids, const double *record, int64_t len) {
+    if (!g || q < 2 || !ids || !record || g->active) return SPG_EINVAL;
+    const int nm = (int)record[0];
+    if (nm < 1 || len != SPG_MULTI_LEN(g->d, nm)) return set_err(g->ctx, SPG_EINVAL, "multi edge record length does not match its measurement count");
+    for (int i = 0; i < 2 * nm; i++) if (record[1 + i] < 0 || record[1 + i] >= q) return set_err(g->ctx, SPG_EINVAL, "multi edge: a measurement refers to a vertex outside the edge");
+    std::vector<int32_t> vix(q);
+    for (int i = 0; i < q; i++) {
+        auto it = g->vidx.find(ids[i]);
+        if (it == g->vidx.end() || !g->valive[it->second]) return set_err(g->ctx, SPG_EINVAL, "edge endpoint does not exist");
+        vix[i] = it->second;
+    }
+    int64_t off = arena_push(g, record, len);
+    add_edge_idx(g, SPG_EDGE_MULTI, q, vix.data(), off, (int32_t)len);
+    return 0;
+}
+
 // bulk forms of addVertex / addEdge (same semantics, one call per array)
 extern "C" int spg_graph_add_vertices(spg_graph *g, int n, const int32_t *ids, const double *poses) {
     if (!g || n < 0 || !ids || !poses) return SPG_EINVAL;
@@ -790,6 +806,21 @@ static void write_g2o_stream(spg_graph *g, FILE *f) {
         if (e.kind == SPG_EDGE_BINARY) {
             fprintf(f, "%s %d %d", et, g->vid[edge_verts(g, e)[0]], g->vid[edge_verts(g, e)[1]]);
             for (int i = 0; i < e.len; i++) fprintf(f, " %.17g", g->host[e.off + i]);
+        } else if (e.kind == SPG_EDGE_MULTI) {
+            // MultiEdgeCorrelated::write (src/multi_edge_correlated.hpp:227-267): "|| nmeas nrelevant meas... info(upper)". As in
+            // the reference the vertex pair of each measurement is NOT part of the line (its own reader cannot restore it).
+            const double *rec = g->host.data() + e.off;
+            const int nm = (int)rec[0], r = g->d * nm;
+            const double *meas = rec + 1 + 2 * nm, *W = meas + (size_t)nm * g->ps;
+            fprintf(f, "%s", g->d == 3 ? "MULTI_EDGE_SE2" : "MULTI_EDGE_SE3");
+            for (int i = 0; i < e.nv; i++) fprintf(f, " %d", g->vid[edge_verts(g, e)[i]]);
+            fprintf(f, " || %d %d", nm, g->ps);
+            for (int i = 0; i < nm * g->ps; i++) fprintf(f, " %.17g", meas[i]);
+            for (int i = 0; i < r; i++) for (int j = i; j < r; j++) {
+                double v = 0;
+                for (int t = 0; t < r; t++) v += W[(size_t)t * r + i] * W[(size_t)t * r + j];
+                fprintf(f, " %.17g", v);
+            }
         } else {
             // GLCEdge::write (src/glc_edge.cpp:95-119): "|| <reparam tag> r dq meas W info(upper of I_r)"
             int n = g->d * e.nv, r = (e.len - n) / n;
@@ -824,6 +855,7 @@ extern "C" int spg_graph_clone_portion(spg_graph *g, int maxid, spg_graph **out)
         if (!in) continue;
         const double *rec = g->host.data() + e.off;
         if (e.kind == SPG_EDGE_BINARY) rc = spg_graph_add_edge(c, ids[0], ids[1], rec, rec + g->ps);
+        else if (e.kind == SPG_EDGE_MULTI) rc = spg_graph_add_multi_edge(c, e.nv, ids.data(), rec, e.len);
         else { int n = g->d * e.nv; rc = spg_graph_add_glc_edge(c, e.nv, ids.data(), (e.len - n) / n, rec, rec + n); }
     }
     if (rc) { spg_graph_destroy(c); return rc; }
@@ -931,6 +963,8 @@ static void new_edge_budget(const spg_options &o, int d, int k, int32_t &n_new_m
         }
         n_new_vert_max = 2 * n_new_max;
         new_len = (int64_t)n_new_max * (ps + info_len(d));
+        // correlated patterns: up to k - 1 measurements in all, possibly in one SPG_EDGE_MULTI record
+        if (k > 2 && (o.topology == SPG_TOPO_CLIQUEY_SUBGRAPH || o.topology == SPG_TOPO_CLIQUEY_DENSE)) new_len += SPG_MULTI_LEN(d, k - 1);
     } else if (o.topology == SPG_TOPO_DENSE || k <= 1) {
         int64_t n = (int64_t)d * k;
         n_new_max = k > 0 ? 1 : 0;

@@ -69,7 +69,7 @@ struct IpArgs {
     double chord_ratio;
 };
 int nfr_ip_pattern_size(int topology, double chord_ratio, int k);   // new edges of a blanket with k kept vertices (-1: correlated patterns)
-int64_t nfr_ip_workspace(int D, int k, int m, int E, int64_t *hot);  // doubles of workspace one such blanket needs (*hot: its LDS-eligible part)
+int64_t nfr_ip_workspace(int D, int k, int m, int E, int closed, int64_t *hot);  // doubles of workspace one such blanket needs (*hot: its LDS-eligible part)
 int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int64_t hot_max);
 
 // RCCL binding (spg_rccl.cpp): librccl.so.1 is bound with dlopen when the first multi-rank context is created

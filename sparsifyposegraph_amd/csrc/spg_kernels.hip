@@ -1953,7 +1953,8 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     // kernel (spg_nfr_ip.hip), one workgroup per blanket after the launches below
     std::vector<int32_t> ip_list;
     int64_t ip_stride = 0, ip_hot = 0;
-    if (o.algorithm == SPG_ALG_NFR && (o.topology == SPG_TOPO_DENSE || o.topology == SPG_TOPO_SUBGRAPH)) {
+    if (o.algorithm == SPG_ALG_NFR) {
+        const bool cliquey = o.topology == SPG_TOPO_CLIQUEY_SUBGRAPH || o.topology == SPG_TOPO_CLIQUEY_DENSE;
         for (int i = 0; i < NB; i++) {
             size_t keep = 0;
             int kmax = 0, mmax = 0, smax = 0;
@@ -1961,14 +1962,18 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
                 const spg_blanket_desc &bd = rd->blankets[b];
                 const int k = bd.n_vert - bd.n_remove, m = bd.n_remove;
                 const int E = spg::nfr_ip_pattern_size(o.topology, o.chord_ratio, k);
-                if (k >= 3 && E > k - 1) {
-                    if ((int64_t)D * D * E > 2048 || k > 64) {
-                        snprintf(err, sizeof hb->err, "interior-point NFR: a blanket with k=%d kept vertices and %d new edges needs a %d^2 Hessian (limit 2048^2)", k, E, D * D * E);
+                bool has_multi = false;
+                for (int e = bd.edge_begin; e < bd.edge_begin + bd.n_edge; e++) has_multi |= rd->edges[e].kind == SPG_EDGE_MULTI;
+                const bool ip = k >= 3 && !cliquey && E > k - 1;           // uncorrelated pattern without a closed form
+                // correlated patterns (and any blanket that holds a correlated edge) take the same generic kernel's closed form
+                if (ip || (cliquey && k >= 3) || (has_multi && k >= 2)) {
+                    if ((ip && (int64_t)D * D * E > 2048) || k > 64) {
+                        snprintf(err, sizeof hb->err, "interior-point / correlated NFR: a blanket with k=%d kept vertices and %d new measurements is beyond the generic kernel (Hessian limit 2048^2, k <= 64)", k, E);
                         return SPG_ECAPACITY;
                     }
                     ip_list.push_back(b);
                     int64_t hot = 0;
-                    ip_stride = std::max(ip_stride, spg::nfr_ip_workspace(D, k, m, E, &hot));
+                    ip_stride = std::max(ip_stride, spg::nfr_ip_workspace(D, k, m, E, ip ? 0 : 1, &hot));
                     ip_hot = std::max(ip_hot, hot);
                     continue;
                 }

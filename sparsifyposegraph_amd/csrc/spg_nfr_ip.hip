@@ -42,19 +42,21 @@ constexpr int kPanelDoubles = 8192;   // 64 KB: 16 columns of a panel up to 480 
 struct IpLayout {   // offsets (doubles) of one blanket's buffers: a cold part in the global workspace, a hot part (everything the
                     // Newton iterations touch except the Hessian) relative to its own base — LDS when it fits, else behind the cold part
     int n, nm, N, r, E, q, nx;
-    int64_t H, Lam, A1, V, Hx, pose, w, cold_total;
+    int64_t H, Lam, A1, V, Hx, pose, w, Sc, zbuf, grp, otab, cold_total;
     int64_t S, U, J, JU, Ai, T1, M, Mc, Mi, Li, Y, P, T2, x, xn, g, gn, dv, Xi, hot_total;
     int64_t total;
 };
 
-__host__ __device__ inline IpLayout ip_layout(int D, int k, int m, int E) {
+__host__ __device__ inline IpLayout ip_layout(int D, int k, int m, int E, bool closed) {
     IpLayout L;
     L.n = D * k; L.nm = D * m; L.N = L.n + L.nm; L.r = L.n - D; L.E = E; L.q = D * E; L.nx = D * D * E;
     int64_t o = 0;
     auto take = [&](int64_t len) { int64_t at = o; o += (len + 7) & ~(int64_t)7; return at; };
     const int64_t n = L.n, N = L.N, r = L.r > 0 ? L.r : 1, q = L.q, nx = L.nx, P2 = (int64_t)k * (k - 1) / 2;
-    L.H = take(N * N); L.Lam = take(n * n); L.A1 = take(n * n); L.V = take(n * n); L.Hx = take(nx * nx);
+    L.H = take(N * N); L.Lam = take(n * n); L.A1 = take(n * n); L.V = take(n * n); L.Hx = take(closed ? 8 : nx * nx);   // (no Newton iterations when the pattern has a closed form)
     L.pose = take(12 * (int64_t)(k + m)); L.w = take(4 * P2 + 8);
+    L.Sc = take(3 * N * N + 5 * n * n);            // correlated input edges (J, W J), closed form of correlated new edges (J_e, G, C, W, X)
+    L.zbuf = take(7 * (int64_t)(E + 1)); L.grp = take(2 * (int64_t)k + 8); L.otab = take(8 * (int64_t)k + 8);
     L.cold_total = o;
     o = 0;
     L.S = take(n); L.U = take(n * r); L.J = take(2 * (int64_t)D * D * E); L.JU = take(q * r); L.Ai = take(n * n); L.T1 = take(n * r);
@@ -74,7 +76,7 @@ __host__ __device__ inline int ip_pattern_size(int topology, double chord_ratio,
     if (topology == SPG_TOPO_TREE) return k - 1;
     if (topology == SPG_TOPO_DENSE || (topology == SPG_TOPO_SUBGRAPH && full)) return k * (k - 1) / 2;
     if (topology == SPG_TOPO_SUBGRAPH) return msub;
-    return -1;
+    return k - 1;     // CliqueySubgraph / CliqueyDense: the Chow-Liu tree's measurements, grouped into correlated edges
 }
 
 // lower Cholesky of a small matrix by ONE thread (IEEE divide / sqrt: this is the control path of the line search)
@@ -109,7 +111,11 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     const spg_blanket_desc bd = a.blk[b];
     const int nv = bd.n_vert, m = bd.n_remove, k = nv - m;
     const int E = ip_pattern_size(a.topology, a.chord_ratio, k);
-    const IpLayout L = ip_layout(D, k, m, E > 0 ? E : 1);
+    const bool cliquey = a.topology == SPG_TOPO_CLIQUEY_SUBGRAPH || a.topology == SPG_TOPO_CLIQUEY_DENSE;
+    // closed form (src/logdet_function.cpp:83-86): as many measurement rows as the target has rank — every correlated
+    // pattern, and the uncorrelated ones that are trees (they come here when the blanket holds correlated input edges)
+    const bool closed = cliquey || E <= k - 1;
+    const IpLayout L = ip_layout(D, k, m, E > 0 ? E : 1, closed);
     const int n = L.n, nm = L.nm, N = L.N, r = L.r, q = L.q, nx = L.nx;
     double *ws = a.ws + (int64_t)blockIdx.x * a.ws_stride;
     // hot buffers in LDS when this blanket's fit into what the launch reserved (latency per dependent phase ~0.1 us
@@ -125,10 +131,20 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     // L.w: [0, P2) pair weights | [P2, 2 P2) pair (i, j) ints | [2 P2, 3 P2) pop order + rejected bin (ints) | 3 P2 + 2: the pattern (2 E ints)
     int *pairs = reinterpret_cast<int *>(ws + L.w + 3 * ((int64_t)k * (k - 1) / 2) + 2);
 
+    bool tab_mode = false;          // correlated patterns: the new-edge table was prepared in ws + L.otab
     auto finish = [&]() {
         __syncthreads();
         if (tid == 0) {
             orec[0] = (double)status; orec[1] = (double)info; orec[2] = kld; orec[3] = min_gap; orec[4] = (double)n_new;
+            if (tab_mode) {
+                const double *ot = ws + L.otab;
+                int nvt = 0;
+                for (int e = 0; e < n_new; e++) {
+                    for (int c = 0; c < 4; c++) orec[SPG_OUT_HDR + 4 * e + c] = ot[4 * e + c];
+                    nvt += (int)ot[4 * e + 3];
+                }
+                for (int i = 0; i < nvt; i++) orec[SPG_OUT_HDR + 4 * bd.n_new_max + i] = ot[4 * k + i];
+            } else
             for (int e = 0; e < n_new; e++) {
                 orec[SPG_OUT_HDR + 4 * e + 0] = (double)SPG_EDGE_BINARY;
                 orec[SPG_OUT_HDR + 4 * e + 1] = (double)(e * REC);
@@ -145,8 +161,8 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     if (k < 2) { finish(); return; }
     if (E < 0) { status = SPG_ST_UNSUPPORTED; finish(); return; }
     if (a.lin_point != SPG_LIN_GLOBAL) { status = SPG_ST_NEEDS_LOCAL_OPTIMIZATION; finish(); return; }
-    for (int e = 0; e < bd.n_edge; e++)
-        if (a.er[bd.edge_begin + e].kind != SPG_EDGE_BINARY) { status = SPG_ST_UNSUPPORTED; finish(); return; }
+    for (int e = 0; e < bd.n_edge; e++)    // pose-pose and correlated multi edges (src/topology_provider_binary.hpp:16-21); GLC edges belong to the GLC provider
+        if (a.er[bd.edge_begin + e].kind == SPG_EDGE_GLC) { status = SPG_ST_UNSUPPORTED; finish(); return; }
 
     // ---- gather poses; H = sum_e J^T Omega J over the blanket's edges (one edge at a time: sizes are tiny next to
     // the Newton iterations below), vertices ordered [removed | kept] as the descriptors list them
@@ -162,8 +178,47 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         double *Je = hot + L.Ai;    // scratch: Ji, Jj, T = Omega [Ji Jj]   (Ai is free until the interior point)
         for (int e = 0; e < bd.n_edge; e++) {
             const spg_edge_ref er = a.er[bd.edge_begin + e];
-            const int vi = a.ev[er.vbegin], vj = a.ev[er.vbegin + 1];
             const double *rec = arena + er.off;
+            if (er.kind == SPG_EDGE_MULTI) {
+                // MultiEdgeCorrelated::linearizeOplus (src/multi_edge_correlated.hpp:101-140): J (r x d q) has the two
+                // pose-pose blocks of measurement i in row block i; information W^T W  =>  H += (W J)^T (W J)
+                const int q = er.nv, nmi = (int)rec[0], rr = D * nmi, dq = D * q;
+                const double *meas = rec + 1 + 2 * nmi, *Wd = meas + nmi * PS;
+                double *Jm = ws + L.Sc, *Am = Jm + (int64_t)rr * dq;
+                for (int it = tid; it < rr * dq; it += NT) Jm[it] = 0.0;
+                __syncthreads();
+                for (int i = tid; i < nmi; i += NT) {
+                    const int la = (int)rec[1 + 2 * i], lb = (int)rec[2 + 2 * i];
+                    const int va = a.ev[er.vbegin + la], vb = a.ev[er.vbegin + lb];
+                    double Ja[DD], Jbb[DD];
+                    if (D == 6) {
+                        double Z[kIso];
+                        iso_from_tq(meas + i * PS, Z);
+                        se3_edge_jac(pose + va * PSZ, pose + vb * PSZ, Z, Ja, Jbb, nullptr);
+                    } else {
+                        se2_edge_jac(pose + va * PSZ, pose + vb * PSZ, meas + i * PS, Ja, Jbb, nullptr);
+                    }
+                    for (int x = 0; x < D; x++) for (int y = 0; y < D; y++) { Jm[(i * D + x) * dq + la * D + y] += Ja[x * D + y]; Jm[(i * D + x) * dq + lb * D + y] += Jbb[x * D + y]; }
+                }
+                __syncthreads();
+                for (int it = tid; it < rr * dq; it += NT) {
+                    const int p = it / dq, c = it - p * dq;
+                    double sacc = 0;
+                    for (int t = 0; t < rr; t++) sacc += Wd[p * rr + t] * Jm[t * dq + c];
+                    Am[it] = sacc;
+                }
+                __syncthreads();
+                for (int it = tid; it < dq * dq; it += NT) {
+                    const int r1 = it / dq, c1 = it - r1 * dq;
+                    double sacc = 0;
+                    for (int p = 0; p < rr; p++) sacc += Am[p * dq + r1] * Am[p * dq + c1];
+                    const int gi = a.ev[er.vbegin + r1 / D] * D + r1 % D, gj = a.ev[er.vbegin + c1 / D] * D + c1 % D;
+                    H[gi * N + gj] += sacc;
+                }
+                __syncthreads();
+                continue;
+            }
+            const int vi = a.ev[er.vbegin], vj = a.ev[er.vbegin + 1];
             if (vi == vj) continue;
             if (tid == 0) {
                 if (D == 6) {
@@ -234,7 +289,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     // ---- sparsity pattern (src/pseudo_chow_liu.cpp:33-87)
     if (k == 2) {
         if (tid == 0) { pairs[0] = 0; pairs[1] = 1; }
-    } else if (E == k * (k - 1) / 2) {
+    } else if (!cliquey && E == k * (k - 1) / 2) {
         if (tid == 0) { int e = 0; for (int i = 0; i < k - 1; i++) for (int j = i + 1; j < k; j++) { pairs[2 * e] = i; pairs[2 * e + 1] = j; e++; } }
     } else {
         // pseudo-Chow-Liu weights from Sigma~ = (Lambda_t + I)^-1 (:169-196), Kruskal in pop order, accepted edges first,
@@ -296,6 +351,54 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                 } else rej[nrej++] = p;
             }
             for (int t = 0; nacc + t < E && t < nrej; t++) { pairs[2 * (nacc + t)] = pij[2 * rej[t]]; pairs[2 * (nacc + t) + 1] = pij[2 * rej[t] + 1]; }
+            if (cliquey) {
+                // groups of tree measurements = correlated edges (src/pseudo_chow_liu.cpp:62-85, fillCliques :198-251);
+                // cliques as bit masks over the k <= 64 kept vertices. grp: [0] number of groups, [1 + g] start of group g
+                // in the regrouped measurement list, which replaces pairs[] (bin order inside a group).
+                int *grp = reinterpret_cast<int *>(ws + L.grp);
+                const int msub = (int)((1 + a.chord_ratio) * (k - 1));
+                unsigned long long mask[64];
+                int ncl = k - 1;
+                for (int i = 0; i < ncl; i++) mask[i] = (1ull << pairs[2 * i]) | (1ull << pairs[2 * i + 1]);
+                if (a.topology == SPG_TOPO_CLIQUEY_DENSE || msub >= k * (k - 1) / 2) {
+                    ncl = 1;
+                    mask[0] = (k >= 64) ? ~0ull : ((1ull << k) - 1);
+                } else {
+                    bool joined = true;
+                    for (int nedges = k - 1, maxfill = 1; nedges < msub && joined; maxfill++) {
+                        joined = false;
+                        int minfill = 0x7fffffff;
+                        for (int i = 0; i < ncl; i++)
+                            for (int j = i + 1; j < ncl; j++) {
+                                if (!(mask[i] & mask[j])) continue;
+                                const int thisfill = (__popcll(mask[i]) - 1) * (__popcll(mask[j]) - 1);
+                                minfill = min(thisfill, minfill);
+                                if (thisfill <= maxfill && nedges + thisfill <= msub) {
+                                    mask[i] |= mask[j];
+                                    nedges += thisfill;
+                                    for (int t = j; t + 1 < ncl; t++) mask[t] = mask[t + 1];
+                                    ncl--;
+                                    joined = true;
+                                    j--;
+                                }
+                            }
+                        if (!joined && minfill > maxfill) { joined = true; maxfill = minfill - 1; }
+                    }
+                }
+                int tmp[128], nout = 0;
+                grp[0] = ncl;
+                for (int gidx = 0; gidx < ncl; gidx++) {
+                    grp[1 + gidx] = nout;
+                    for (int i = 0; i < k - 1; i++)
+                        if (((mask[gidx] >> pairs[2 * i]) & 1) && ((mask[gidx] >> pairs[2 * i + 1]) & 1)) {
+                            if (nout < 64) { tmp[2 * nout] = pairs[2 * i]; tmp[2 * nout + 1] = pairs[2 * i + 1]; }
+                            nout++;
+                        }
+                }
+                grp[1 + ncl] = nout;
+                si[1] = nout;
+                if (nout == k - 1) for (int i = 0; i < 2 * nout; i++) pairs[i] = tmp[i];
+            }
             const int upto = min(last + 1, P2 - 1);
             double g = __builtin_inf();
             for (int s = 0; s < upto; s++) {
@@ -307,6 +410,15 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
         __syncthreads();
         min_gap = sc[0];
+        // a tree edge inside two cliques: more measurements than rank, no closed form — the reference then runs the
+        // interior point over correlated blocks, which is not built
+        if (cliquey && si[1] != k - 1) { status = SPG_ST_UNSUPPORTED; finish(); return; }
+    }
+    __syncthreads();
+    if (closed && (!cliquey || k == 2) && tid == 0) {      // uncorrelated closed form: one group per measurement
+        int *grp = reinterpret_cast<int *>(ws + L.grp);
+        grp[0] = E;
+        for (int e = 0; e <= E; e++) grp[1 + e] = e;
     }
     __syncthreads();
 
@@ -314,7 +426,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     double *Jb = hot + L.J;
     for (int e = tid; e < E; e += NT) {
         const int va = m + pairs[2 * e], vb = m + pairs[2 * e + 1];
-        double *rec = arena + bd.new_off + (int64_t)e * REC;
+        double *rec = closed ? (ws + L.zbuf + (int64_t)e * PS) : (arena + bd.new_off + (int64_t)e * REC);
         if (D == 6) {
             double Z[kIso], qd[4];
             iso_inv_mul(pose + va * PSZ, pose + vb * PSZ, Z);
@@ -353,6 +465,159 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         for (int j = tid; j < r; j += NT) l += log(Sv[j]);
         logdetS = T.sum(l);
     }
+    double *Ai = hot + L.Ai, *T1 = hot + L.T1, *M = hot + L.M, *Mc = hot + L.Mc, *Mi = hot + L.Mi, *Li = hot + L.Li, *Y = hot + L.Y;
+    // LogdetFunction::value (src/logdet_function.cpp:119-133) of the product information held in Ai (full symmetric):
+    // M = U^T A U, 1/2 (tr(M S) - log det M - log det S - r); leaves chol(M) in Mc
+    auto value_from_A = [&](bool &ok) -> double {
+        for (int it = tid; it < n * r; it += NT) {
+            const int i = it / r, c = it - i * r;
+            double sacc = 0;
+            for (int t = 0; t < n; t++) sacc += Ai[i * n + t] * U[t * r + c];
+            T1[it] = sacc;
+        }
+        __syncthreads();
+        for (int it = tid; it < r * r; it += NT) {
+            const int i = it / r, j = it - i * r;
+            if (j >= i) {
+                double sacc = 0;
+                for (int t = 0; t < n; t++) sacc += U[t * r + i] * T1[t * r + j];
+                M[i * r + j] = sacc; M[j * r + i] = sacc;
+            }
+        }
+        __syncthreads();
+        double tr = 0;
+        for (int i = tid; i < r; i += NT) tr += M[i * r + i] * Sv[i];
+        tr = T.sum(tr);
+        for (int it = tid; it < r * r; it += NT) Mc[it] = M[it];
+        if (tid == 0) flag_s = 0;
+        __syncthreads();
+        chol_lower<NT>(T, Mc, r, r);
+        ok = flag_s == 0;
+        __syncthreads();
+        if (!ok) { if (tid == 0) flag_s = 0; __syncthreads(); return __builtin_inf(); }
+        double l = 0;
+        for (int i = tid; i < r; i += NT) l += log(Mc[i * r + i]);
+        l = T.sum(l);
+        return 0.5 * (tr - 2.0 * l - logdetS - r);
+    };
+    if (closed) {
+        // ---- closed form per group, X_e = (J_e Sigma J_e^T)^-1 (src/logdet_function.cpp:236-279),
+        // one SPG_EDGE_MULTI record per group with more than one measurement (src/topology_provider_binary.hpp:48-67)
+        const int *grp = reinterpret_cast<const int *>(ws + L.grp);
+        const int ng = grp[0];
+        double *Sig = Y, *otab = ws + L.otab;
+        for (int it = tid; it < n * r; it += NT) { const int c = it % r; T1[it] = U[it] * Sv[c]; }
+        __syncthreads();
+        for (int it = tid; it < n * n; it += NT) {
+            const int i = it / n, j = it - i * n;
+            if (j <= i) { double sacc = 0; for (int t = 0; t < r; t++) sacc += T1[i * r + t] * U[j * r + t]; Sig[i * n + j] = sacc; Sig[j * n + i] = sacc; }
+        }
+        for (int it = tid; it < n * n; it += NT) Ai[it] = 0.0;
+        __syncthreads();
+        int64_t rel = 0;
+        int nvt = 0;
+        for (int gi = 0; gi < ng; gi++) {
+            const int i0 = grp[1 + gi], nmg = grp[2 + gi] - i0, re = D * nmg;
+            double *Je = ws + L.Sc, *G = Je + (int64_t)re * n, *C = G + re * re, *Wm = C + re * re, *X = Wm + re * re, *Tm = ws + L.A1;
+            for (int it = tid; it < re * n; it += NT) Je[it] = 0.0;
+            __syncthreads();
+            for (int i = tid; i < nmg; i += NT) {
+                const int oa = pairs[2 * (i0 + i)] * D, ob = pairs[2 * (i0 + i) + 1] * D;
+                const double *Ja = Jb + (i0 + i) * 2 * DD, *Jbb = Ja + DD;
+                for (int x = 0; x < D; x++) for (int y = 0; y < D; y++) {
+                    double ja = Ja[x * D + y], jb = Jbb[x * D + y];
+                    if (ng == 1 && nmg > 0) {      // a single measurement block goes through sparseJacobian(): entries below epsilon are dropped (:243-247, :335)
+                        if (fabs(ja) < 2.220446049250313e-16) ja = 0.0;
+                        if (fabs(jb) < 2.220446049250313e-16) jb = 0.0;
+                    }
+                    Je[(i * D + x) * n + oa + y] += ja;
+                    Je[(i * D + x) * n + ob + y] += jb;
+                }
+            }
+            __syncthreads();
+            for (int it = tid; it < re * n; it += NT) {
+                const int pr = it / n, c = it - pr * n;
+                double sacc = 0;
+                for (int t = 0; t < n; t++) sacc += Je[pr * n + t] * Sig[t * n + c];
+                Tm[it] = sacc;
+            }
+            __syncthreads();
+            for (int it = tid; it < re * re; it += NT) {
+                const int pr = it / re, c = it - pr * re;
+                double sacc = 0;
+                for (int t = 0; t < n; t++) sacc += Tm[pr * n + t] * Je[c * n + t];
+                G[it] = sacc;
+            }
+            __syncthreads();
+            for (int it = tid; it < re * re; it += NT) { const int pr = it / re, c = it - pr * re; C[it] = 0.5 * (G[pr * re + c] + G[c * re + pr]); }
+            if (tid == 0) flag_s = 0;
+            __syncthreads();
+            chol_lower<NT>(T, C, re, re);
+            if (flag_s) { status = SPG_ST_CLOSED_FORM_NOT_PD; n_new = 0; finish(); return; }
+            tri_inverse_lower<NT>(T, C, Wm, re, re);        // W = C^-1 (lower): X = W^T W
+            gram_lower_inverse<NT>(T, Wm, X, re, re);
+            // A += J_e^T X J_e
+            for (int it = tid; it < re * n; it += NT) {
+                const int pr = it / n, c = it - pr * n;
+                double sacc = 0;
+                for (int t = 0; t < re; t++) sacc += X[pr * re + t] * Je[t * n + c];
+                Tm[it] = sacc;
+            }
+            __syncthreads();
+            for (int it = tid; it < n * n; it += NT) {
+                const int i = it / n, j = it - i * n;
+                double sacc = 0;
+                for (int t = 0; t < re; t++) sacc += Je[t * n + i] * Tm[t * n + j];
+                Ai[it] += sacc;
+            }
+            // the record
+            double *rec = arena + bd.new_off + rel;
+            const double *zb = ws + L.zbuf + (int64_t)i0 * PS;
+            if (nmg == 1) {
+                for (int it = tid; it < PS; it += NT) rec[it] = zb[it];
+                for (int it = tid; it < D * (D + 1) / 2; it += NT) {
+                    int o = it, i = 0;
+                    while (o >= D - i) { o -= D - i; i++; }
+                    rec[PS + it] = X[i * re + i + o];
+                }
+                if (tid == 0) {
+                    otab[4 * gi] = (double)SPG_EDGE_BINARY; otab[4 * gi + 1] = (double)rel; otab[4 * gi + 2] = (double)REC; otab[4 * gi + 3] = 2.0;
+                    otab[4 * k + nvt] = (double)(m + pairs[2 * i0]); otab[4 * k + nvt + 1] = (double)(m + pairs[2 * i0 + 1]);
+                }
+                rel += REC; nvt += 2;
+            } else {
+                if (tid == 0) {
+                    int lv[64], nq = 0;
+                    rec[0] = (double)nmg;
+                    for (int i = 0; i < nmg; i++)
+                        for (int side = 0; side < 2; side++) {
+                            const int v = pairs[2 * (i0 + i) + side];
+                            int at = -1;
+                            for (int t = 0; t < nq; t++) if (lv[t] == v) at = t;
+                            if (at < 0) { at = nq; lv[nq++] = v; }
+                            rec[1 + 2 * i + side] = (double)at;
+                        }
+                    otab[4 * gi] = (double)SPG_EDGE_MULTI; otab[4 * gi + 1] = (double)rel; otab[4 * gi + 2] = (double)SPG_MULTI_LEN(D, nmg); otab[4 * gi + 3] = (double)nq;
+                    for (int t = 0; t < nq; t++) otab[4 * k + nvt + t] = (double)(m + lv[t]);
+                    si[2] = nq;
+                }
+                for (int it = tid; it < nmg * PS; it += NT) rec[1 + 2 * nmg + it] = zb[it];
+                double *Wr = rec + 1 + 2 * nmg + nmg * PS;
+                for (int it = tid; it < re * re; it += NT) Wr[it] = Wm[it];
+                __syncthreads();
+                rel += SPG_MULTI_LEN(D, nmg); nvt += si[2];
+            }
+            __syncthreads();
+        }
+        bool okc = false;
+        const double fv = value_from_A(okc);
+        tab_mode = true;
+        n_new = ng;
+        if (!okc || !isfinite(fv)) { status = SPG_ST_KLD_NOT_PD; kld = __builtin_nan(""); finish(); return; }
+        kld = fv;
+        finish();
+        return;
+    }
     // JU = sparseJacobian * U  (q x r): row (e, p) = Ja[p,:] U[a-block,:] + Jb[p,:] U[b-block,:]
     double *JU = hot + L.JU;
     for (int it = tid; it < q * r; it += NT) {
@@ -370,7 +635,6 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     __syncthreads();
 
     // ---- the function: value(xv) leaves chol(M) in Mc; gradient(xv, gv) leaves M^-1 in Mi and the X_e^-1 in Xi
-    double *Ai = hot + L.Ai, *T1 = hot + L.T1, *M = hot + L.M, *Mc = hot + L.Mc, *Mi = hot + L.Mi, *Li = hot + L.Li, *Y = hot + L.Y;
     double *P = hot + L.P, *T2 = hot + L.T2, *Hx = ws + L.Hx, *Xi = hot + L.Xi;
     double *x = hot + L.x, *xn = hot + L.xn, *g = hot + L.g, *gn = hot + L.gn, *dv = hot + L.dv;
     double rho = 0;
@@ -408,37 +672,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
         for (int it = tid; it < n * n; it += NT) { const int i = it / n, j = it - i * n; if (j < i) Ai[it] = Ai[j * n + i]; }
         __syncthreads();
-        // M = U^T A U, symmetric from the upper triangle
-        for (int it = tid; it < n * r; it += NT) {
-            const int i = it / r, c = it - i * r;
-            double s = 0;
-            for (int t = 0; t < n; t++) s += Ai[i * n + t] * U[t * r + c];
-            T1[it] = s;
-        }
-        __syncthreads();
-        for (int it = tid; it < r * r; it += NT) {
-            const int i = it / r, j = it - i * r;
-            if (j >= i) {
-                double s = 0;
-                for (int t = 0; t < n; t++) s += U[t * r + i] * T1[t * r + j];
-                M[i * r + j] = s; M[j * r + i] = s;
-            }
-        }
-        __syncthreads();
-        double tr = 0;
-        for (int i = tid; i < r; i += NT) tr += M[i * r + i] * Sv[i];
-        tr = T.sum(tr);
-        for (int it = tid; it < r * r; it += NT) Mc[it] = M[it];
-        if (tid == 0) flag_s = 0;
-        __syncthreads();
-        chol_lower<NT>(T, Mc, r, r);
-        ok = flag_s == 0;
-        __syncthreads();
-        if (!ok) { if (tid == 0) flag_s = 0; __syncthreads(); return __builtin_inf(); }
-        double l = 0;
-        for (int i = tid; i < r; i += NT) l += log(Mc[i * r + i]);
-        l = T.sum(l);
-        return 0.5 * (tr - 2.0 * l - logdetS - r);
+        return value_from_A(ok);
     };
     bool chol_ok = false;
     auto value = [&](const double *xv) -> double {
@@ -755,8 +989,8 @@ namespace spg {
 
 int nfr_ip_pattern_size(int topology, double chord_ratio, int k) { return ip_pattern_size(topology, chord_ratio, k); }
 
-int64_t nfr_ip_workspace(int D, int k, int m, int E, int64_t *hot) {
-    const IpLayout L = ip_layout(D, k, m, E > 0 ? E : 1);
+int64_t nfr_ip_workspace(int D, int k, int m, int E, int closed, int64_t *hot) {
+    const IpLayout L = ip_layout(D, k, m, E > 0 ? E : 1, closed != 0);
     if (hot) *hot = L.hot_total;
     return L.total;
 }

@@ -50,6 +50,7 @@ SYMBOLS = {
     "spg_graph_add_vertices": (C.c_int, [C.c_void_p, C.c_int, _i32p, _f64p]),
     "spg_graph_add_edges": (C.c_int, [C.c_void_p, C.c_int, _i32p, _f64p]),
     "spg_graph_add_glc_edge": (C.c_int, [C.c_void_p, C.c_int, _i32p, C.c_int, _f64p, _f64p]),
+    "spg_graph_add_multi_edge": (C.c_int, [C.c_void_p, C.c_int, _i32p, _f64p, C.c_int64]),
     "spg_graph_pose_dim": (C.c_int, [C.c_void_p]),
     "spg_graph_num_vertices": (C.c_int, [C.c_void_p]),
     "spg_graph_num_edges": (C.c_int, [C.c_void_p]),

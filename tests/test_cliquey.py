@@ -1,0 +1,135 @@
+"""Correlated NFR patterns: SparsityOptions::CliqueySubgraph / ::CliqueyDense group the Chow-Liu tree's
+measurements into MultiEdgeCorrelated edges (src/pseudo_chow_liu.cpp:62-85,198-251, src/topology_provider_binary.hpp:48-67,
+src/multi_edge_correlated.hpp:65-140) whose joint information has a closed form (src/logdet_function.cpp:236-279).
+CPU: the oracle through invariants — CliqueyDense reproduces the target exactly (per-blanket KLD 0, global KLD of the
+sparsified graph 0: the same statement GLC Dense makes), CliqueySubgraph sits between the tree and that. GPU: the
+generic NFR kernel (csrc/spg_nfr_ip.hip) and the assembly kernels with SPG_EDGE_MULTI edges against the oracle."""
+import numpy as np
+import pytest
+
+from sparsifyposegraph_amd import abi
+from tests import oracle_lib, util
+
+
+def _opts(d, topo, chord=1.0):
+    o = abi.make_options(d, abi.ALG_NFR, topo)
+    o.chord_ratio = chord
+    return o
+
+
+CASES = [("sphere_nfr_tree", abi.TOPO_CLIQUEY_DENSE, 1.0), ("sphere_nfr_tree", abi.TOPO_CLIQUEY_SUBGRAPH, 0.5),
+         ("manhattan_nfr_tree", abi.TOPO_CLIQUEY_DENSE, 1.0), ("manhattan_nfr_tree", abi.TOPO_CLIQUEY_SUBGRAPH, 0.5),
+         ("parking_nfr_tree", abi.TOPO_CLIQUEY_SUBGRAPH, 0.3), ("intel_nfr_tree_sp3", abi.TOPO_CLIQUEY_DENSE, 1.0)]
+
+
+@pytest.mark.parametrize("case,topo,chord", CASES)
+def test_oracle_correlated_patterns(case, topo, chord, oracle):
+    g, which, opts, *_ = util.load_golden(case)
+    d = opts.pose_dim
+    batch, roots = util.first_round_batch(g, which, _opts(d, topo, chord))
+    ref = abi.marginalize_batch(oracle, None, _opts(d, topo, chord), batch)
+    tree = abi.marginalize_batch(oracle, None, _opts(d, abi.TOPO_TREE), batch)
+    assert (ref["status"] == 0).all()
+    fin = np.isfinite(ref["kld"])
+    ne = ref["new_edge_off"][-1]
+    kinds = ref["new_edge_kind"][:ne]
+    assert (kinds == abi.EDGE_MULTI).sum() >= 5 and set(kinds) <= {abi.EDGE_BINARY, abi.EDGE_MULTI}
+    if topo == abi.TOPO_CLIQUEY_DENSE:
+        assert np.abs(ref["kld"][fin]).max() <= 1e-10          # one fully correlated edge carries the whole target
+        assert (np.diff(ref["new_edge_off"])[fin] == 1).all()
+    else:
+        assert (ref["kld"][fin] <= tree["kld"][fin] + 1e-9).all() and (ref["kld"][fin] >= -1e-9).all()
+    # every measurement of a correlated edge is a tree measurement, its information is PD
+    for e in np.nonzero(kinds == abi.EDGE_MULTI)[0][:30]:
+        data = ref["new_edge_data"][ref["new_edge_data_off"][e]:ref["new_edge_data_off"][e + 1]]
+        pairs, meas, om = util.multi_parts(d, data)
+        nv = ref["new_edge_vert_off"][e + 1] - ref["new_edge_vert_off"][e]
+        assert len(data) == 1 + 2 * len(pairs) + len(pairs) * abi.pose_stride(d) + (d * len(pairs)) ** 2
+        assert pairs.max() == nv - 1 and len(pairs) == nv - 1 and np.linalg.eigvalsh(om).min() > 0
+
+
+@pytest.mark.parametrize("case,n,topo,chord", [("sphere_nfr_tree", 150, abi.TOPO_CLIQUEY_DENSE, 1.0), ("manhattan_nfr_tree", 250, abi.TOPO_CLIQUEY_DENSE, 1.0),
+                                               ("manhattan_nfr_tree", 250, abi.TOPO_CLIQUEY_SUBGRAPH, 0.5)])
+def test_oracle_whole_graph_with_correlated_edges(case, n, topo, chord):
+    """Later blankets contain the correlated edges earlier ones produced. CliqueyDense keeps the marginal exactly: the
+    global KLD of the sparsified graph against its baseline is 0 — which exercises the multi edges' Jacobians and
+    information in assembly, Schur complement and KLD at once."""
+    g, which, opts, *_ = util.load_golden(case)
+    sub, w = util.prefix_graph(g, which, n)
+    fid = int(min(sub["ids"]))
+    ob, og = oracle_lib.OracleGraph.from_dict(sub), oracle_lib.OracleGraph.from_dict(sub)
+    assert og.marginalize(w, _opts(opts.pose_dim, topo, chord)) == 0
+    b = og.blankets()
+    assert (b["status"] == 0).all() and (og.edges()["kind"] == abi.EDGE_MULTI).sum() >= 2
+    r = ob.kullback_leibler(og, fid)
+    ot = oracle_lib.OracleGraph.from_dict(sub)
+    assert ot.marginalize(w, _opts(opts.pose_dim, abi.TOPO_TREE)) == 0
+    rt = ob.kullback_leibler(ot, fid)
+    if topo == abi.TOPO_CLIQUEY_DENSE:
+        assert abs(r["kld"]) <= 1e-9 * r["n"]
+    else:
+        assert -1e-9 <= r["kld"] <= rt["kld"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,topo,chord", CASES)
+def test_device_correlated_patterns_match_oracle(case, topo, chord, hip_ctx, oracle):
+    g, which, opts, *_ = util.load_golden(case)
+    d = opts.pose_dim
+    o = _opts(d, topo, chord)
+    batch, roots = util.first_round_batch(g, which, o)
+    ref = abi.marginalize_batch(oracle, None, o, batch)
+    got = hip_ctx.marginalize_batch(o, batch)
+    assert np.array_equal(ref["status"], got["status"])
+    for key in ("new_edge_off", "new_edge_kind", "new_edge_vert_off", "new_edge_vert", "new_edge_data_off"):
+        ne = ref["new_edge_off"][-1]
+        n = {"new_edge_off": len(ref[key]), "new_edge_kind": ne, "new_edge_vert_off": ne + 1, "new_edge_vert": ref["new_edge_vert_off"][ne], "new_edge_data_off": ne + 1}[key]
+        assert np.array_equal(ref[key][:n], got[key][:n]), key
+    worst = 0.0
+    ps = abi.pose_stride(d)
+    for e in range(ref["new_edge_off"][-1]):
+        xa = ref["new_edge_data"][ref["new_edge_data_off"][e]:ref["new_edge_data_off"][e + 1]]
+        xb = got["new_edge_data"][got["new_edge_data_off"][e]:got["new_edge_data_off"][e + 1]]
+        if ref["new_edge_kind"][e] == abi.EDGE_MULTI:
+            (pa, ma, oa), (pb, mb, ob) = util.multi_parts(d, xa), util.multi_parts(d, xb)
+            assert np.array_equal(pa, pb)
+            worst = max(worst, util.rel_err(ma, mb), util.rel_err(oa, ob))
+        else:
+            worst = max(worst, util.rel_err(xa[:ps], xb[:ps]), util.rel_err(xa[ps:], xb[ps:]))
+    fin = np.isfinite(ref["kld"])
+    kerr = np.abs(ref["kld"][fin] - got["kld"][fin]).max()
+    print(f"{case} topo={topo}: {int((ref['new_edge_kind'][:ref['new_edge_off'][-1]] == abi.EDGE_MULTI).sum())} correlated edges, worst rel err {worst:.1e}, KLD abs err {kerr:.1e}")
+    assert worst <= 1e-9 and kerr <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,n,topo,chord", [("sphere_nfr_tree", 200, abi.TOPO_CLIQUEY_DENSE, 1.0), ("manhattan_nfr_tree", 300, abi.TOPO_CLIQUEY_DENSE, 1.0),
+                                               ("manhattan_nfr_tree", 300, abi.TOPO_CLIQUEY_SUBGRAPH, 0.5), ("parking_nfr_tree", 200, abi.TOPO_CLIQUEY_SUBGRAPH, 0.3),
+                                               ("intel_nfr_tree_sp3", 300, abi.TOPO_CLIQUEY_SUBGRAPH, 0.4)])
+def test_device_whole_graph_with_correlated_edges(case, n, topo, chord, hip_ctx):
+    """Through the round scheduler: graph identical to the sequential oracle's (edges to 1e-9), and the device's global KLD
+    of the result — dense assembly with SPG_EDGE_MULTI edges — equal to the oracle's (0 for CliqueyDense)."""
+    from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    g, which, opts, *_ = util.load_golden(case)
+    d = opts.pose_dim
+    sub, w = util.prefix_graph(g, which, n)
+    o = _opts(d, topo, chord)
+    hg = GraphWrapperHIP.from_dict(sub, ctx=hip_ctx)
+    st = hg.marginalizeNoOptimize(w, o)
+    og = oracle_lib.OracleGraph.from_dict(sub)
+    assert og.marginalize(w, o) == 0 and st["n_bad_status"] == 0
+    worst = util.compare_edge_sets(d, og.edges(), hg.edges(), rtol=1e-9)
+    kref = float(np.nansum(og.blankets()["kld"]))
+    assert abs(st["kld_sum"] - kref) <= 1e-9 * max(1.0, abs(kref))
+    fid = int(min(sub["ids"]))
+    hb, ob = GraphWrapperHIP.from_dict(sub, ctx=hip_ctx), oracle_lib.OracleGraph.from_dict(sub)
+    kld = hb.kullbackLeibler(hg)
+    r = ob.kullback_leibler(og, fid)
+    assert abs(kld - r["kld"]) <= 1e-9 * r["n"]
+    if topo == abi.TOPO_CLIQUEY_DENSE:
+        assert abs(kld) <= 1e-9 * r["n"]
+    # chi2 / optimize see the correlated edges too
+    c_dev, c_ref = hg.chi2(), og.chi2(fid)
+    assert c_dev == pytest.approx(c_ref, rel=1e-9, abs=1e-12)
+    n_multi = int((og.edges()["kind"] == abi.EDGE_MULTI).sum())
+    print(f"{case} topo={topo}: {n_multi} correlated edges in the result, worst edge rel err {worst:.1e}, global KLD {kld:.3e} (oracle {r['kld']:.3e})")

@@ -48,6 +48,17 @@ def glc_gram(d, ids, data):
     return W.T @ W
 
 
+def multi_parts(d, data):
+    """SPG_EDGE_MULTI record (include/spg.h) -> (pairs [nm, 2], measurements [nm, ps], information W^T W)"""
+    ps = abi.pose_stride(d)
+    nm = int(data[0])
+    r = d * nm
+    pairs = np.asarray(data[1:1 + 2 * nm]).reshape(nm, 2).astype(int)
+    meas = np.asarray(data[1 + 2 * nm:1 + 2 * nm + nm * ps]).reshape(nm, ps)
+    W = np.asarray(data[1 + 2 * nm + nm * ps:1 + 2 * nm + nm * ps + r * r]).reshape(r, r)
+    return pairs, meas, W.T @ W
+
+
 def rel_err(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     den = max(np.abs(a).max(initial=0.0), np.abs(b).max(initial=0.0), 1e-300)
@@ -65,6 +76,10 @@ def compare_edge_sets(d, ea, eb, rtol=RTOL):
         if k == abi.EDGE_BINARY:
             assert len(xa) == len(xb)
             worst = max(worst, rel_err(xa[:ps], xb[:ps]), rel_err(xa[ps:], xb[ps:]))
+        elif k == abi.EDGE_MULTI:
+            (pa, ma, oa), (pb, mb, ob) = multi_parts(d, xa), multi_parts(d, xb)
+            assert np.array_equal(pa, pb), "measurement pairs of a correlated edge differ"
+            worst = max(worst, rel_err(ma, mb), rel_err(oa, ob))
         else:
             n = d * len(ids)
             worst = max(worst, rel_err(xa[:n], xb[:n]))
