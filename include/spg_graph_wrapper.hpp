@@ -240,11 +240,18 @@ class GraphWrapperHIP : public GraphWrapper {
         std::vector<const GraphWrapper::Vertex *> vertices() const override { return _verts; }
         // pose-pose edge: its measurement; n-ary GLC edge: the reparametrised measurement has no IsometryXd form
         IsometryXd measurement() const override {
-            if (_kind != SPG_EDGE_BINARY) throw std::runtime_error("measurement(): GLC edge (use record())");
+            if (_kind != SPG_EDGE_BINARY) throw std::runtime_error("measurement(): n-ary edge (GLC / MultiEdgeCorrelated: use record())");
             return IsometryXd(std::vector<double>(_rec.begin(), _rec.begin() + (_d == 3 ? 3 : 7)));
         }
         // pose-pose edge: d x d; GLC edge: I_r (src/topology_provider_glc.cpp:91)
         MatrixXd information() const override {
+            if (_kind == SPG_EDGE_MULTI) {   // MultiEdgeCorrelated: the joint information W^T W of its nm measurements (include/spg.h)
+                const int nm = (int)_rec[0], r = _d * nm;
+                const double *W = _rec.data() + 1 + 2 * nm + nm * (_d == 3 ? 3 : 7);
+                MatrixXd m(r, r);
+                for (int i = 0; i < r; i++) for (int j = 0; j < r; j++) { double v = 0; for (int t = 0; t < r; t++) v += W[t * r + i] * W[t * r + j]; m(i, j) = v; }
+                return m;
+            }
             if (_kind != SPG_EDGE_BINARY) { int n = _d * (int)_verts.size(); return MatrixXd::Identity(((int)_rec.size() - n) / n); }
             MatrixXd m(_d, _d);
             int ps = _d == 3 ? 3 : 7, p = 0;
@@ -446,7 +453,7 @@ public:
 
     // ---- beyond the reference interface -----------------------------------------------------------------
     struct EdgeRecord {
-        int kind;                    // SPG_EDGE_BINARY | SPG_EDGE_GLC
+        int kind;                    // SPG_EDGE_BINARY | SPG_EDGE_GLC | SPG_EDGE_MULTI
         std::vector<int> vertices;   // ids
         std::vector<double> data;    // record as in spg_batch.edge_data
     };
