@@ -32,6 +32,7 @@ using namespace spgdev;
 namespace {
 
 constexpr int NT = 256;
+constexpr int RIF = 4;    // rows in flight per wavefront in the trailing update of the out-of-L2 Cholesky
 #ifdef SPG_IP_PROF
 #define IPT(k) do { long long t_ = (long long)__builtin_amdgcn_s_memtime(); ipt[k] += t_ - ipt_last; ipt_last = t_; } while (0)
 #else
@@ -53,7 +54,7 @@ __host__ __device__ inline IpLayout ip_layout(int D, int k, int m, int E, bool c
     int64_t o = 0;
     auto take = [&](int64_t len) { int64_t at = o; o += (len + 7) & ~(int64_t)7; return at; };
     const int64_t n = L.n, N = L.N, r = L.r > 0 ? L.r : 1, q = L.q, nx = L.nx, P2 = (int64_t)k * (k - 1) / 2;
-    L.H = take(N * N); L.Lam = take(n * n); L.A1 = take(n * n); L.V = take(n * n); L.Hx = take(closed ? 8 : nx * nx);   // (no Newton iterations when the pattern has a closed form)
+    L.H = take(N * N); L.Lam = take(n * n); L.A1 = take(n * n); L.V = take(n * n); L.Hx = take(closed ? 8 : nx * nx + nx);   // (no Newton iterations when the pattern has a closed form)
     L.pose = take(12 * (int64_t)(k + m)); L.w = take(4 * P2 + 8);
     L.Sc = take(3 * N * N + 5 * n * n);            // correlated input edges (J, W J), closed form of correlated new edges (J_e, G, C, W, X)
     L.zbuf = take(7 * (int64_t)(E + 1)); L.grp = take(2 * (int64_t)k + 8); L.otab = take(8 * (int64_t)k + 8);
@@ -105,7 +106,6 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     __shared__ double sc[8];      // scalars broadcast by thread 0
     __shared__ int si[8];
     __shared__ double colbuf[2048];   // running vector of the Newton solve (d^2 E <= 2048)
-    __shared__ double panel[kPanelDoubles];   // panel of the Hessian's Cholesky
     const int tid = threadIdx.x;
     const int b = a.list[blockIdx.x];
     const spg_blanket_desc bd = a.blk[b];
@@ -120,7 +120,14 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     double *ws = a.ws + (int64_t)blockIdx.x * a.ws_stride;
     // hot buffers in LDS when this blanket's fit into what the launch reserved (latency per dependent phase ~0.1 us
     // instead of ~1 us out of L2: a Newton step is a few hundred such phases)
-    double *hot = (L.hot_total <= (int64_t)a.lds_doubles) ? lds_pool : ws + L.cold_total;
+    // Dynamic LDS, one of two uses per blanket. (A) the whole Hessian, lower triangle packed by rows with the Newton
+    // right-hand side as an extra row — its Cholesky and the substitution then never leave LDS (a 144-variable problem:
+    // 85 KB); (B) when that does not fit: a 64 KB panel for the blocked out-of-L2 factorisation, and behind it the hot
+    // small matrices if they fit.
+    const long long packed_len = (long long)(nx + 1) * (nx + 2) / 2;
+    const bool hx_lds = !closed && packed_len <= (long long)a.lds_doubles;
+    double *panel = lds_pool;
+    double *hot = (!hx_lds && kPanelDoubles + L.hot_total <= (int64_t)a.lds_doubles) ? lds_pool + kPanelDoubles : ws + L.cold_total;
     double *arena = a.arena;
     double *orec = a.mail ? (a.mail + (bd.out_off - a.mail_base)) : (arena + bd.out_off);
     if (tid == 0) flag_s = 0;
@@ -779,6 +786,24 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         for (int it = tid; it < q * q; it += NT) { const int i = it / q, j = it - i * q; if (j < i) P[it] = P[j * q + i]; }
         __syncthreads();
         // H[(e, ii, jj)][(e2, uu, vv)] = P(e2 D + uu, e D + ii) P(e D + jj, e2 D + vv)  (+ rho Xinv(uu, ii) Xinv(jj, vv) on e2 = e)
+        if (hx_lds) {
+            // lower triangle only, packed by rows in LDS: row s at s (s + 1) / 2
+            for (int s0 = tid; s0 < nx; s0 += NT) {
+                // (rows are dealt round-robin from both ends so that the triangular row lengths balance)
+                const int sidx = (s0 & 1) ? (nx - 1 - (s0 >> 1)) : (s0 >> 1);
+                const int e = sidx / DD, jj = (sidx - e * DD) / D, ii = sidx - e * DD - jj * D;
+                double *row = lds_pool + (long long)sidx * (sidx + 1) / 2;
+                int e2 = 0, vv = 0, uu = 0;
+                for (int t = 0; t <= sidx; t++) {
+                    double v = P[(e2 * D + uu) * q + e * D + ii] * P[(e * D + jj) * q + e2 * D + vv];
+                    if (e2 == e && chol_ok) v += rho * Xi[e * DD + uu * D + ii] * Xi[e * DD + jj * D + vv];
+                    row[t] = v;
+                    if (++uu == D) { uu = 0; if (++vv == D) { vv = 0; e2++; } }
+                }
+            }
+            __syncthreads();
+            return;
+        }
         for (long long it = tid; it < (long long)nx * nx; it += NT) {
             const int s = (int)(it / nx), t = (int)(it - (long long)s * nx);
             const int e = s / DD, jj = (s - e * DD) / D, ii = s - e * DD - jj * D;
@@ -789,21 +814,68 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
         __syncthreads();
     };
-    // Cholesky of the Hessian (Eigen::LLT in the reference, src/pqn/pqn_optimizer.cpp:52-53), lower, in place, out of L2.
+    // (A) Cholesky of the packed Hessian in LDS, right-looking, the scaled column copied to colbuf so that the trailing update
+    // walks rows only; the right-hand side is row nn. Three barriers per column, no global memory. Then L^T x = y by one
+    // wavefront (right-looking over the rows of L, no barriers). Same operations in the same order as the out-of-L2 version.
+    auto chol_solve_packed = [&](int nn, const double *rhs_neg, double *out) -> bool {
+        double *Hp = lds_pool;
+        auto rowp = [&](int i) { return Hp + (long long)i * (i + 1) / 2; };
+        for (int it = tid; it < nn; it += NT) rowp(nn)[it] = rhs_neg[it];
+        __syncthreads();
+        bool okc = true;
+        for (int j = 0; j < nn; j++) {
+            double dpiv = rowp(j)[j];
+            if (!(dpiv > 0.0) || !isfinite(dpiv)) { okc = false; dpiv = 1.0; }
+            const double l = sqrt(dpiv);
+            __syncthreads();
+            for (int i = j + 1 + tid; i <= nn; i += NT) { const double v = rowp(i)[j] / l; rowp(i)[j] = v; colbuf[i] = v; }
+            if (tid == 0) rowp(j)[j] = l;
+            __syncthreads();
+            for (int i = j + 1 + (tid >> 6); i <= nn; i += NT / 64) {
+                const double li = colbuf[i];
+                double *row = rowp(i);
+                const int cmax = min(i, nn - 1);
+                for (int c = j + 1 + (tid & 63); c <= cmax; c += 64) row[c] -= li * colbuf[c];
+            }
+            __syncthreads();
+        }
+        if (!okc) return false;
+        for (int it = tid; it < nn; it += NT) colbuf[it] = rowp(nn)[it];
+        __syncthreads();
+        if (tid < 64) {
+            const int lane = tid;
+            for (int i = nn - 1; i >= 0; i--) {
+                const double *row = rowp(i);
+                const double xi = colbuf[i] / row[i];
+                for (int t = lane; t < i; t += 64) colbuf[t] -= row[t] * xi;
+                if (lane == 0) colbuf[i] = xi;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        for (int it = tid; it < nn; it += NT) out[it] = colbuf[it];
+        __syncthreads();
+        return true;
+    };
+    // (B) Cholesky of the Hessian (Eigen::LLT in the reference, src/pqn/pqn_optimizer.cpp:52-53), lower, in place, out of L2.
     // Blocked right-looking: a panel of PB columns is factorised in LDS, then the trailing matrix takes ONE pass of
     // read-modify-writes per panel (rows are walked, four rows in flight per wavefront so that the L2 round trips overlap:
     // a column-at-a-time version spent ~1 us of load latency per row and column, 5 ms per factorisation at 216^2).
     // Every entry still has its products subtracted one by one in column order, as the unblocked algorithm does.
     // Returns false (uniformly) on a non-positive pivot.
+    // The right-hand side travels as row nn of the matrix (A has nn + 1 rows of nn columns): after the factorisation that
+    // row holds L^-1 rhs — the forward substitution comes out of the trailing updates for free.
     auto chol_rows = [&](double *A, int nn) -> bool {
-        const int PB = max(1, min(16, kPanelDoubles / nn - 1));   // panel columns: nn rows of PB + 1 doubles fit the LDS panel
-        const int PBS = PB + 1;                                     // row stride (odd for the usual PB = 16: column walks conflict-free)
+        const int PB = max(1, min(16, kPanelDoubles / (nn + 1) - 1));   // panel columns: nn + 1 rows of PB + 1 doubles fit the LDS panel
+        const int PBS = PB + 1;                                           // row stride (odd for the usual PB = 16: column walks conflict-free)
+        const int nr = nn + 1;                                            // rows incl. the right-hand side
         bool okc = true;
         for (int j0 = 0; j0 < nn; j0 += PB) {
-            const int pb = min(PB, nn - j0), nrows = nn - j0;
-            for (int it = tid; it < nrows * pb; it += NT) {          // panel rows j0.., columns j0..j0+pb (lower part)
-                const int rr = it / pb, pc = it - rr * pb;
-                panel[rr * PBS + pc] = (pc <= rr) ? A[(long long)(j0 + rr) * nn + j0 + pc] : 0.0;
+            const int pb = min(PB, nn - j0), nrows = nr - j0;
+            for (int rr = tid >> 4; rr < nrows; rr += NT / 16) {           // panel rows j0.., columns j0..j0+pb (lower part)
+                const int pc = tid & 15;
+                if (pc < pb) panel[rr * PBS + pc] = (pc <= rr) ? A[(long long)(j0 + rr) * nn + j0 + pc] : 0.0;
             }
             __syncthreads();
             for (int pc = 0; pc < pb; pc++) {
@@ -814,32 +886,37 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                 for (int rr = pc + 1 + tid; rr < nrows; rr += NT) panel[rr * PBS + pc] /= l;
                 if (tid == 0) panel[pc * PBS + pc] = l;
                 __syncthreads();
-                const int rest = pb - pc - 1;
-                for (int it = tid; it < (nrows - pc - 1) * rest; it += NT) {
-                    const int rr = pc + 1 + it / rest, p2 = pc + 1 + it % rest;
-                    if (rr >= p2) panel[rr * PBS + p2] -= panel[rr * PBS + pc] * panel[p2 * PBS + pc];
-                }
+                const int p2 = pc + 1 + (tid & 15);
+                if (p2 < pb)
+                    for (int rr = pc + 1 + (tid >> 4); rr < nrows; rr += NT / 16)
+                        if (rr >= p2) panel[rr * PBS + p2] -= panel[rr * PBS + pc] * panel[p2 * PBS + pc];
                 __syncthreads();
             }
-            for (int it = tid; it < nrows * pb; it += NT) {
-                const int rr = it / pb, pc = it - rr * pb;
-                if (pc <= rr) A[(long long)(j0 + rr) * nn + j0 + pc] = panel[rr * PBS + pc];
+            for (int rr = tid >> 4; rr < nrows; rr += NT / 16) {
+                const int pc = tid & 15;
+                if (pc < pb && pc <= rr) A[(long long)(j0 + rr) * nn + j0 + pc] = panel[rr * PBS + pc];
             }
-            // trailing update: rows i >= j0 + pb, columns j0 + pb <= c <= i
+            // trailing update: rows i >= j0 + pb (the right-hand side row included), columns j0 + pb <= c <= min(i, nn - 1)
             const int t0 = j0 + pb, wv = tid >> 6, lane = tid & 63;
-            for (int ib = t0 + 4 * wv; ib < nn; ib += 16) {
-                for (int cb = t0 + lane; cb <= min(ib + 3, nn - 1); cb += 64) {
-                    double v[4];
+            for (int cb = t0 + lane; cb < nn; cb += 64) {
+                double pcv[16];
+                const double *pcp = panel + (cb - j0) * PBS;
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { const int i = ib + u; v[u] = (i < nn && cb <= i) ? A[(long long)i * nn + cb] : 0.0; }
-                    const double *pcv = panel + (cb - j0) * PBS;
+                for (int pc = 0; pc < 16; pc++) pcv[pc] = (pc < pb) ? pcp[pc] : 0.0;
+                // this lane's column cb; rows are uniform over the wavefront (coalesced row segments), starting at the first
+                // column of this 64-column chunk (rows above it lie over the diagonal for every lane), RIF rows in flight
+                for (int ib = (cb - lane) + RIF * wv; ib < nr; ib += 4 * RIF) {
+                    double v[RIF];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < RIF; u++) { const int i = ib + u; v[u] = (i < nr && cb <= i) ? A[(long long)i * nn + cb] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < RIF; u++) {
                         const int i = ib + u;
-                        if (i < nn && cb <= i) {
+                        if (i < nr && cb <= i) {
                             const double *piv = panel + (i - j0) * PBS;
                             double acc = v[u];
-                            for (int pc = 0; pc < pb; pc++) acc -= piv[pc] * pcv[pc];
+#pragma unroll
+                            for (int pc = 0; pc < 16; pc++) if (pc < pb) acc -= piv[pc] * pcv[pc];
                             A[(long long)i * nn + cb] = acc;
                         }
                     }
@@ -849,10 +926,12 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
         return okc;
     };
-    // out = -(L L^T)^-1 rhs by ONE wavefront without barriers: the running vector lives in LDS, a row of L is one
-    // coalesced read (the next row is fetched while the current one is reduced); forward by rows (dot products, wave
-    // reduction), backward right-looking (x_i, then y_t -= L[i][t] x_i over the row).
-    auto solve_rows = [&](const double *Lc, int nn, const double *rhs, double *out) {
+    // out = L^-T y with y = row nn of the factorised matrix (= L^-1 rhs, see chol_rows), by ONE wavefront without
+    // barriers: the running vector lives in LDS, a row of L is one coalesced read (the next row is fetched while the
+    // current one is applied), right-looking: x_i = y_i / L_ii, then y_t -= L[i][t] x_i over the row.
+    auto solve_rows = [&](const double *Lc, int nn, double *out) {
+        for (int it = tid; it < nn; it += NT) colbuf[it] = Lc[(long long)nn * nn + it];
+        __syncthreads();
         if (tid < 64) {
             const int lane = tid;
             constexpr int CH = 4;                       // columns [0, 256) of a row travel in registers
@@ -862,26 +941,6 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
 #pragma unroll
                 for (int c = 0; c < CH; c++) { const int t = lane + 64 * c; dst[c] = (t <= i && t < nn) ? row[t] : 0.0; }
             };
-            fetch(0, cur);
-            for (int i = 0; i < nn; i++) {
-                if (i + 1 < nn) fetch(i + 1, nxt);
-                const double *row = Lc + (long long)i * nn;
-                double sacc = 0;
-#pragma unroll
-                for (int c = 0; c < CH; c++) { const int t = lane + 64 * c; if (t < i) sacc += cur[c] * colbuf[t]; }
-                for (int t = 64 * CH + lane; t < i; t += 64) sacc += row[t] * colbuf[t];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
-                const int owner = i & 63, slot = i >> 6;
-                double dii = (slot < CH) ? 0.0 : row[i];
-#pragma unroll
-                for (int c = 0; c < CH; c++) if (slot == c) dii = __shfl(cur[c], owner, 64);
-                if (lane == 0) colbuf[i] = (-rhs[i] - sacc) / dii;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int c = 0; c < CH; c++) cur[c] = nxt[c];
-            }
             fetch(nn - 1, cur);
             for (int i = nn - 1; i >= 0; i--) {
                 if (i > 0) fetch(i - 1, nxt);
@@ -917,11 +976,21 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             IPT(0);
             hessian();
             IPT(1);
-            const bool hok = chol_rows(Hx, nx);
-            IPT(2);
-            if (!hok) return;
-            solve_rows(Hx, nx, g, dv);     // d = -(L L^T)^-1 g
-            IPT(3);
+            if (hx_lds) {
+                for (int it = tid; it < nx; it += NT) xn[it] = -g[it];
+                __syncthreads();
+                const bool hok = chol_solve_packed(nx, xn, dv);      // d = -(L L^T)^-1 g, all in LDS
+                IPT(2);
+                if (!hok) return;
+            } else {
+                for (int it = tid; it < nx; it += NT) Hx[(long long)nx * nx + it] = -g[it];     // the right-hand side rides along as row nx
+                __syncthreads();
+                const bool hok = chol_rows(Hx, nx);
+                IPT(2);
+                if (!hok) return;
+                solve_rows(Hx, nx, dv);     // d = -(L L^T)^-1 g
+                IPT(3);
+            }
             double gd = 0, da = 0;
             for (int it = tid; it < nx; it += NT) { gd += g[it] * dv[it]; da += fabs(dv[it]); }
             gd = T.sum(gd); da = T.sum(da);
@@ -998,14 +1067,18 @@ int64_t nfr_ip_workspace(int D, int k, int m, int E, int closed, int64_t *hot) {
 int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int64_t hot_max) {
     if (count <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    // dynamic LDS for the hot buffers of the largest blanket that fits next to the 84 KB of static LDS (panel, solve vector)
-    const size_t lds = (size_t)std::min<int64_t>(hot_max * 8, 72 * 1024);
+    // dynamic LDS next to the 18 KB of static LDS: as much as the device gives one workgroup (packed Hessians up to
+    // ~185 variables live there; otherwise the factorisation panel and, if they fit, the hot small matrices)
+    (void)hot_max;
+    const size_t lds = 140 * 1024;
     a.lds_doubles = (int)(lds / 8);
     const void *fn = D == 6 ? reinterpret_cast<const void *>(nfr_ip_kernel<6>) : reinterpret_cast<const void *>(nfr_ip_kernel<3>);
-    if (lds > 40 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); a.lds_doubles = 0; }
-    const size_t use = a.lds_doubles ? lds : 0;
-    if (D == 6) hipLaunchKernelGGL((nfr_ip_kernel<6>), dim3(count), dim3(NT), use, s, a);
-    else hipLaunchKernelGGL((nfr_ip_kernel<3>), dim3(count), dim3(NT), use, s, a);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return SPG_EHIP;
+    }
+    if (D == 6) hipLaunchKernelGGL((nfr_ip_kernel<6>), dim3(count), dim3(NT), lds, s, a);
+    else hipLaunchKernelGGL((nfr_ip_kernel<3>), dim3(count), dim3(NT), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : SPG_EHIP;
 }
 
