@@ -1967,8 +1967,10 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
                 const bool ip = k >= 3 && !cliquey && E > k - 1;           // uncorrelated pattern without a closed form
                 // correlated patterns (and any blanket that holds a correlated edge) take the same generic kernel's closed form
                 if (ip || (cliquey && k >= 3) || (has_multi && k >= 2)) {
-                    if ((ip && (int64_t)D * D * E > 2048) || k > 64) {
-                        snprintf(err, sizeof hb->err, "interior-point / correlated NFR: a blanket with k=%d kept vertices and %d new measurements is beyond the generic kernel (Hessian limit 2048^2, k <= 64)", k, E);
+                    const int msub = (int)((1 + o.chord_ratio) * (k - 1));
+                    const bool masks = o.topology == SPG_TOPO_CLIQUEY_SUBGRAPH && msub < k * (k - 1) / 2;   // fillCliques on 64-bit vertex masks
+                    if ((ip && (int64_t)D * D * E > 2048) || (masks && k > 64) || k > 256) {
+                        snprintf(err, sizeof hb->err, "interior-point / correlated NFR: a blanket with k=%d kept vertices and %d new measurements is beyond the generic kernel (Hessian limit 2048^2; k <= 64 for CliqueySubgraph, 256 otherwise)", k, E);
                         return SPG_ECAPACITY;
                     }
                     ip_list.push_back(b);

@@ -43,7 +43,7 @@ constexpr int kPanelDoubles = 8192;   // 64 KB: 16 columns of a panel up to 480 
 struct IpLayout {   // offsets (doubles) of one blanket's buffers: a cold part in the global workspace, a hot part (everything the
                     // Newton iterations touch except the Hessian) relative to its own base — LDS when it fits, else behind the cold part
     int n, nm, N, r, E, q, nx;
-    int64_t H, Lam, A1, V, Hx, pose, w, Sc, zbuf, grp, otab, cold_total;
+    int64_t H, Lam, A1, V, Hx, pose, w, Sc, zbuf, grp, otab, ibuf, cold_total;
     int64_t S, U, J, JU, Ai, T1, M, Mc, Mi, Li, Y, P, T2, x, xn, g, gn, dv, Xi, hot_total;
     int64_t total;
 };
@@ -58,6 +58,7 @@ __host__ __device__ inline IpLayout ip_layout(int D, int k, int m, int E, bool c
     L.pose = take(12 * (int64_t)(k + m)); L.w = take(4 * P2 + 8);
     L.Sc = take(3 * N * N + 5 * n * n);            // correlated input edges (J, W J), closed form of correlated new edges (J_e, G, C, W, X)
     L.zbuf = take(7 * (int64_t)(E + 1)); L.grp = take(2 * (int64_t)k + 8); L.otab = take(8 * (int64_t)k + 8);
+    L.ibuf = take(4 * (int64_t)k + 16);             // ints: Kruskal components (k), regrouped measurement list (2 k), vertex list of a record (k)
     L.cold_total = o;
     o = 0;
     L.S = take(n); L.U = take(n * r); L.J = take(2 * (int64_t)D * D * E); L.JU = take(q * r); L.Ai = take(n * n); L.T1 = take(n * r);
@@ -328,22 +329,18 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             };
             const int vi[1] = {i}, vj[1] = {j}, vij[2] = {i, j};
             const double li = ld_of(vi, 1), lj = ld_of(vj, 1), lij = ld_of(vij, 2);
-            w[p] = (li + lj) - lij;
+            w[p] = -((li + lj) - lij);      // stored negated: ascending sort == max-heap pop order
             if (!isfinite(w[p])) flag_s = 1;
         }
         __syncthreads();
         if (flag_s) { status = SPG_ST_TIKHONOV_NOT_PD; finish(); return; }
+        // pop order: weight descending, ties by (i, j) ascending = index ascending (rank by counting, all lanes: a
+        // serial sort of the k (k - 1) / 2 weights of a 100-vertex cluster would take seconds)
+        sort_ascending<NT>(T, w, 1, P2, pij + 2 * P2);
+        __syncthreads();
         if (tid == 0) {
-            // pop order: weight descending, ties by (i, j) ascending = index ascending
             int *order = pij + 2 * P2;     // P2 ints (inside the 4 P2 + 8 doubles reserved at L.w)
-            for (int p = 0; p < P2; p++) order[p] = p;
-            for (int x = 1; x < P2; x++) {
-                const int v = order[x];
-                int y = x - 1;
-                while (y >= 0 && (w[order[y]] < w[v] || (w[order[y]] == w[v] && order[y] > v))) { order[y + 1] = order[y]; y--; }
-                order[y + 1] = v;
-            }
-            int comp[64];
+            int *comp = reinterpret_cast<int *>(ws + L.ibuf);
             for (int v = 0; v < k; v++) comp[v] = v;
             int nacc = 0, nrej = 0, last = 0;
             int *rej = order + P2;         // rejected pair indices, in pop order (P2 more ints)
@@ -363,14 +360,19 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                 // cliques as bit masks over the k <= 64 kept vertices. grp: [0] number of groups, [1 + g] start of group g
                 // in the regrouped measurement list, which replaces pairs[] (bin order inside a group).
                 int *grp = reinterpret_cast<int *>(ws + L.grp);
+                int *tmp = reinterpret_cast<int *>(ws + L.ibuf) + k;
                 const int msub = (int)((1 + a.chord_ratio) * (k - 1));
+                if (a.topology == SPG_TOPO_CLIQUEY_DENSE || msub >= k * (k - 1) / 2) {
+                    // one fully correlated edge over the whole tree, in bin order (any k)
+                    grp[0] = 1; grp[1] = 0; grp[2] = k - 1;
+                    si[1] = k - 1;
+                } else if (k > 64) {
+                    si[1] = -1;     // the clique masks below hold 64 vertices
+                } else {
                 unsigned long long mask[64];
                 int ncl = k - 1;
                 for (int i = 0; i < ncl; i++) mask[i] = (1ull << pairs[2 * i]) | (1ull << pairs[2 * i + 1]);
-                if (a.topology == SPG_TOPO_CLIQUEY_DENSE || msub >= k * (k - 1) / 2) {
-                    ncl = 1;
-                    mask[0] = (k >= 64) ? ~0ull : ((1ull << k) - 1);
-                } else {
+                {
                     bool joined = true;
                     for (int nedges = k - 1, maxfill = 1; nedges < msub && joined; maxfill++) {
                         joined = false;
@@ -392,24 +394,25 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                         if (!joined && minfill > maxfill) { joined = true; maxfill = minfill - 1; }
                     }
                 }
-                int tmp[128], nout = 0;
+                int nout = 0;
                 grp[0] = ncl;
                 for (int gidx = 0; gidx < ncl; gidx++) {
                     grp[1 + gidx] = nout;
                     for (int i = 0; i < k - 1; i++)
                         if (((mask[gidx] >> pairs[2 * i]) & 1) && ((mask[gidx] >> pairs[2 * i + 1]) & 1)) {
-                            if (nout < 64) { tmp[2 * nout] = pairs[2 * i]; tmp[2 * nout + 1] = pairs[2 * i + 1]; }
+                            if (nout < k - 1) { tmp[2 * nout] = pairs[2 * i]; tmp[2 * nout + 1] = pairs[2 * i + 1]; }
                             nout++;
                         }
                 }
                 grp[1 + ncl] = nout;
                 si[1] = nout;
                 if (nout == k - 1) for (int i = 0; i < 2 * nout; i++) pairs[i] = tmp[i];
+                }
             }
             const int upto = min(last + 1, P2 - 1);
             double g = __builtin_inf();
             for (int s = 0; s < upto; s++) {
-                const double x = w[order[s]], y = w[order[s + 1]];
+                const double x = -w[order[s]], y = -w[order[s + 1]];
                 const double den = fmax(fmax(fabs(x), fabs(y)), 1e-300);
                 g = fmin(g, (x - y) / den);
             }
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                 rel += REC; nvt += 2;
             } else {
                 if (tid == 0) {
-                    int lv[64], nq = 0;
+                    int *lv = reinterpret_cast<int *>(ws + L.ibuf) + 3 * k, nq = 0;
                     rec[0] = (double)nmg;
                     for (int i = 0; i < nmg; i++)
                         for (int side = 0; side < 2; side++) {
