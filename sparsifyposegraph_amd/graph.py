@@ -118,6 +118,13 @@ class GraphWrapperHIP:
         meas = np.ascontiguousarray(meas, np.float64)
         check(self.L.spg_graph_add_glc_edge(self.h, len(ids), _p(ids, C.c_int32), W.shape[0], _p(meas, C.c_double), _p(W, C.c_double)), self.ctx.h, "addGLCEdge")
 
+    def addMultiEdge(self, ids, record):
+        """MultiEdgeCorrelated over the vertices `ids` (src/multi_edge_correlated.hpp:28-63); `record` in the
+        SPG_EDGE_MULTI layout of include/spg.h: nm | vertex pair of each measurement | measurements | W (information W^T W)."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        record = np.ascontiguousarray(record, np.float64)
+        check(self.L.spg_graph_add_multi_edge(self.h, len(ids), _p(ids, C.c_int32), _p(record, C.c_double), len(record)), self.ctx.h, "addMultiEdge")
+
     def setEstimate(self, vertexid, est):
         est = np.ascontiguousarray(est, np.float64)
         check(self.L.spg_graph_set_estimate(self.h, int(vertexid), _p(est, C.c_double)), self.ctx.h, "setEstimate")

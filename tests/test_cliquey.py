@@ -133,3 +133,51 @@ def test_device_whole_graph_with_correlated_edges(case, n, topo, chord, hip_ctx)
     assert c_dev == pytest.approx(c_ref, rel=1e-9, abs=1e-12)
     n_multi = int((og.edges()["kind"] == abi.EDGE_MULTI).sum())
     print(f"{case} topo={topo}: {n_multi} correlated edges in the result, worst edge rel err {worst:.1e}, global KLD {kld:.3e} (oracle {r['kld']:.3e})")
+
+
+@pytest.mark.parametrize("case,d", [("manhattan_nfr_tree", 3), ("sphere_nfr_tree", 6)])
+def test_host_path_with_correlated_edges(case, d, tmp_path):
+    """CPU: the product's host code (round scheduler, budgets, commit, clonePortion, .g2o writer) with the oracle injected as
+    the arithmetic: CliqueyDense through spg_graph_marginalize equals the oracle's own sequential run, the written file
+    holds MULTI_EDGE_* lines in the reference's format (src/multi_edge_correlated.hpp:227-267: '|| nmeas nrelevant
+    measurements information-upper'), a clone carries the correlated edges, spg_graph_add_multi_edge validates its input."""
+    from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    from sparsifyposegraph_amd.lib import SpgError
+    g, which, opts, *_ = util.load_golden(case)
+    sub, w = util.prefix_graph(g, which, 120)
+    o = _opts(d, abi.TOPO_CLIQUEY_DENSE)
+    hg = GraphWrapperHIP.from_dict(sub, ctx=oracle_lib.injected_context())
+    st = hg.marginalizeNoOptimize(w, o)
+    og = oracle_lib.OracleGraph.from_dict(sub)
+    assert og.marginalize(w, o) == 0 and st["n_bad_status"] == 0
+    util.compare_edge_sets(d, og.edges(), hg.edges(), rtol=1e-12)
+    e = hg.edges()
+    multi = np.nonzero(e["kind"] == abi.EDGE_MULTI)[0]
+    assert len(multi) >= 2
+    lines = [l for l in hg.writeString().splitlines() if l.startswith("MULTI_EDGE")]
+    assert len(lines) == len(multi)
+    ps = abi.pose_stride(d)
+    for l in lines:
+        t = l.split()
+        assert t[0] == ("MULTI_EDGE_SE2" if d == 3 else "MULTI_EDGE_SE3")
+        bar = t.index("||")
+        q, nm, nrel = bar - 1, int(t[bar + 1]), int(t[bar + 2])
+        r = d * nm
+        assert nrel == ps and nm == q - 1 and len(t) == bar + 3 + nm * ps + r * (r + 1) // 2
+    # clonePortion keeps the correlated edges whose vertices survive the cut
+    top = int(max(hg.vertices()[0]))
+    clone = hg.clonePortion(top, optimize=False)     # (optimize() is a device path)
+    util.compare_edge_sets(d, hg.edges(), clone.edges(), rtol=0)
+    # add_multi_edge: a record of the wrong length / a measurement that points outside the edge is refused
+    i0 = multi[0]
+    ids = e["vert_ids"][e["vert_off"][i0]:e["vert_off"][i0 + 1]]
+    rec = e["data"][e["data_off"][i0]:e["data_off"][i0 + 1]].copy()
+    fresh = GraphWrapperHIP.from_dict(sub, ctx=oracle_lib.injected_context())
+    fresh.addMultiEdge(ids, rec)
+    assert fresh.numEdges() == len(sub["edge_ij"]) + 1
+    with pytest.raises(SpgError):
+        fresh.addMultiEdge(ids, rec[:-1])
+    bad = rec.copy()
+    bad[1] = len(ids)
+    with pytest.raises(SpgError):
+        fresh.addMultiEdge(ids, bad)
