@@ -43,7 +43,7 @@ constexpr int kPanelDoubles = 8192;   // 64 KB: 16 columns of a panel up to 480 
 struct IpLayout {   // offsets (doubles) of one blanket's buffers: a cold part in the global workspace, a hot part (everything the
                     // Newton iterations touch except the Hessian) relative to its own base — LDS when it fits, else behind the cold part
     int n, nm, N, r, E, q, nx;
-    int64_t H, Lam, A1, V, Hx, pose, w, Sc, zbuf, grp, otab, ibuf, cold_total;
+    int64_t H, Lam, A1, V, Hx, pose, w, Sc, zbuf, grp, otab, ibuf, Ng, cold_total;
     int64_t S, U, J, JU, Ai, T1, M, Mc, Mi, Li, Y, P, T2, x, xn, g, gn, dv, Xi, hot_total;
     int64_t total;
 };
@@ -58,6 +58,7 @@ __host__ __device__ inline IpLayout ip_layout(int D, int k, int m, int E, bool c
     L.pose = take(12 * (int64_t)(k + m)); L.w = take(4 * P2 + 8);
     L.Sc = take(3 * N * N + 5 * n * n);            // correlated input edges (J, W J), closed form of correlated new edges (J_e, G, C, W, X)
     L.zbuf = take(7 * (int64_t)(E + 1)); L.grp = take(2 * (int64_t)k + 8); L.otab = take(8 * (int64_t)k + 8);
+    L.Ng = take(n * D);                             // orthonormal gauge basis (closed-form path)
     L.ibuf = take(4 * (int64_t)k + 16);             // ints: Kruskal components (k), regrouped measurement list (2 k), vertex list of a record (k)
     L.cold_total = o;
     o = 0;
@@ -452,8 +453,105 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     }
     __syncthreads();
     // sparseJacobian() drops entries below epsilon (src/logdet_function.cpp:335); it feeds J U of the Hessian
-    // ---- spectrum of the target (src/logdet_function.cpp:14-64)
     double *A1 = ws + L.A1, *Vv = ws + L.V, *Sv = hot + L.S, *U = hot + L.U;
+    // ---- closed-form path, gauge route (as blanket_kernel): Lambda_t of relative-pose edges has the rigid motions
+    // of the blanket as its exact null space; with N^ an orthonormal basis of it and C = Lambda_t + N^ N^^T (SPD):
+    //   U S U^T = C^-1 - N^ N^^T,  J_e N^ = 0 => J_e Sigma J_e^T = J_e C^-1 J_e^T,  log det S = -log det C,
+    //   tr(S M) = tr(C^-1 A),  log det(U^T A U) = log det(A + N^ N^^T)
+    // — Cholesky-class work instead of the Jacobi sweeps below (a 600 x 600 target of a Dense cluster: seconds of them).
+    // Taken only if trace(C^-1) < 5e4, which proves lambda_{d+1}(Lambda_t) > 1e-5, the reference's `smalleigs <= dim` branch.
+    bool gauge_ok = false;
+    double logdetC = 0;
+    double *Ng = ws + L.Ng;
+    if (closed) {
+        for (int v = tid; v < k; v += NT) {
+            const double *X = pose + (m + v) * PSZ;
+            double *Gv = Ng + v * DD;
+            if (D == 6) {
+                for (int rr = 0; rr < 3; rr++)
+                    for (int c = 0; c < 3; c++) {
+                        // rows of vertex v: [R^T | -R^T [t]x ; 0 | 1/2 R^T]  (update X <- X * fromVectorMQT(delta))
+                        const int ca = (c + 1) % 3, cb = (c + 2) % 3;
+                        const double rt = X[c * 3 + rr];
+                        const double cx_a = X[9 + cb], cx_b = -X[9 + ca];
+                        const double val = -(X[ca * 3 + rr] * cx_a + X[cb * 3 + rr] * cx_b);
+                        Gv[rr * 6 + c] = rt;
+                        Gv[rr * 6 + 3 + c] = val;
+                        Gv[(3 + rr) * 6 + c] = 0.0;
+                        Gv[(3 + rr) * 6 + 3 + c] = 0.5 * rt;
+                    }
+            } else {
+                Gv[0] = 1; Gv[1] = 0; Gv[2] = -X[1];
+                Gv[3] = 0; Gv[4] = 1; Gv[5] = X[0];
+                Gv[6] = 0; Gv[7] = 0; Gv[8] = 1;
+            }
+        }
+        __syncthreads();
+        double *nn_s = hot + L.T2;       // D x D: N^T N, then L^-1 of its Cholesky factor
+        if (tid < DD) {
+            const int rr = tid / D, c = tid - rr * D;
+            double sacc = 0;
+            for (int i = 0; i < n; i++) sacc += Ng[i * D + rr] * Ng[i * D + c];
+            nn_s[tid] = sacc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double Ab[DD], Lin[DD];
+            for (int i = 0; i < DD; i++) Ab[i] = nn_s[i];
+            si[3] = chol_serial(Ab, D, D) ? 1 : 0;
+            for (int c = 0; c < D; c++)
+                for (int i = 0; i < D; i++) {
+                    if (i < c) Lin[i * D + c] = 0.0;
+                    else if (i == c) Lin[i * D + c] = 1.0 / Ab[c * D + c];
+                    else {
+                        double sacc = 0;
+                        for (int qq = c; qq < i; qq++) sacc += Ab[i * D + qq] * Lin[qq * D + c];
+                        Lin[i * D + c] = -sacc / Ab[i * D + i];
+                    }
+                }
+            for (int i = 0; i < DD; i++) nn_s[DD + i] = Lin[i];
+        }
+        __syncthreads();
+        bool gfail = si[3] == 0;
+        for (int i = tid; i < n; i += NT) {
+            double nv_[D];
+            for (int c = 0; c < D; c++) {
+                double sacc = 0;
+                for (int qq = 0; qq <= c; qq++) sacc += Ng[i * D + qq] * nn_s[DD + c * D + qq];
+                nv_[c] = sacc;
+            }
+            for (int c = 0; c < D; c++) Ng[i * D + c] = nv_[c];
+        }
+        __syncthreads();
+        for (int it = tid; it < n * n; it += NT) {
+            const int i = it / n, j = it - i * n;
+            double sacc = Lam[it];
+            for (int qq = 0; qq < D; qq++) sacc += Ng[i * D + qq] * Ng[j * D + qq];
+            A1[it] = sacc;
+        }
+        if (tid == 0) flag_s = 0;
+        __syncthreads();
+        chol_lower<NT>(T, A1, n, n);
+        gfail |= flag_s != 0;
+        __syncthreads();
+        if (tid == 0) flag_s = 0;
+        __syncthreads();
+        if (!gfail) {
+            double l = 0;
+            for (int i = tid; i < n; i += NT) l += log(A1[i * n + i]);
+            logdetC = 2.0 * T.sum(l);
+            double *Cinv = hot + L.Y;
+            tri_inverse_lower<NT>(T, A1, Vv, n, n);
+            gram_lower_inverse<NT>(T, Vv, Cinv, n, n);
+            double trc = 0;
+            for (int i = tid; i < n; i += NT) trc += Cinv[i * n + i];
+            trc = T.sum(trc);
+            gauge_ok = isfinite(trc) && trc < 5e4 && isfinite(logdetC);
+        }
+    }
+    // ---- spectrum of the target (src/logdet_function.cpp:14-64): the interior point needs U and S; the closed form only
+    // when the gauge route did not apply
+    if (!gauge_ok) {
     for (int it = tid; it < n * n; it += NT) A1[it] = Lam[it];
     __syncthreads();
     if (!jacobi_eigh<NT>(T, A1, Vv, n, n, hot + L.T1)) { status = SPG_ST_EIG_FAIL; finish(); return; }
@@ -464,17 +562,61 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         double small = 0;
         for (int i = tid; i < n; i += NT) if (A1[i * (n + 1)] < 1e-5) small += 1;
         const int smalleigs = (int)T.sum(small);
-        if (smalleigs > D) { status = SPG_ST_UNSUPPORTED; info |= SPG_INFO_RANK_DEFICIENT; finish(); return; }   // chooseDimensions branch
+        if (smalleigs > D) {
+            // chooseDimensions (src/logdet_function.cpp:40-59,66-81): of the candidate directions (eigenvalues below the cutoff)
+            // drop the d whose image under the new measurements' Jacobian is smallest; keep the others with clamped 1 / lambda
+            info |= SPG_INFO_RANK_DEFICIENT;
+            double *norms = hot + L.T1 + n;          // (behind the n ints of perm)
+            int *keepidx = reinterpret_cast<int *>(hot + L.T1 + 2 * n);
+            for (int c = tid; c < smalleigs; c += NT) {
+                const int col = perm[c];
+                double nrm2 = 0;
+                for (int e = 0; e < E; e++) {
+                    const int oa = pairs[2 * e] * D, ob = pairs[2 * e + 1] * D;
+                    const double *Ja = Jb + e * 2 * DD, *Jbb = Ja + DD;
+                    for (int p = 0; p < D; p++) {
+                        double sacc = 0;
+                        for (int t = 0; t < D; t++) {
+                            const double ja = Ja[p * D + t], jb = Jbb[p * D + t];
+                            if (fabs(ja) >= 2.220446049250313e-16) sacc += ja * Vv[(oa + t) * n + col];
+                            if (fabs(jb) >= 2.220446049250313e-16) sacc += jb * Vv[(ob + t) * n + col];
+                        }
+                        nrm2 += sacc * sacc;
+                    }
+                }
+                norms[c] = sqrt(nrm2);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                // the d smallest (norm, index) pairs are dropped; the kept eigenpairs stay in ascending eigenvalue order
+                for (int c = 0; c < smalleigs; c++) keepidx[n + c] = 0;            // dropped flags
+                for (int t = 0; t < D; t++) {
+                    int best = -1;
+                    for (int c = 0; c < smalleigs; c++)
+                        if (!keepidx[n + c] && (best < 0 || norms[c] < norms[best])) best = c;
+                    keepidx[n + best] = 1;
+                }
+                int j = 0;
+                for (int i = 0; i < n; i++) if (!(i < smalleigs && keepidx[n + i])) keepidx[j++] = i;
+            }
+            __syncthreads();
+            const double wmax = A1[perm[n - 1] * (n + 1)];
+            for (int j = tid; j < r; j += NT) { const double wv = A1[perm[keepidx[j]] * (n + 1)]; Sv[j] = fmin(fabs(1.0 / wv), 1e6 / wmax); }
+            for (int it = tid; it < n * r; it += NT) { const int i = it / r, j = it - i * r; U[it] = Vv[i * n + perm[keepidx[j]]]; }
+            __syncthreads();
+        } else {
         for (int j = tid; j < r; j += NT) Sv[j] = 1.0 / A1[perm[D + j] * (n + 1)];
         for (int it = tid; it < n * r; it += NT) { const int i = it / r, j = it - i * r; U[it] = Vv[i * n + perm[D + j]]; }
         __syncthreads();
+        }
+    }
     }
     double logdetS = 0;
-    {
+    if (!gauge_ok) {
         double l = 0;
         for (int j = tid; j < r; j += NT) l += log(Sv[j]);
         logdetS = T.sum(l);
-    }
+    } else logdetS = -logdetC;
     double *Ai = hot + L.Ai, *T1 = hot + L.T1, *M = hot + L.M, *Mc = hot + L.Mc, *Mi = hot + L.Mi, *Li = hot + L.Li, *Y = hot + L.Y;
     // LogdetFunction::value (src/logdet_function.cpp:119-133) of the product information held in Ai (full symmetric):
     // M = U^T A U, 1/2 (tr(M S) - log det M - log det S - r); leaves chol(M) in Mc
@@ -515,12 +657,14 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         // one SPG_EDGE_MULTI record per group with more than one measurement (src/topology_provider_binary.hpp:48-67)
         const int *grp = reinterpret_cast<const int *>(ws + L.grp);
         const int ng = grp[0];
-        double *Sig = Y, *otab = ws + L.otab;
-        for (int it = tid; it < n * r; it += NT) { const int c = it % r; T1[it] = U[it] * Sv[c]; }
-        __syncthreads();
-        for (int it = tid; it < n * n; it += NT) {
-            const int i = it / n, j = it - i * n;
-            if (j <= i) { double sacc = 0; for (int t = 0; t < r; t++) sacc += T1[i * r + t] * U[j * r + t]; Sig[i * n + j] = sacc; Sig[j * n + i] = sacc; }
+        double *Sig = Y, *otab = ws + L.otab;      // gauge route: Y already holds C^-1, which stands in for Sigma
+        if (!gauge_ok) {
+            for (int it = tid; it < n * r; it += NT) { const int c = it % r; T1[it] = U[it] * Sv[c]; }
+            __syncthreads();
+            for (int it = tid; it < n * n; it += NT) {
+                const int i = it / n, j = it - i * n;
+                if (j <= i) { double sacc = 0; for (int t = 0; t < r; t++) sacc += T1[i * r + t] * U[j * r + t]; Sig[i * n + j] = sacc; Sig[j * n + i] = sacc; }
+            }
         }
         for (int it = tid; it < n * n; it += NT) Ai[it] = 0.0;
         __syncthreads();
@@ -620,7 +764,30 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             __syncthreads();
         }
         bool okc = false;
-        const double fv = value_from_A(okc);
+        double fv;
+        if (gauge_ok) {
+            // 1/2 (tr(C^-1 A) - log det(A + N^ N^^T) + log det C - r)
+            double tr = 0;
+            for (int it = tid; it < n * n; it += NT) tr += Sig[it] * Ai[it];
+            tr = T.sum(tr);
+            for (int it = tid; it < n * n; it += NT) {
+                const int i = it / n, j = it - i * n;
+                double sacc = Ai[it];
+                for (int qq = 0; qq < D; qq++) sacc += Ng[i * D + qq] * Ng[j * D + qq];
+                A1[it] = sacc;
+            }
+            if (tid == 0) flag_s = 0;
+            __syncthreads();
+            chol_lower<NT>(T, A1, n, n);
+            okc = flag_s == 0;
+            __syncthreads();
+            if (tid == 0) flag_s = 0;
+            __syncthreads();
+            double l = 0;
+            for (int i = tid; i < n; i += NT) l += log(A1[i * n + i]);
+            l = T.sum(l);
+            fv = okc ? 0.5 * (tr - 2.0 * l + logdetC - r) : __builtin_inf();
+        } else fv = value_from_A(okc);
         tab_mode = true;
         n_new = ng;
         if (!okc || !isfinite(fv)) { status = SPG_ST_KLD_NOT_PD; kld = __builtin_nan(""); finish(); return; }

@@ -181,3 +181,26 @@ def test_host_path_with_correlated_edges(case, d, tmp_path):
     bad[1] = len(ids)
     with pytest.raises(SpgError):
         fresh.addMultiEdge(ids, bad)
+
+
+@pytest.mark.gpu
+def test_device_rank_deficient_blankets_choose_dimensions(hip_ctx):
+    """parking.g2o at full size under CliqueySubgraph(0.5): six of the 828 blankets have more than d eigenvalues below the
+    cutoff, the reference's chooseDimensions branch (src/logdet_function.cpp:40-59,66-81) — the generic kernel's eigen route;
+    everything else takes its gauge route. Statuses, rank-deficiency flags, every KLD and the whole graph equal the oracle's."""
+    from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    g, which, opts, *_ = util.load_golden("parking_full_nfr_tree")
+    o = _opts(6, abi.TOPO_CLIQUEY_SUBGRAPH, 0.5)
+    hg = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+    st = hg.marginalizeNoOptimize(which, o)
+    og = oracle_lib.OracleGraph.from_dict(g)
+    assert og.marginalize(which, o) == 0 and st["n_bad_status"] == 0
+    hb, ob = hg.blankets(), og.blankets()
+    at = {int(r): i for i, r in enumerate(hb["root"])}
+    idx = np.array([at[int(r)] for r in ob["root"]])
+    assert np.array_equal(ob["status"], hb["status"][idx])
+    assert int((ob["info"] & 1).sum()) >= 3 and np.array_equal(ob["info"] & 1, hb["info"][idx] & 1)
+    fin = np.isfinite(ob["kld"])
+    assert np.abs(ob["kld"][fin] - hb["kld"][idx][fin]).max() <= 1e-9
+    worst = util.compare_edge_sets(6, og.edges(), hg.edges(), rtol=1e-9)
+    print(f"parking full, CliqueySubgraph(0.5): {int((ob['info'] & 1).sum())} rank-deficient blankets, worst edge rel err {worst:.1e}")
