@@ -637,6 +637,17 @@ extern "C" void *spg_graph_arena(spg_graph *g, int64_t *capacity) {
 extern "C" int spg_graph_reserve(spg_graph *g, int64_t arena_doubles) {
     if (!g) return SPG_EINVAL;
     if (int rc = arena_ensure(g, std::max(arena_doubles, g->used))) return rc;
+    // The host mirror is reserved AND touched up to the same size: the commit copies every batch's out records into it,
+    // and a first touch there is a page fault inside the timed path — with transparent huge pages a 2 MB zero-fill
+    // (~100 us) per fault, ~150 of them per 100 k-pose marginalisation on the mirrors the kernel happened to back with
+    // huge pages (measured: 25 ms per call on some graphs, 55 ms on others, device time identical).
+    if ((int64_t)g->host.size() < g->cap) g->host.resize((size_t)g->cap);
+    // the same for the containers a marginalisation appends to: room for as many new edges as there are now, touched
+    {
+        const size_t ne = g->edges.size(), nl = g->log.size();
+        g->edges.resize(2 * ne + 1024); g->edges.resize(ne);
+        g->log.resize(g->vid.size() + 16); g->log.resize(nl);
+    }
     return sync_device(g);
 }
 
