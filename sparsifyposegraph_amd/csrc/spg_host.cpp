@@ -647,6 +647,17 @@ extern "C" int spg_graph_reserve(spg_graph *g, int64_t arena_doubles) {
         const size_t ne = g->edges.size(), nl = g->log.size();
         g->edges.resize(2 * ne + 1024); g->edges.resize(ne);
         g->log.resize(g->vid.size() + 16); g->log.resize(nl);
+        // and the scheduler's own scratch, to the sizes a few hundred blankets per batch need (they grow past that as ever)
+        auto touch = [](auto &v, size_t n) { if (v.capacity() < n) { const size_t keep = v.size(); v.resize(n); v.resize(keep); } };
+        const size_t nv = g->vid.size();
+        for (int i = 0; i < spg_graph::NB; i++) {
+            Batch &b = g->bt[i];
+            touch(b.rb, 1024); touch(b.rb_verts, 16384); touch(b.rb_edges, 32768); touch(b.h_blk, 1024); touch(b.h_vpo, 16384);
+            touch(b.h_er, 32768); touch(b.h_ev, 65536); touch(b.kld_pending, 1024);
+        }
+        touch(g->pending, nv); touch(g->in_set, nv); touch(g->vstamp, nv); touch(g->estamp, 2 * ne + 1024);
+        touch(g->owners, 8192); touch(g->ocnt, 8192); touch(g->owner_free, 8192); touch(g->transient, 4096); touch(g->Dpool, 65536);
+        touch(g->s_newpending, 4096); touch(g->hdr_buf, 65536);
     }
     return sync_device(g);
 }

@@ -33,9 +33,12 @@ for i, r in enumerate(reps):
         for _ in range(int(os.environ["INTERLEAVE"])): GraphWrapperHIP.from_dict(small, ctx=ctx).marginalizeNoOptimize(sw, opts)
     if os.environ.get("SLEEP_MS"): time.sleep(float(os.environ["SLEEP_MS"]) * 1e-3)
     ctx.synchronize()
+    import resource
+    f0 = resource.getrusage(resource.RUSAGE_SELF).ru_minflt
     t0 = time.perf_counter()
     st = r.marginalizeNoOptimize(which, opts)
     t1 = time.perf_counter()
+    print(f"  minor page faults during the call: {resource.getrusage(resource.RUSAGE_SELF).ru_minflt - f0}", flush=True)
     ctx.synchronize()
     t2 = time.perf_counter()
     import ctypes as C
