@@ -277,6 +277,9 @@ public:
         check(spg_graph_load_g2o(_ctx->h, fname, &_g), "spg_graph_load_g2o");
         if (optimizeAtLoad) optimize();
     }
+    // dense / block-sparse factorisation behind optimize() and kullbackLeibler() of this wrapper's context (SPG_SOLVER_AUTO by
+    // default: by size) — CHOLMOD's / SimplicialLLT's role in src/graph_wrapper_g2o.cpp:250-269,531-548
+    void setLinearSolver(int solver) { check(spg_ctx_set_linear_solver(_ctx->h, solver), "spg_ctx_set_linear_solver"); }
     GraphWrapperHIP(const GraphWrapperHIP &) = delete;
     GraphWrapperHIP &operator=(const GraphWrapperHIP &) = delete;
     ~GraphWrapperHIP() override {
