@@ -279,6 +279,8 @@ public:
     }
     // dense / block-sparse factorisation behind optimize() and kullbackLeibler() of this wrapper's context (SPG_SOLVER_AUTO by
     // default: by size) — CHOLMOD's / SimplicialLLT's role in src/graph_wrapper_g2o.cpp:250-269,531-548
+    // arena capacity up front + the host-side buffers of a marginalisation sized and touched (include/spg.h: spg_graph_reserve)
+    void reserve(long long arena_doubles) { check(spg_graph_reserve(_g, arena_doubles), "spg_graph_reserve"); }
     void setLinearSolver(int solver) { check(spg_ctx_set_linear_solver(_ctx->h, solver), "spg_ctx_set_linear_solver"); }
     GraphWrapperHIP(const GraphWrapperHIP &) = delete;
     GraphWrapperHIP &operator=(const GraphWrapperHIP &) = delete;
