@@ -36,6 +36,10 @@ CASES = [
     # configs 3 and 4 at full size
     ("sphere_full_nfr_tree", "sphere.g2o", 2499, abi.ALG_NFR, abi.TOPO_TREE, ("sparsity", 2)),
     ("parking_full_nfr_tree", "parking.g2o", 1660, abi.ALG_NFR, abi.TOPO_TREE, ("sparsity", 2)),
+    # correlated NFR patterns (MultiEdgeCorrelated edges, SPG_EDGE_MULTI): one fully correlated edge per (clustered) blanket,
+    # and the partially correlated cliques of fillCliques at chord ratio 1
+    ("manhattan_cliquey_dense", "manhattan.g2o", 499, abi.ALG_NFR, abi.TOPO_CLIQUEY_DENSE, ("sparsity", 2)),
+    ("sphere_cliquey_subgraph", "sphere.g2o", 399, abi.ALG_NFR, abi.TOPO_CLIQUEY_SUBGRAPH, ("sparsity", 2)),
 ]
 
 

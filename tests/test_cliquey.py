@@ -204,3 +204,17 @@ def test_device_rank_deficient_blankets_choose_dimensions(hip_ctx):
     assert np.abs(ob["kld"][fin] - hb["kld"][idx][fin]).max() <= 1e-9
     worst = util.compare_edge_sets(6, og.edges(), hg.edges(), rtol=1e-9)
     print(f"parking full, CliqueySubgraph(0.5): {int((ob['info'] & 1).sum())} rank-deficient blankets, worst edge rel err {worst:.1e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["manhattan_cliquey_dense", "sphere_cliquey_subgraph"])
+def test_device_reproduces_correlated_fixtures(case, hip_ctx):
+    """The committed fixtures (tests/golden/make_golden.py: oracle outputs on dataset prefixes) carry the bar to the GPU box."""
+    from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    g, which, opts, gold_edges, gold_bl, gold_vids = util.load_golden(case)
+    hg = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+    st = hg.marginalizeNoOptimize(which, opts)
+    assert st["n_bad_status"] == 0 and np.array_equal(hg.vertices()[0], gold_vids)
+    worst = util.compare_edge_sets(g["pose_dim"], gold_edges, hg.edges(), rtol=1e-9)
+    assert abs(st["kld_sum"] - float(np.nansum(gold_bl["kld"]))) <= 1e-9 * max(1.0, abs(float(np.nansum(gold_bl["kld"]))))
+    print(f"{case}: {int((gold_edges['kind'] == abi.EDGE_MULTI).sum())} correlated edges, worst rel err {worst:.1e}")

@@ -64,7 +64,7 @@ def test_rounds_equal_sequential(case, ictx):
     hg = GraphWrapperHIP.from_dict(g, ctx=ictx, useGLC=bool(opts.algorithm))
     st = hg.marginalizeNoOptimize(which, opts)
     assert st["n_bad_status"] == 0
-    assert st["n_removed"] == int(np.sum(gold_bl["k"] >= 0)) or opts.topology == abi.TOPO_DENSE
+    assert st["n_removed"] == int(np.sum(gold_bl["k"] >= 0)) or opts.topology in (abi.TOPO_DENSE, abi.TOPO_CLIQUEY_DENSE)   # (clustered blankets remove several vertices each)
     ids, _ = hg.vertices()
     assert np.array_equal(ids, gold_vids)
     util.compare_edge_sets(g["pose_dim"], gold_edges, hg.edges(), rtol=1e-11)
