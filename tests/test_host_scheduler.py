@@ -126,3 +126,19 @@ def test_leaf_and_duplicate_edges(ictx):
     util.compare_edge_sets(3, og.edges(), hg.edges(), rtol=1e-11)
     ids_left, _ = hg.vertices()
     assert list(ids_left) == [0, 1, 3]
+
+
+def test_reserve_changes_nothing_but_memory(ictx):
+    """spg_graph_reserve sizes and touches the host-side buffers of a marginalisation (include/spg.h); the result is the same
+    graph as without it, and the arena's capacity is what was asked for."""
+    g, which, opts, gold_edges, gold_bl, gold_vids = util.load_golden("sphere_nfr_tree")
+    a = GraphWrapperHIP.from_dict(g, ctx=ictx)
+    b = GraphWrapperHIP.from_dict(g, ctx=ictx)
+    need = int(len(g["ids"]) * 7 + len(g["edge_ij"]) * 28) * 3
+    b.reserve(need)
+    _, cap = b.arena()
+    assert cap >= need
+    sa, sb = a.marginalizeNoOptimize(which, opts), b.marginalizeNoOptimize(which, opts)
+    assert sa["n_removed"] == sb["n_removed"] and sa["kld_sum"] == sb["kld_sum"]
+    util.compare_edge_sets(g["pose_dim"], a.edges(), b.edges(), rtol=0)
+    util.compare_edge_sets(g["pose_dim"], gold_edges, b.edges(), rtol=1e-11)
