@@ -66,6 +66,7 @@ struct IpArgs {
     int64_t mail_base;
     int topology, lin_point, tag;
     int lds_doubles;          // dynamic LDS of the launch: a blanket whose hot buffers fit keeps them there
+    int ip_untiled;           // diagnostic (SPG_IP_UNTILED=1): the column-at-a-time LDS factorisation instead of the register-tiled one
     double chord_ratio;
 };
 int nfr_ip_pattern_size(int topology, double chord_ratio, int k);   // new edges of a blanket with k kept vertices (-1: correlated patterns)

@@ -99,6 +99,23 @@ __device__ inline bool chol_serial(double *A, int n, int ld) {
     return true;
 }
 
+// a / b given rb = 1 / b correctly rounded (one IEEE division, off the dependent chain): the quotient estimate a rb is
+// within an ulp, its remainder a - q b is exact in an fma, and q + rem rb rounds to the correctly rounded quotient
+// (Markstein; the one exception, a divisor whose significand is all ones, and operands within 2^-970 of the
+// underflow threshold do not occur here: b is a Cholesky pivot). Three dependent operations instead of the ~13 of the
+// IEEE division sequence — the factorisation and the substitution are chains of those.
+__device__ __forceinline__ double div_by(double a, double b, double rb) {
+    const double q = a * rb;
+    const double rem = __builtin_fma(-q, b, a);
+    return __builtin_fma(rem, rb, q);
+}
+
+// the value lane `lane` (uniform over the wavefront) holds, through the scalar unit
+__device__ __forceinline__ double read_lane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 template <int D>
 __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     constexpr int DD = D * D, PS = (D == 6) ? 7 : 3, PSZ = (D == 6) ? 12 : 3, REC = PS + D * (D + 1) / 2;
@@ -124,12 +141,15 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     // instead of ~1 us out of L2: a Newton step is a few hundred such phases)
     // Dynamic LDS, one of two uses per blanket. (A) the whole Hessian, lower triangle packed by rows with the Newton
     // right-hand side as an extra row — its Cholesky and the substitution then never leave LDS (a 144-variable problem:
-    // 85 KB); (B) when that does not fit: a 64 KB panel for the blocked out-of-L2 factorisation, and behind it the hot
+    // 85 KB), and behind it the hot small matrices if they still fit (they do at 144 variables: 48 KB); (B) when that does not fit: a 64 KB panel for the blocked out-of-L2 factorisation, and behind it the hot
     // small matrices if they fit.
     const long long packed_len = (long long)(nx + 1) * (nx + 2) / 2;
     const bool hx_lds = !closed && packed_len <= (long long)a.lds_doubles;
+    const bool hx_tiled = hx_lds && nx + 1 <= 176 && !a.ip_untiled;     // (A') below: the Hessian goes straight into register tiles
     double *panel = lds_pool;
-    double *hot = (!hx_lds && kPanelDoubles + L.hot_total <= (int64_t)a.lds_doubles) ? lds_pool + kPanelDoubles : ws + L.cold_total;
+    const long long packed_pad = (packed_len + 1) & ~1LL;
+    double *hot = hx_lds ? ((packed_pad + L.hot_total <= (int64_t)a.lds_doubles) ? lds_pool + packed_pad : ws + L.cold_total)
+                         : ((kPanelDoubles + L.hot_total <= (int64_t)a.lds_doubles) ? lds_pool + kPanelDoubles : ws + L.cold_total);
     double *arena = a.arena;
     double *orec = a.mail ? (a.mail + (bd.out_off - a.mail_base)) : (arena + bd.out_off);
     if (tid == 0) flag_s = 0;
@@ -956,6 +976,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         for (int it = tid; it < q * q; it += NT) { const int i = it / q, j = it - i * q; if (j < i) P[it] = P[j * q + i]; }
         __syncthreads();
         // H[(e, ii, jj)][(e2, uu, vv)] = P(e2 D + uu, e D + ii) P(e D + jj, e2 D + vv)  (+ rho Xinv(uu, ii) Xinv(jj, vv) on e2 = e)
+        if (hx_tiled) return;       // chol_solve_tiled builds its tiles from P and Xi
         if (hx_lds) {
             // lower triangle only, packed by rows in LDS: row s at s (s + 1) / 2
             for (int s0 = tid; s0 < nx; s0 += NT) {
@@ -1028,6 +1049,187 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         __syncthreads();
         return true;
     };
+#ifdef SPG_IP_PROF
+    long long ipt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ipt_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    // (A') the same factorisation with the running matrix in REGISTERS: thread t owns the 8 x 8 tile (I, C), C <= I, of the
+    // lower triangle (rows incl. the right-hand side row nn), 253 tiles at most, so nn + 1 <= 176. Per block column J:
+    //   1. the owners of column J's tiles put their running values into the LDS panel (row stride 9, block stride 73:
+    //      rows and blocks spread over the banks);
+    //   2. thread u takes row (J + 1) 8 + u: it factorises the diagonal block itself (every thread does, redundantly — the
+    //      sqrt/divide chain is the sequential part anyway and this saves a barrier and a broadcast) and solves its row
+    //      against it; the finished values go to the panel in place and to the packed matrix;
+    //   3. every tile right of J takes its 8 x 8 x 8 products from two panel blocks.
+    // Two barriers per EIGHT columns (the column version above: three per column, and a dependent LDS round trip per
+    // entry and column — 1.4 M cycles for 144 variables; this one: see profiles/r02_interior_point.md). Every entry still
+    // has its products subtracted one at a time in column order and is divided by the pivot: bit-identical to (A) and (B).
+    constexpr int TR = 9, TB = 73;
+    auto chol_solve_tiled = [&](int nn, const double *rhs_neg, double *out) -> bool {
+        double *Hp = lds_pool;
+        double *pan = colbuf;
+        auto rowp = [&](int i) { return Hp + (long long)i * (i + 1) / 2; };
+        const int nr = nn + 1, nb = (nr + 7) >> 3;
+        int I = -1, C = -1;
+        if (tid < nb * (nb + 1) / 2) {
+            int i = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
+            while ((i + 1) * (i + 2) / 2 <= tid) i++;
+            while (i * (i + 1) / 2 > tid) i--;
+            I = i; C = tid - i * (i + 1) / 2;
+        }
+        // the tile of the Hessian (the expression of hessian() above, entry by entry) or of the right-hand side row
+        double t[8][8];
+        {
+            int ra[8], rb[8], rx1[8], rx2[8], re[8], cc[8], cd[8], cu[8], ce[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int sidx = min(max(I, 0) * 8 + r, nn - 1);
+                const int e = sidx / DD, jj = (sidx - e * DD) / D, ii = sidx - e * DD - jj * D;
+                re[r] = e; ra[r] = e * D + ii; rb[r] = (e * D + jj) * q; rx1[r] = e * DD + ii; rx2[r] = e * DD + jj * D;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int tidx = min(max(C, 0) * 8 + c, nn - 1);
+                const int e2 = tidx / DD, vv = (tidx - e2 * DD) / D, uu = tidx - e2 * DD - vv * D;
+                ce[c] = e2; cc[c] = (e2 * D + uu) * q; cd[c] = e2 * D + vv; cu[c] = uu * D + (vv << 16);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int row = I * 8 + r, col = C * 8 + c;
+                    double v = 0.0;
+                    if (I >= 0 && col < nn && col <= row) {
+                        if (row < nn) {
+                            v = P[cc[c] + ra[r]] * P[rb[r] + cd[c]];
+                            const double vb = __builtin_fma(rho * Xi[rx1[r] + (cu[c] & 0xffff)], Xi[rx2[r] + (cu[c] >> 16)], v);   // v += rho Xi Xi, without a branch
+                            v = (ce[c] == re[r] && chol_ok) ? vb : v;
+                        } else if (row == nn) v = rhs_neg[col];
+                    }
+                    t[r][c] = v;
+                }
+        }
+        bool okc = true;
+        for (int J = 0; J < nb; J++) {
+            if (C == J) {
+                double *pb = pan + I * TB;
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) pb[r * TR + c] = t[r][c];
+            }
+            __syncthreads();
+            IPT(2);
+            {
+                double d[8][8], rl[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+                const double *pj = pan + J * TB;
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+#pragma unroll
+                    for (int c = 0; c <= r; c++) d[r][c] = pj[r * TR + c];
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    if (J * 8 + jj < nn) {
+                        double dpiv = d[jj][jj];
+                        if (!(dpiv > 0.0) || !isfinite(dpiv)) { okc = false; dpiv = 1.0; }
+                        const double l = sqrt(dpiv);
+                        d[jj][jj] = l;
+                        rl[jj] = 1.0 / l;
+#pragma unroll
+                        for (int r = jj + 1; r < 8; r++) d[r][jj] = div_by(d[r][jj], l, rl[jj]);
+#pragma unroll
+                        for (int c = jj + 1; c < 8; c++)
+#pragma unroll
+                            for (int r = c; r < 8; r++) d[r][c] -= d[r][jj] * d[c][jj];
+                    }
+                }
+                const int row = (J + 1) * 8 + tid;
+                if (row < nr) {
+                    double *pr = pan + (row >> 3) * TB + (row & 7) * TR;
+                    double *hr = rowp(row) + J * 8;
+                    double v[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) v[jj] = pr[jj];
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) {
+#pragma unroll
+                        for (int u = 0; u < jj; u++) v[jj] -= v[u] * d[jj][u];
+                        v[jj] = div_by(v[jj], d[jj][jj], rl[jj]);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) { pr[jj] = v[jj]; hr[jj] = v[jj]; }
+                } else if (tid == NT - 1) {
+                    // the finished diagonal block (rows beyond nn and columns beyond nn - 1 do not exist in the packed matrix)
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+#pragma unroll
+                        for (int c = 0; c <= r; c++) {
+                            const int rw = J * 8 + r, cl = J * 8 + c;
+                            if (rw < nr && cl < nn) rowp(rw)[cl] = d[r][c];
+                        }
+                }
+            }
+            __syncthreads();
+            IPT(6);
+            if (C > J) {
+                const double *pi = pan + I * TB, *pc = pan + C * TB;
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    double li[8], lc[8];
+#pragma unroll
+                    for (int r = 0; r < 8; r++) { li[r] = pi[r * TR + jj]; lc[r] = pc[r * TR + jj]; }
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+#pragma unroll
+                        for (int c = 0; c < 8; c++) t[r][c] -= li[r] * lc[c];
+                }
+            }
+        }
+        __syncthreads();
+        IPT(2);
+        if (!okc) return false;
+        // L^T x = y (y = row nn) by one wavefront, right-looking over the rows of L from the last: the running vector lives in
+        // registers (entries lane, lane + 64, lane + 128), x_i is passed by a lane read, the next row is fetched from LDS while
+        // the current one is applied. Same operations as the LDS version in (A).
+        if (tid < 64) {
+            const int lane = tid;
+            const int nns = __builtin_amdgcn_readfirstlane(nn);       // the row loop runs on the scalar unit
+            double y[3], cur[3], nxt[3];
+            auto fetch = [&](int i, double *dst) {
+                const double *row = rowp(i);
+#pragma unroll
+                for (int c = 0; c < 3; c++) { const int u = lane + 64 * c; dst[c] = (u <= i) ? row[u] : 0.0; }
+            };
+            fetch(nns, y);
+#pragma unroll
+            for (int c = 0; c < 3; c++) if (lane + 64 * c >= nns) y[c] = 0.0;
+            double dg[3], rd[3];        // the diagonal of L and its reciprocals, entry u with the lane that owns y_u
+#pragma unroll
+            for (int c = 0; c < 3; c++) { const int u = lane + 64 * c; dg[c] = (u < nns) ? rowp(u)[u] : 1.0; rd[c] = 1.0 / dg[c]; }
+            fetch(nns - 1, cur);
+            for (int i = nns - 1; i >= 0; i--) {
+                if (i > 0) fetch(i - 1, nxt);
+                const int owner = i & 63, slot = i >> 6;
+                double yo = 0.0, dgo = 1.0, rdo = 1.0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) if (slot == c) { yo = read_lane(y[c], owner); dgo = read_lane(dg[c], owner); rdo = read_lane(rd[c], owner); }
+                const double xi = div_by(yo, dgo, rdo);               // every lane computes the same x_i
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    if (c > slot) continue;
+                    const int u = lane + 64 * c;
+                    if (u < i) y[c] -= cur[c] * xi;
+                    else if (u == i) y[c] = xi;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) cur[c] = nxt[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) { const int u = lane + 64 * c; if (u < nns) out[u] = y[c]; }
+        }
+        __syncthreads();
+        IPT(3);
+        return true;
+    };
     // (B) Cholesky of the Hessian (Eigen::LLT in the reference, src/pqn/pqn_optimizer.cpp:52-53), lower, in place, out of L2.
     // Blocked right-looking: a panel of PB columns is factorised in LDS, then the trailing matrix takes ONE pass of
     // read-modify-writes per panel (rows are walked, four rows in flight per wavefront so that the L2 round trips overlap:
@@ -1043,11 +1245,13 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         bool okc = true;
         for (int j0 = 0; j0 < nn; j0 += PB) {
             const int pb = min(PB, nn - j0), nrows = nr - j0;
+            IPT(2);
             for (int rr = tid >> 4; rr < nrows; rr += NT / 16) {           // panel rows j0.., columns j0..j0+pb (lower part)
                 const int pc = tid & 15;
                 if (pc < pb) panel[rr * PBS + pc] = (pc <= rr) ? A[(long long)(j0 + rr) * nn + j0 + pc] : 0.0;
             }
             __syncthreads();
+            IPT(6);
             for (int pc = 0; pc < pb; pc++) {
                 double dpiv = panel[pc * PBS + pc];
                 if (!(dpiv > 0.0) || !isfinite(dpiv)) { okc = false; dpiv = 1.0; }
@@ -1062,6 +1266,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                         if (rr >= p2) panel[rr * PBS + p2] -= panel[rr * PBS + pc] * panel[p2 * PBS + pc];
                 __syncthreads();
             }
+            IPT(7);
             for (int rr = tid >> 4; rr < nrows; rr += NT / 16) {
                 const int pc = tid & 15;
                 if (pc < pb && pc <= rr) A[(long long)(j0 + rr) * nn + j0 + pc] = panel[rr * PBS + pc];
@@ -1136,9 +1341,6 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     };
     // PQNOptimizer::optimize with useHessian (src/pqn/pqn_optimizer.cpp:29-126)
     int newton_steps = 0;
-#ifdef SPG_IP_PROF
-    long long ipt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ipt_last = (long long)__builtin_amdgcn_s_memtime();
-#endif
     auto optimize = [&](double tol) {
         double f = value(x);
         gradient(x, g);
@@ -1149,7 +1351,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             if (hx_lds) {
                 for (int it = tid; it < nx; it += NT) xn[it] = -g[it];
                 __syncthreads();
-                const bool hok = chol_solve_packed(nx, xn, dv);      // d = -(L L^T)^-1 g, all in LDS
+                const bool hok = hx_tiled ? chol_solve_tiled(nx, xn, dv) : chol_solve_packed(nx, xn, dv);      // d = -(L L^T)^-1 g, all in LDS
                 IPT(2);
                 if (!hok) return;
             } else {
@@ -1203,7 +1405,8 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
     }
 #ifdef SPG_IP_PROF
-    if (tid == 0 && blockIdx.x == 0) printf("ip prof k=%d E=%d nx=%d steps=%d: other %lld hessian %lld chol %lld solve %lld value %lld gradient %lld (x100MHz ticks)\n", k, E, nx, newton_steps, ipt[0], ipt[1], ipt[2], ipt[3], ipt[4], ipt[5]);
+    if (tid == 0) { long long tot = 0; for (int u = 0; u < 8; u++) tot += ipt[u]; printf("ipb %d %d %d %d %c %lld %lld %lld\n", k, E, nx, newton_steps, hx_tiled ? 'T' : hx_lds ? 'A' : 'B', tot, ipt[2] + ipt[6] + ipt[7], ipt[3]); }
+    if (tid == 0 && blockIdx.x == 0) printf("ip prof k=%d E=%d nx=%d steps=%d mode %c: other %lld hessian %lld chol(trailing+rest) %lld solve %lld value %lld gradient %lld | panel load %lld panel factor %lld (cycles)\n", k, E, nx, newton_steps, hx_lds ? 'A' : 'B', ipt[0], ipt[1], ipt[2], ipt[3], ipt[4], ipt[5], ipt[6], ipt[7]);
 #endif
     bool okf = false;
     const double fin = base_value(x, okf);
@@ -1242,6 +1445,10 @@ int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int64_t hot_max)
     (void)hot_max;
     const size_t lds = 140 * 1024;
     a.lds_doubles = (int)(lds / 8);
+    static const bool no_packed = [] { const char *e = getenv("SPG_IP_NO_LDS_HESSIAN"); return e && e[0] == '1'; }();   // diagnostic: mode (B) for every blanket
+    if (no_packed) a.lds_doubles = 9000;
+    static const bool untiled = [] { const char *e = getenv("SPG_IP_UNTILED"); return e && e[0] == '1'; }();           // diagnostic: the column-at-a-time LDS factorisation
+    a.ip_untiled = untiled ? 1 : 0;
     const void *fn = D == 6 ? reinterpret_cast<const void *>(nfr_ip_kernel<6>) : reinterpret_cast<const void *>(nfr_ip_kernel<3>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
