@@ -18,6 +18,7 @@
 // records in the arena, out record + ready / final word in the mailbox or the arena).
 // Scope: pose-pose edges in, Global linearisation point, the `smalleigs <= dim` branch of the spectrum
 // (src/logdet_function.cpp:36-39); anything else reports a status and writes no edges.
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     const long long packed_len = (long long)(nx + 1) * (nx + 2) / 2;
     const bool hx_lds = !closed && packed_len <= (long long)a.lds_doubles;
     const bool hx_tiled = hx_lds && nx + 1 <= 176 && !a.ip_untiled;     // (A') below: the Hessian goes straight into register tiles
+    const bool hx_tiled2 = !closed && !hx_tiled && nx + 1 > 176 && nx + 1 <= 248 && !a.ip_untiled;     // two tiles per thread, factor in the L2 workspace
     double *panel = lds_pool;
     const long long packed_pad = (packed_len + 1) & ~1LL;
     double *hot = hx_lds ? ((packed_pad + L.hot_total <= (int64_t)a.lds_doubles) ? lds_pool + packed_pad : ws + L.cold_total)
@@ -976,7 +978,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         for (int it = tid; it < q * q; it += NT) { const int i = it / q, j = it - i * q; if (j < i) P[it] = P[j * q + i]; }
         __syncthreads();
         // H[(e, ii, jj)][(e2, uu, vv)] = P(e2 D + uu, e D + ii) P(e D + jj, e2 D + vv)  (+ rho Xinv(uu, ii) Xinv(jj, vv) on e2 = e)
-        if (hx_tiled) return;       // chol_solve_tiled builds its tiles from P and Xi
+        if (hx_tiled || hx_tiled2) return;       // chol_solve_tiled builds its tiles from P and Xi
         if (hx_lds) {
             // lower triangle only, packed by rows in LDS: row s at s (s + 1) / 2
             for (int s0 = tid; s0 < nx; s0 += NT) {
@@ -1060,35 +1062,42 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     //      sqrt/divide chain is the sequential part anyway and this saves a barrier and a broadcast) and solves its row
     //      against it; the finished values go to the panel in place and to the packed matrix;
     //   3. every tile right of J takes its 8 x 8 x 8 products from two panel blocks.
-    // Two barriers per EIGHT columns (the column version above: three per column, and a dependent LDS round trip per
+    // Three barriers per EIGHT columns (the column version above: three per column, and a dependent LDS round trip per
     // entry and column — 1.4 M cycles for 144 variables; this one: see profiles/r02_interior_point.md). Every entry still
     // has its products subtracted one at a time in column order and is divided by the pivot: bit-identical to (A) and (B).
+    // Beyond 175 variables (up to 247) each thread owns TWO tiles (t and t + 256) and the finished factor goes to the
+    // L2 workspace instead of LDS (217 packed rows would be 189 KB); the substitution reads it back three rows ahead.
     constexpr int TR = 9, TB = 73;
-    auto chol_solve_tiled = [&](int nn, const double *rhs_neg, double *out) -> bool {
-        double *Hp = lds_pool;
-        double *pan = colbuf;
-        auto rowp = [&](int i) { return Hp + (long long)i * (i + 1) / 2; };
+    auto chol_solve_tiled = [&](auto ntl_c, int nn, const double *rhs_neg, double *out) -> bool {
+        constexpr int NTL = decltype(ntl_c)::value;                       // tiles per thread
+        constexpr int CH = (NTL == 1) ? 3 : 4;                            // 64-entry chunks of the solution vector
+        double *pan = (NTL == 1) ? colbuf : panel;
+        double *Lb = (NTL == 1) ? lds_pool : Hx;                          // NTL == 1: packed rows in LDS; else nn-strided rows in L2
+        auto rowp = [&](int i) { return (NTL == 1) ? Lb + (long long)i * (i + 1) / 2 : Lb + (long long)i * nn; };
         const int nr = nn + 1, nb = (nr + 7) >> 3;
-        int I = -1, C = -1;
-        if (tid < nb * (nb + 1) / 2) {
-            int i = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
-            while ((i + 1) * (i + 2) / 2 <= tid) i++;
-            while (i * (i + 1) / 2 > tid) i--;
-            I = i; C = tid - i * (i + 1) / 2;
-        }
-        // the tile of the Hessian (the expression of hessian() above, entry by entry) or of the right-hand side row
-        double t[8][8];
-        {
+        int I[NTL], C[NTL];
+        double t[NTL][8][8];
+#pragma unroll
+        for (int s = 0; s < NTL; s++) {
+            const int tix = tid + s * NT;
+            I[s] = -1; C[s] = -1;
+            if (tix < nb * (nb + 1) / 2) {
+                int i = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5);
+                while ((i + 1) * (i + 2) / 2 <= tix) i++;
+                while (i * (i + 1) / 2 > tix) i--;
+                I[s] = i; C[s] = tix - i * (i + 1) / 2;
+            }
+            // the tile of the Hessian (the expression of hessian() above, entry by entry) or of the right-hand side row
             int ra[8], rb[8], rx1[8], rx2[8], re[8], cc[8], cd[8], cu[8], ce[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const int sidx = min(max(I, 0) * 8 + r, nn - 1);
+                const int sidx = min(max(I[s], 0) * 8 + r, nn - 1);
                 const int e = sidx / DD, jj = (sidx - e * DD) / D, ii = sidx - e * DD - jj * D;
                 re[r] = e; ra[r] = e * D + ii; rb[r] = (e * D + jj) * q; rx1[r] = e * DD + ii; rx2[r] = e * DD + jj * D;
             }
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                const int tidx = min(max(C, 0) * 8 + c, nn - 1);
+                const int tidx = min(max(C[s], 0) * 8 + c, nn - 1);
                 const int e2 = tidx / DD, vv = (tidx - e2 * DD) / D, uu = tidx - e2 * DD - vv * D;
                 ce[c] = e2; cc[c] = (e2 * D + uu) * q; cd[c] = e2 * D + vv; cu[c] = uu * D + (vv << 16);
             }
@@ -1096,27 +1105,29 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             for (int r = 0; r < 8; r++)
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
-                    const int row = I * 8 + r, col = C * 8 + c;
+                    const int row = I[s] * 8 + r, col = C[s] * 8 + c;
                     double v = 0.0;
-                    if (I >= 0 && col < nn && col <= row) {
+                    if (I[s] >= 0 && col < nn && col <= row) {
                         if (row < nn) {
                             v = P[cc[c] + ra[r]] * P[rb[r] + cd[c]];
                             const double vb = __builtin_fma(rho * Xi[rx1[r] + (cu[c] & 0xffff)], Xi[rx2[r] + (cu[c] >> 16)], v);   // v += rho Xi Xi, without a branch
                             v = (ce[c] == re[r] && chol_ok) ? vb : v;
                         } else if (row == nn) v = rhs_neg[col];
                     }
-                    t[r][c] = v;
+                    t[s][r][c] = v;
                 }
         }
         bool okc = true;
         for (int J = 0; J < nb; J++) {
-            if (C == J) {
-                double *pb = pan + I * TB;
 #pragma unroll
-                for (int r = 0; r < 8; r++)
+            for (int s = 0; s < NTL; s++)
+                if (C[s] == J) {
+                    double *pb = pan + I[s] * TB;
 #pragma unroll
-                    for (int c = 0; c < 8; c++) pb[r * TR + c] = t[r][c];
-            }
+                    for (int r = 0; r < 8; r++)
+#pragma unroll
+                        for (int c = 0; c < 8; c++) pb[r * TR + c] = t[s][r][c];
+                }
             __syncthreads();
             IPT(2);
             {
@@ -1158,7 +1169,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
 #pragma unroll
                     for (int jj = 0; jj < 8; jj++) { pr[jj] = v[jj]; hr[jj] = v[jj]; }
                 } else if (tid == NT - 1) {
-                    // the finished diagonal block (rows beyond nn and columns beyond nn - 1 do not exist in the packed matrix)
+                    // the finished diagonal block (rows beyond nn and columns beyond nn - 1 do not exist in the factor)
 #pragma unroll
                     for (int r = 0; r < 8; r++)
 #pragma unroll
@@ -1170,61 +1181,65 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             }
             __syncthreads();
             IPT(6);
-            if (C > J) {
-                const double *pi = pan + I * TB, *pc = pan + C * TB;
 #pragma unroll
-                for (int jj = 0; jj < 8; jj++) {
-                    double li[8], lc[8];
+            for (int s = 0; s < NTL; s++)
+                if (C[s] > J) {
+                    const double *pi = pan + I[s] * TB, *pc = pan + C[s] * TB;
 #pragma unroll
-                    for (int r = 0; r < 8; r++) { li[r] = pi[r * TR + jj]; lc[r] = pc[r * TR + jj]; }
+                    for (int jj = 0; jj < 8; jj++) {
+                        double li[8], lc[8];
 #pragma unroll
-                    for (int r = 0; r < 8; r++)
+                        for (int r = 0; r < 8; r++) { li[r] = pi[r * TR + jj]; lc[r] = pc[r * TR + jj]; }
 #pragma unroll
-                        for (int c = 0; c < 8; c++) t[r][c] -= li[r] * lc[c];
+                        for (int r = 0; r < 8; r++)
+#pragma unroll
+                            for (int c = 0; c < 8; c++) t[s][r][c] -= li[r] * lc[c];
+                    }
                 }
-            }
+            __syncthreads();        // the panel is rewritten by the next block column's step 1
         }
-        __syncthreads();
         IPT(2);
         if (!okc) return false;
         // L^T x = y (y = row nn) by one wavefront, right-looking over the rows of L from the last: the running vector lives in
-        // registers (entries lane, lane + 64, lane + 128), x_i is passed by a lane read, the next row is fetched from LDS while
-        // the current one is applied. Same operations as the LDS version in (A).
+        // registers (entries lane, lane + 64, ...), x_i is computed by every lane from lane reads, rows are fetched three
+        // ahead (they come from L2 when two tiles per thread are in use). Same operations as the LDS version in (A).
         if (tid < 64) {
             const int lane = tid;
             const int nns = __builtin_amdgcn_readfirstlane(nn);       // the row loop runs on the scalar unit
-            double y[3], cur[3], nxt[3];
+            double y[CH], r0[CH], r1[CH], r2[CH];
             auto fetch = [&](int i, double *dst) {
+                if (i < 0) return;
                 const double *row = rowp(i);
 #pragma unroll
-                for (int c = 0; c < 3; c++) { const int u = lane + 64 * c; dst[c] = (u <= i) ? row[u] : 0.0; }
+                for (int c = 0; c < CH; c++) { const int u = lane + 64 * c; dst[c] = (u <= i && u < nns) ? row[u] : 0.0; }
             };
             fetch(nns, y);
+            double dg[CH], rd[CH];        // the diagonal of L and its reciprocals, entry u with the lane that owns y_u
 #pragma unroll
-            for (int c = 0; c < 3; c++) if (lane + 64 * c >= nns) y[c] = 0.0;
-            double dg[3], rd[3];        // the diagonal of L and its reciprocals, entry u with the lane that owns y_u
-#pragma unroll
-            for (int c = 0; c < 3; c++) { const int u = lane + 64 * c; dg[c] = (u < nns) ? rowp(u)[u] : 1.0; rd[c] = 1.0 / dg[c]; }
-            fetch(nns - 1, cur);
-            for (int i = nns - 1; i >= 0; i--) {
-                if (i > 0) fetch(i - 1, nxt);
+            for (int c = 0; c < CH; c++) { const int u = lane + 64 * c; dg[c] = (u < nns) ? rowp(u)[u] : 1.0; rd[c] = 1.0 / dg[c]; }
+            auto apply = [&](int i, const double *cur) {
+                if (i < 0) return;
                 const int owner = i & 63, slot = i >> 6;
                 double yo = 0.0, dgo = 1.0, rdo = 1.0;
 #pragma unroll
-                for (int c = 0; c < 3; c++) if (slot == c) { yo = read_lane(y[c], owner); dgo = read_lane(dg[c], owner); rdo = read_lane(rd[c], owner); }
+                for (int c = 0; c < CH; c++) if (slot == c) { yo = read_lane(y[c], owner); dgo = read_lane(dg[c], owner); rdo = read_lane(rd[c], owner); }
                 const double xi = div_by(yo, dgo, rdo);               // every lane computes the same x_i
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
+                for (int c = 0; c < CH; c++) {
                     if (c > slot) continue;
                     const int u = lane + 64 * c;
                     if (u < i) y[c] -= cur[c] * xi;
                     else if (u == i) y[c] = xi;
                 }
-#pragma unroll
-                for (int c = 0; c < 3; c++) cur[c] = nxt[c];
+            };
+            fetch(nns - 1, r0); fetch(nns - 2, r1); fetch(nns - 3, r2);
+            for (int i = nns - 1; i >= 0; i -= 3) {
+                apply(i, r0); fetch(i - 3, r0);
+                apply(i - 1, r1); fetch(i - 4, r1);
+                apply(i - 2, r2); fetch(i - 5, r2);
             }
 #pragma unroll
-            for (int c = 0; c < 3; c++) { const int u = lane + 64 * c; if (u < nns) out[u] = y[c]; }
+            for (int c = 0; c < CH; c++) { const int u = lane + 64 * c; if (u < nns) out[u] = y[c]; }
         }
         __syncthreads();
         IPT(3);
@@ -1348,10 +1363,12 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             IPT(0);
             hessian();
             IPT(1);
-            if (hx_lds) {
+            if (hx_lds || hx_tiled2) {
                 for (int it = tid; it < nx; it += NT) xn[it] = -g[it];
                 __syncthreads();
-                const bool hok = hx_tiled ? chol_solve_tiled(nx, xn, dv) : chol_solve_packed(nx, xn, dv);      // d = -(L L^T)^-1 g, all in LDS
+                const bool hok = hx_tiled    ? chol_solve_tiled(std::integral_constant<int, 1>{}, nx, xn, dv)
+                                 : hx_tiled2 ? chol_solve_tiled(std::integral_constant<int, 2>{}, nx, xn, dv)
+                                             : chol_solve_packed(nx, xn, dv);      // d = -(L L^T)^-1 g
                 IPT(2);
                 if (!hok) return;
             } else {
@@ -1405,7 +1422,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
     }
 #ifdef SPG_IP_PROF
-    if (tid == 0) { long long tot = 0; for (int u = 0; u < 8; u++) tot += ipt[u]; printf("ipb %d %d %d %d %c %lld %lld %lld\n", k, E, nx, newton_steps, hx_tiled ? 'T' : hx_lds ? 'A' : 'B', tot, ipt[2] + ipt[6] + ipt[7], ipt[3]); }
+    if (tid == 0) { long long tot = 0; for (int u = 0; u < 8; u++) tot += ipt[u]; printf("ipb %d %d %d %d %c %lld %lld %lld\n", k, E, nx, newton_steps, hx_tiled ? 'T' : hx_tiled2 ? 'U' : hx_lds ? 'A' : 'B', tot, ipt[2] + ipt[6] + ipt[7], ipt[3]); }
     if (tid == 0 && blockIdx.x == 0) printf("ip prof k=%d E=%d nx=%d steps=%d mode %c: other %lld hessian %lld chol(trailing+rest) %lld solve %lld value %lld gradient %lld | panel load %lld panel factor %lld (cycles)\n", k, E, nx, newton_steps, hx_lds ? 'A' : 'B', ipt[0], ipt[1], ipt[2], ipt[3], ipt[4], ipt[5], ipt[6], ipt[7]);
 #endif
     bool okf = false;
