@@ -111,6 +111,30 @@ __device__ __forceinline__ double div_by(double a, double b, double rb) {
     return __builtin_fma(rem, rb, q);
 }
 
+// chol_serial for a compile-time size, fully unrolled so that the matrix stays in registers (a runtime-indexed private
+// array lives in scratch memory: every access a round trip to L2); rl[j] = 1 / L[j][j]. Same operations in the same order.
+template <int N>
+__device__ __forceinline__ bool chol_static(double (&A)[N * N], double (&rl)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        double d = A[j * N + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= A[j * N + k] * A[j * N + k];
+        if (!(d > 0.0) || !isfinite(d)) return false;
+        const double l = sqrt(d);
+        A[j * N + j] = l;
+        rl[j] = 1.0 / l;
+#pragma unroll
+        for (int i = j + 1; i < N; i++) {
+            double s = A[i * N + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= A[i * N + k] * A[j * N + k];
+            A[i * N + j] = div_by(s, l, rl[j]);
+        }
+    }
+    return true;
+}
+
 // the value lane `lane` (uniform over the wavefront) holds, through the scalar unit
 __device__ __forceinline__ double read_lane(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -157,6 +181,9 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     if (tid == 0) flag_s = 0;
     __syncthreads();
     Team<NT> T{tid, red, &flag_s};
+#ifdef SPG_IP_PROF
+    long long ipt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ipt_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
     int status = SPG_OK, info = 0, n_new = 0;
     double kld = __builtin_nan(""), min_gap = __builtin_inf();
     // L.w: [0, P2) pair weights | [P2, 2 P2) pair (i, j) ints | [2 P2, 3 P2) pop order + rejected bin (ints) | 3 P2 + 2: the pattern (2 E ints)
@@ -646,6 +673,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         for (int it = tid; it < n * r; it += NT) {
             const int i = it / r, c = it - i * r;
             double sacc = 0;
+#pragma unroll 8
             for (int t = 0; t < n; t++) sacc += Ai[i * n + t] * U[t * r + c];
             T1[it] = sacc;
         }
@@ -654,20 +682,24 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             const int i = it / r, j = it - i * r;
             if (j >= i) {
                 double sacc = 0;
+#pragma unroll 8
                 for (int t = 0; t < n; t++) sacc += U[t * r + i] * T1[t * r + j];
                 M[i * r + j] = sacc; M[j * r + i] = sacc;
             }
         }
         __syncthreads();
+        IPT(8);
         double tr = 0;
         for (int i = tid; i < r; i += NT) tr += M[i * r + i] * Sv[i];
         tr = T.sum(tr);
         for (int it = tid; it < r * r; it += NT) Mc[it] = M[it];
         if (tid == 0) flag_s = 0;
         __syncthreads();
+        IPT(10);
         chol_lower<NT>(T, Mc, r, r);
         ok = flag_s == 0;
         __syncthreads();
+        IPT(9);
         if (!ok) { if (tid == 0) flag_s = 0; __syncthreads(); return __builtin_inf(); }
         double l = 0;
         for (int i = tid; i < r; i += NT) l += log(Mc[i * r + i]);
@@ -871,6 +903,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
         for (int it = tid; it < n * n; it += NT) { const int i = it / n, j = it - i * n; if (j < i) Ai[it] = Ai[j * n + i]; }
         __syncthreads();
+        IPT(11);
         return value_from_A(ok);
     };
     bool chol_ok = false;
@@ -879,10 +912,18 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         // barrier: - rho * sum_e log det X_e, +inf when a block is not positive definite
         double pen = 0;
         for (int e = tid; e < E; e += NT) {
-            double B[DD];
-            for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) B[i * D + j] = Xat(xv, e, i, j);
-            if (!chol_serial(B, D, D)) pen = __builtin_inf();
-            else { double l = 0; for (int i = 0; i < D; i++) l += log(B[i * D + i]); pen += 2.0 * l; }
+            double B[DD], rB[D];
+#pragma unroll
+            for (int i = 0; i < D; i++)
+#pragma unroll
+                for (int j = 0; j < D; j++) B[i * D + j] = Xat(xv, e, i, j);
+            if (!chol_static<D>(B, rB)) pen = __builtin_inf();
+            else {
+                double l = 0;
+#pragma unroll
+                for (int i = 0; i < D; i++) l += log(B[i * D + i]);
+                pen += 2.0 * l;
+            }
         }
         // deterministic: per-edge terms summed in edge order by thread 0
         red[tid] = pen;
@@ -898,11 +939,14 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     auto gradient = [&](const double *xv, double *gv) {
         if (!chol_ok) { for (int it = tid; it < nx; it += NT) gv[it] = 0.0; __syncthreads(); return; }
         tri_inverse_lower<NT>(T, Mc, Li, r, r);
+        IPT(5);
         gram_lower_inverse<NT>(T, Li, Mi, r, r);           // xinv = M^-1
+        IPT(12);
         // Y = U (diag(S) - xinv) U^T
         for (int it = tid; it < n * r; it += NT) {
             const int i = it / r, c = it - i * r;
             double s = 0;
+#pragma unroll 8
             for (int t = 0; t < r; t++) s += U[i * r + t] * ((t == c ? Sv[t] : 0.0) - Mi[t * r + c]);
             T1[it] = s;
         }
@@ -910,10 +954,12 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         for (int it = tid; it < n * n; it += NT) {
             const int i = it / n, j = it - i * n;
             double s = 0;
+#pragma unroll 8
             for (int t = 0; t < r; t++) s += T1[i * r + t] * U[j * r + t];
             Y[it] = s;
         }
         __syncthreads();
+        IPT(13);
         // per edge: block = sym(Ja Yaa Ja^T) + sym(Jb Ybb Jb^T) + (Ja Yab Jb^T + its transpose); g_e = block / 2
         for (int it = tid; it < nx; it += NT) {
             const int e = it / DD, jj = (it - e * DD) / D, ii = it - e * DD - jj * D;      // column-major (ii, jj)
@@ -934,19 +980,37 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             gv[it] = 0.5 * (aa + bb + ab);
         }
         __syncthreads();
+        IPT(14);
         // constraint part: X_e^-1, g_e -= rho X_e^-1
         if (tid == 0) si[0] = 0;
         __syncthreads();
         for (int e = tid; e < E; e += NT) {
-            double B[DD], Inv[DD];
-            for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) B[i * D + j] = Xat(xv, e, i, j);
-            if (!chol_serial(B, D, D)) { si[0] = 1; continue; }
-            // solve L L^T Inv = I column by column
+            double B[DD], Inv[DD], rB[D];
+#pragma unroll
+            for (int i = 0; i < D; i++)
+#pragma unroll
+                for (int j = 0; j < D; j++) B[i * D + j] = Xat(xv, e, i, j);
+            if (!chol_static<D>(B, rB)) { si[0] = 1; continue; }
+            // solve L L^T Inv = I column by column (all in registers: every index is a compile-time constant)
+#pragma unroll
             for (int c = 0; c < D; c++) {
                 double y[D];
-                for (int i = 0; i < D; i++) { double s = (i == c) ? 1.0 : 0.0; for (int t = 0; t < i; t++) s -= B[i * D + t] * y[t]; y[i] = s / B[i * D + i]; }
-                for (int i = D - 1; i >= 0; i--) { double s = y[i]; for (int t = i + 1; t < D; t++) s -= B[t * D + i] * Inv[t * D + c]; Inv[i * D + c] = s / B[i * D + i]; }
+#pragma unroll
+                for (int i = 0; i < D; i++) {
+                    double s = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int t = 0; t < i; t++) s -= B[i * D + t] * y[t];
+                    y[i] = div_by(s, B[i * D + i], rB[i]);
+                }
+#pragma unroll
+                for (int i = D - 1; i >= 0; i--) {
+                    double s = y[i];
+#pragma unroll
+                    for (int t = i + 1; t < D; t++) s -= B[t * D + i] * Inv[t * D + c];
+                    Inv[i * D + c] = div_by(s, B[i * D + i], rB[i]);
+                }
             }
+#pragma unroll
             for (int i = 0; i < DD; i++) Xi[e * DD + i] = Inv[i];      // row-major (u, v)
         }
         __syncthreads();
@@ -962,6 +1026,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         for (int it = tid; it < q * r; it += NT) {
             const int i = it / r, c = it - i * r;
             double s = 0;
+#pragma unroll 8
             for (int t = 0; t < r; t++) s += JU[i * r + t] * Mi[t * r + c];
             T2[it] = s;
         }
@@ -969,6 +1034,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         for (int it = tid; it < q * q; it += NT) {
             const int i = it / q, j = it - i * q;
             double s = 0;
+#pragma unroll 8
             for (int t = 0; t < r; t++) s += T2[i * r + t] * JU[j * r + t];
             P[it] = s;
         }
@@ -1051,9 +1117,6 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         __syncthreads();
         return true;
     };
-#ifdef SPG_IP_PROF
-    long long ipt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ipt_last = (long long)__builtin_amdgcn_s_memtime();
-#endif
     // (A') the same factorisation with the running matrix in REGISTERS: thread t owns the 8 x 8 tile (I, C), C <= I, of the
     // lower triangle (rows incl. the right-hand side row nn), 253 tiles at most, so nn + 1 <= 176. Per block column J:
     //   1. the owners of column J's tiles put their running values into the LDS panel (row stride 9, block stride 73:
@@ -1065,7 +1128,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     // Three barriers per EIGHT columns (the column version above: three per column, and a dependent LDS round trip per
     // entry and column — 1.4 M cycles for 144 variables; this one: see profiles/r02_interior_point.md). Every entry still
     // has its products subtracted one at a time in column order and is divided by the pivot: bit-identical to (A) and (B).
-    // Beyond 175 variables (up to 247) each thread owns TWO tiles (t and t + 256) and the finished factor goes to the
+    // Beyond 175 variables (up to 247) each thread owns TWO tiles and the finished factor goes to the
     // L2 workspace instead of LDS (217 packed rows would be 189 KB); the substitution reads it back three rows ahead.
     constexpr int TR = 9, TB = 73;
     auto chol_solve_tiled = [&](auto ntl_c, int nn, const double *rhs_neg, double *out) -> bool {
@@ -1079,13 +1142,23 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         double t[NTL][8][8];
 #pragma unroll
         for (int s = 0; s < NTL; s++) {
-            const int tix = tid + s * NT;
+            // slot 0: the tiles of the last 22 block columns (at most 253: one per thread — from block column c0 on only this
+            // slot has work, a single tile update per step); slot 1: the tiles of the first c0 block columns, column by column
+            const int c0 = (NTL == 1) ? 0 : max(nb - 22, 0), nl = nb - c0;
             I[s] = -1; C[s] = -1;
-            if (tix < nb * (nb + 1) / 2) {
-                int i = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5);
-                while ((i + 1) * (i + 2) / 2 <= tix) i++;
-                while (i * (i + 1) / 2 > tix) i--;
-                I[s] = i; C[s] = tix - i * (i + 1) / 2;
+            if (s == 0) {
+                if (tid < nl * (nl + 1) / 2) {
+                    int i = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
+                    while ((i + 1) * (i + 2) / 2 <= tid) i++;
+                    while (i * (i + 1) / 2 > tid) i--;
+                    I[s] = c0 + i; C[s] = c0 + tid - i * (i + 1) / 2;
+                }
+            } else {
+                int off = 0;
+                for (int c = 0; c < c0; c++) {
+                    if (tid >= off && tid < off + nb - c) { C[s] = c; I[s] = c + tid - off; }
+                    off += nb - c;
+                }
             }
             // the tile of the Hessian (the expression of hessian() above, entry by entry) or of the right-hand side row
             int ra[8], rb[8], rx1[8], rx2[8], re[8], cc[8], cd[8], cu[8], ce[8];
@@ -1206,38 +1279,53 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         if (tid < 64) {
             const int lane = tid;
             const int nns = __builtin_amdgcn_readfirstlane(nn);       // the row loop runs on the scalar unit
-            double y[CH], r0[CH], r1[CH], r2[CH];
-            auto fetch = [&](int i, double *dst) {
-                if (i < 0) return;
-                const double *row = rowp(i);
+            auto srow = [&](int i) { return (NTL == 1) ? Lb + (long long)i * (i + 1) / 2 : Lb + (long long)i * nns; };
+            double y[CH], dg[CH], rd[CH];       // the running vector, the diagonal of L and its reciprocals: entry u = lane + 64 c
 #pragma unroll
-                for (int c = 0; c < CH; c++) { const int u = lane + 64 * c; dst[c] = (u <= i && u < nns) ? row[u] : 0.0; }
+            for (int c = 0; c < CH; c++) {
+                const int u = lane + 64 * c;
+                y[c] = (u < nns) ? srow(nns)[u] : 0.0;
+                dg[c] = (u < nns) ? srow(u)[u] : 1.0;
+                rd[c] = 1.0 / dg[c];
+            }
+            // chunks 0..CM of row i (entries beyond the diagonal are read as the diagonal entry and never used: no branches)
+            auto fetch = [&](int i, double *dst, auto cm_c) {
+                constexpr int CM = decltype(cm_c)::value;
+                const int ic = max(i, 0);
+                const double *row = srow(ic);
+#pragma unroll
+                for (int c = 0; c <= CM; c++) dst[c] = row[min(lane + 64 * c, ic)];
             };
-            fetch(nns, y);
-            double dg[CH], rd[CH];        // the diagonal of L and its reciprocals, entry u with the lane that owns y_u
+            // row i of slot SL = i >> 6 (compile time): x_i from its owner's y, then y_u -= L[i][u] x_i for u < i
+            auto apply = [&](int i, const double *cur, auto sl_c) {
+                constexpr int SL = decltype(sl_c)::value;
+                const int owner = i & 63;
+                const double xi = div_by(read_lane(y[SL], owner), read_lane(dg[SL], owner), read_lane(rd[SL], owner));   // every lane computes the same x_i
 #pragma unroll
-            for (int c = 0; c < CH; c++) { const int u = lane + 64 * c; dg[c] = (u < nns) ? rowp(u)[u] : 1.0; rd[c] = 1.0 / dg[c]; }
-            auto apply = [&](int i, const double *cur) {
-                if (i < 0) return;
-                const int owner = i & 63, slot = i >> 6;
-                double yo = 0.0, dgo = 1.0, rdo = 1.0;
-#pragma unroll
-                for (int c = 0; c < CH; c++) if (slot == c) { yo = read_lane(y[c], owner); dgo = read_lane(dg[c], owner); rdo = read_lane(rd[c], owner); }
-                const double xi = div_by(yo, dgo, rdo);               // every lane computes the same x_i
-#pragma unroll
-                for (int c = 0; c < CH; c++) {
-                    if (c > slot) continue;
-                    const int u = lane + 64 * c;
-                    if (u < i) y[c] -= cur[c] * xi;
-                    else if (u == i) y[c] = xi;
+                for (int c = 0; c < SL; c++) y[c] -= cur[c] * xi;
+                const double upd = y[SL] - cur[SL] * xi;
+                y[SL] = (lane < owner) ? upd : (lane == owner ? xi : y[SL]);
+            };
+            auto run_slot = [&](auto sl_c, int &i) {
+                constexpr int SL = decltype(sl_c)::value;
+                if ((i >> 6) != SL) return;
+                double r0[CH], r1[CH], r2[CH], r3[CH];
+                // rows down to a multiple of four, one at a time; then four rows in flight down to the slot's first row
+                while (((i + 1) & 3) != 0) { fetch(i, r0, sl_c); apply(i, r0, sl_c); i--; }
+                if ((i >> 6) != SL) return;
+                fetch(i, r0, sl_c); fetch(i - 1, r1, sl_c); fetch(i - 2, r2, sl_c); fetch(i - 3, r3, sl_c);
+                for (; i >= 64 * SL; i -= 4) {
+                    apply(i, r0, sl_c);     fetch(i - 4, r0, sl_c);
+                    apply(i - 1, r1, sl_c); fetch(i - 5, r1, sl_c);
+                    apply(i - 2, r2, sl_c); fetch(i - 6, r2, sl_c);
+                    apply(i - 3, r3, sl_c); fetch(i - 7, r3, sl_c);
                 }
             };
-            fetch(nns - 1, r0); fetch(nns - 2, r1); fetch(nns - 3, r2);
-            for (int i = nns - 1; i >= 0; i -= 3) {
-                apply(i, r0); fetch(i - 3, r0);
-                apply(i - 1, r1); fetch(i - 4, r1);
-                apply(i - 2, r2); fetch(i - 5, r2);
-            }
+            int i = nns - 1;
+            if constexpr (CH > 3) run_slot(std::integral_constant<int, 3>{}, i);
+            run_slot(std::integral_constant<int, 2>{}, i);
+            run_slot(std::integral_constant<int, 1>{}, i);
+            run_slot(std::integral_constant<int, 0>{}, i);
 #pragma unroll
             for (int c = 0; c < CH; c++) { const int u = lane + 64 * c; if (u < nns) out[u] = y[c]; }
         }
@@ -1411,6 +1499,10 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
     };
     // ---- the interior point (src/optimizer.cpp:38-79)
+#ifdef SPG_IP_PROF
+    for (int u = 0; u < 16; u++) ipt[u] = 0;
+    ipt_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
     for (int it = tid; it < nx; it += NT) { const int o = it % DD; x[it] = (o / D == o % D) ? 1.0 : 0.0; }   // educatedGuess
     __syncthreads();
     {
@@ -1422,7 +1514,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
     }
 #ifdef SPG_IP_PROF
-    if (tid == 0) { long long tot = 0; for (int u = 0; u < 8; u++) tot += ipt[u]; printf("ipb %d %d %d %d %c %lld %lld %lld\n", k, E, nx, newton_steps, hx_tiled ? 'T' : hx_tiled2 ? 'U' : hx_lds ? 'A' : 'B', tot, ipt[2] + ipt[6] + ipt[7], ipt[3]); }
+    if (tid == 0) { long long tot = 0; for (int u = 0; u < 16; u++) tot += ipt[u]; printf("ipb %d %d %d %d %c %lld %lld %lld | %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld\n", k, E, nx, newton_steps, hx_tiled ? 'T' : hx_tiled2 ? 'U' : hx_lds ? 'A' : 'B', tot, ipt[2] + ipt[6] + ipt[7], ipt[3], ipt[0], ipt[1], ipt[2], ipt[3], ipt[4], ipt[5], ipt[6], ipt[7], ipt[8], ipt[9], ipt[10], ipt[11], ipt[12], ipt[13], ipt[14]); }
     if (tid == 0 && blockIdx.x == 0) printf("ip prof k=%d E=%d nx=%d steps=%d mode %c: other %lld hessian %lld chol(trailing+rest) %lld solve %lld value %lld gradient %lld | panel load %lld panel factor %lld (cycles)\n", k, E, nx, newton_steps, hx_lds ? 'A' : 'B', ipt[0], ipt[1], ipt[2], ipt[3], ipt[4], ipt[5], ipt[6], ipt[7]);
 #endif
     bool okf = false;
