@@ -141,6 +141,67 @@ __device__ __forceinline__ double read_lane(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// spgdev::tri_inverse_lower for n <= NMAX with thread c's column of L^-1 in registers (the LDS version reads back what
+// the same thread wrote a moment before: one LDS round trip per row and column). The sum for row i starts at column 0
+// instead of c: the entries above the diagonal are zeros, and adding zeros changes nothing. Same operations otherwise.
+template <int NMAX>
+__device__ __forceinline__ void tri_inverse_lower_reg(int tid, const double *L, double *Li, int n, int ld) {
+    if (tid < n) {
+        const int c = tid;
+        double col[NMAX];
+#pragma unroll
+        for (int i = 0; i < NMAX; i++) {
+            if (i < n) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < i; k++) s += L[i * ld + k] * col[k];
+                const double rd = spgdev::fast_rcp(L[i * ld + i]);
+                col[i] = (i < c) ? 0.0 : (i == c) ? rd : -s * rd;
+            } else col[i] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NMAX; i++) if (i < n) Li[i * ld + c] = col[i];
+    }
+    __syncthreads();
+}
+
+// spgdev::chol_lower for n <= NMAX by ONE wavefront with lane i holding row i in registers: the pivot and the scaled
+// column travel by lane reads, no LDS round trips and no barriers inside (the team version: two barriers and four LDS
+// round trips per column). Same operations in the same order; *flag = 1 on a non-positive pivot.
+template <int NMAX>
+__device__ __forceinline__ void chol_lower_reg(int tid, double *A, int n, int ld, int *flag) {
+    if (tid < 64) {
+        const int lane = tid;
+        const int ns = __builtin_amdgcn_readfirstlane(n);
+        double row[NMAX];
+#pragma unroll
+        for (int c = 0; c < NMAX; c++) row[c] = (lane < ns && c <= lane) ? A[lane * ld + c] : 0.0;
+        bool anybad = false;
+#pragma unroll
+        for (int j = 0; j < NMAX; j++) {
+            if (j < ns) {
+                double d = read_lane(row[j], j);
+                const bool bad = !(d > 0.0) || !isfinite(d);
+                if (bad) { d = 1.0; anybad = true; }
+                const double rs = spgdev::fast_rsqrt(d);
+                row[j] = (lane > j) ? row[j] * rs : (lane == j ? d * rs : row[j]);
+#pragma unroll
+                for (int cc = j + 1; cc < NMAX; cc++) {
+                    if (cc < ns) {
+                        const double v = read_lane(row[j], cc);
+                        const double upd = row[cc] - row[j] * v;
+                        row[cc] = (lane >= cc) ? upd : row[cc];
+                    }
+                }
+            }
+        }
+        if (anybad && lane == 0) *flag = 1;
+#pragma unroll
+        for (int c = 0; c < NMAX; c++) if (lane < ns && c <= lane) A[lane * ld + c] = row[c];
+    }
+    __syncthreads();
+}
+
 template <int D>
 __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     constexpr int DD = D * D, PS = (D == 6) ? 7 : 3, PSZ = (D == 6) ? 12 : 3, REC = PS + D * (D + 1) / 2;
@@ -696,7 +757,8 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         if (tid == 0) flag_s = 0;
         __syncthreads();
         IPT(10);
-        chol_lower<NT>(T, Mc, r, r);
+        if (r <= 32) chol_lower_reg<32>(tid, Mc, r, r, &flag_s);
+        else chol_lower<NT>(T, Mc, r, r);
         ok = flag_s == 0;
         __syncthreads();
         IPT(9);
@@ -938,7 +1000,8 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     };
     auto gradient = [&](const double *xv, double *gv) {
         if (!chol_ok) { for (int it = tid; it < nx; it += NT) gv[it] = 0.0; __syncthreads(); return; }
-        tri_inverse_lower<NT>(T, Mc, Li, r, r);
+        if (r <= 32) tri_inverse_lower_reg<32>(tid, Mc, Li, r, r);
+        else tri_inverse_lower<NT>(T, Mc, Li, r, r);
         IPT(5);
         gram_lower_inverse<NT>(T, Li, Mi, r, r);           // xinv = M^-1
         IPT(12);

@@ -222,3 +222,29 @@ def test_device_interior_point_dense_whole_graph(hip_ctx):
     assert st["kld_sum"] < 0.5 * stt["kld_sum"]
     print(f"manhattan prefix, Dense NFR: {same.sum()} of {fin.sum()} blankets identical (first other: k = {int(ob['k'][fin][first_bad]) if first_bad >= 0 else 0}), "
           f"kld_sum {st['kld_sum']:.6g} (Tree {stt['kld_sum']:.6g})")
+
+
+@pytest.mark.gpu
+def test_factorisation_paths_are_bit_identical(tmp_path):
+    """The Newton systems are factorised by one of three paths, chosen by size: register tiles (up to 247 variables), the
+    packed Hessian in LDS, panels out of the L2 workspace. They perform the same operations in the same order — the
+    records of a whole sphere.g2o run (1 248 blankets, ~75 k Newton steps, 108 to 252 variables) must agree byte for
+    byte between the default selection and the column-at-a-time / out-of-L2 paths. The selection is read once per
+    process, so each variant runs in a child process (tools/debug/ip_modes.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "debug", "ip_modes.py")
+    outs = {}
+    for name, env in (("default", {}), ("untiled", {"SPG_IP_UNTILED": "1"})):
+        out = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, tool, out, "sphere_full_nfr_tree"], env={**os.environ, **env}, cwd=root,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[name] = np.load(out)
+    a, b = outs["default"], outs["untiled"]
+    assert set(a.files) == set(b.files)
+    assert int((a["info"] >> 8).sum()) > 50000
+    for k in a.files:
+        assert a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), k
