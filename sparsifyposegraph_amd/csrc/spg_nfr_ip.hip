@@ -55,7 +55,7 @@ __host__ __device__ inline IpLayout ip_layout(int D, int k, int m, int E, bool c
     int64_t o = 0;
     auto take = [&](int64_t len) { int64_t at = o; o += (len + 7) & ~(int64_t)7; return at; };
     const int64_t n = L.n, N = L.N, r = L.r > 0 ? L.r : 1, q = L.q, nx = L.nx, P2 = (int64_t)k * (k - 1) / 2;
-    L.H = take(N * N); L.Lam = take(n * n); L.A1 = take(n * n); L.V = take(n * n); L.Hx = take(closed ? 8 : nx * nx + nx);   // (no Newton iterations when the pattern has a closed form)
+    L.H = take(N * N); L.Lam = take(n * n); L.A1 = take(n * n); L.V = take(n * n); L.Hx = take(closed ? 8 : (nx + 8) * (nx + 8));   // rows of nx + 8 doubles, nx + 8 of them: whole 8 x 8 tiles everywhere (no Newton iterations when the pattern has a closed form)
     L.pose = take(12 * (int64_t)(k + m)); L.w = take(4 * P2 + 8);
     L.Sc = take(3 * N * N + 5 * n * n);            // correlated input edges (J, W J), closed form of correlated new edges (J_e, G, C, W, X)
     L.zbuf = take(7 * (int64_t)(E + 1)); L.grp = take(2 * (int64_t)k + 8); L.otab = take(8 * (int64_t)k + 8);
@@ -233,6 +233,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     const bool hx_lds = !closed && packed_len <= (long long)a.lds_doubles;
     const bool hx_tiled = hx_lds && nx + 1 <= 176 && !a.ip_untiled;     // (A') below: the Hessian goes straight into register tiles
     const bool hx_tiled2 = !closed && !hx_tiled && nx + 1 > 176 && nx + 1 <= 248 && !a.ip_untiled;     // two tiles per thread, factor in the L2 workspace
+    const bool hx_streamed = !closed && !hx_lds && !hx_tiled2 && ((nx + 8) >> 3) * 73 <= kPanelDoubles && !a.ip_untiled;   // (B') below: up to 895 variables
     double *panel = lds_pool;
     const long long packed_pad = (packed_len + 1) & ~1LL;
     double *hot = hx_lds ? ((packed_pad + L.hot_total <= (int64_t)a.lds_doubles) ? lds_pool + packed_pad : ws + L.cold_total)
@@ -929,6 +930,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
 
     // ---- the function: value(xv) leaves chol(M) in Mc; gradient(xv, gv) leaves M^-1 in Mi and the X_e^-1 in Xi
     double *P = hot + L.P, *T2 = hot + L.T2, *Hx = ws + L.Hx, *Xi = hot + L.Xi;
+    const int ldh = nx + 8;       // row stride of the Hessian / its factor in the workspace
     double *x = hot + L.x, *xn = hot + L.xn, *g = hot + L.g, *gn = hot + L.gn, *dv = hot + L.dv;
     double rho = 0;
     // symmetric view of block e of xv from its lower triangle (column-major): X(i, j), i >= j, at xv[e DD + j D + i]
@@ -1132,7 +1134,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             const int e2 = t / DD, vv = (t - e2 * DD) / D, uu = t - e2 * DD - vv * D;
             double v = P[(e2 * D + uu) * q + e * D + ii] * P[(e * D + jj) * q + e2 * D + vv];
             if (e2 == e && chol_ok) v += rho * Xi[e * DD + uu * D + ii] * Xi[e * DD + jj * D + vv];
-            Hx[it] = v;
+            Hx[(long long)s * ldh + t] = v;
         }
         __syncthreads();
     };
@@ -1199,7 +1201,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         constexpr int CH = (NTL == 1) ? 3 : 4;                            // 64-entry chunks of the solution vector
         double *pan = (NTL == 1) ? colbuf : panel;
         double *Lb = (NTL == 1) ? lds_pool : Hx;                          // NTL == 1: packed rows in LDS; else nn-strided rows in L2
-        auto rowp = [&](int i) { return (NTL == 1) ? Lb + (long long)i * (i + 1) / 2 : Lb + (long long)i * nn; };
+        auto rowp = [&](int i) { return (NTL == 1) ? Lb + (long long)i * (i + 1) / 2 : Lb + (long long)i * ldh; };
         const int nr = nn + 1, nb = (nr + 7) >> 3;
         int I[NTL], C[NTL];
         double t[NTL][8][8];
@@ -1342,7 +1344,8 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         if (tid < 64) {
             const int lane = tid;
             const int nns = __builtin_amdgcn_readfirstlane(nn);       // the row loop runs on the scalar unit
-            auto srow = [&](int i) { return (NTL == 1) ? Lb + (long long)i * (i + 1) / 2 : Lb + (long long)i * nns; };
+            const int lds_ = __builtin_amdgcn_readfirstlane(ldh);
+            auto srow = [&](int i) { return (NTL == 1) ? Lb + (long long)i * (i + 1) / 2 : Lb + (long long)i * lds_; };
             double y[CH], dg[CH], rd[CH];       // the running vector, the diagonal of L and its reciprocals: entry u = lane + 64 c
 #pragma unroll
             for (int c = 0; c < CH; c++) {
@@ -1414,7 +1417,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             IPT(2);
             for (int rr = tid >> 4; rr < nrows; rr += NT / 16) {           // panel rows j0.., columns j0..j0+pb (lower part)
                 const int pc = tid & 15;
-                if (pc < pb) panel[rr * PBS + pc] = (pc <= rr) ? A[(long long)(j0 + rr) * nn + j0 + pc] : 0.0;
+                if (pc < pb) panel[rr * PBS + pc] = (pc <= rr) ? A[(long long)(j0 + rr) * ldh + j0 + pc] : 0.0;
             }
             __syncthreads();
             IPT(6);
@@ -1435,7 +1438,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             IPT(7);
             for (int rr = tid >> 4; rr < nrows; rr += NT / 16) {
                 const int pc = tid & 15;
-                if (pc < pb && pc <= rr) A[(long long)(j0 + rr) * nn + j0 + pc] = panel[rr * PBS + pc];
+                if (pc < pb && pc <= rr) A[(long long)(j0 + rr) * ldh + j0 + pc] = panel[rr * PBS + pc];
             }
             // trailing update: rows i >= j0 + pb (the right-hand side row included), columns j0 + pb <= c <= min(i, nn - 1)
             const int t0 = j0 + pb, wv = tid >> 6, lane = tid & 63;
@@ -1449,7 +1452,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                 for (int ib = (cb - lane) + RIF * wv; ib < nr; ib += 4 * RIF) {
                     double v[RIF];
 #pragma unroll
-                    for (int u = 0; u < RIF; u++) { const int i = ib + u; v[u] = (i < nr && cb <= i) ? A[(long long)i * nn + cb] : 0.0; }
+                    for (int u = 0; u < RIF; u++) { const int i = ib + u; v[u] = (i < nr && cb <= i) ? A[(long long)i * ldh + cb] : 0.0; }
 #pragma unroll
                     for (int u = 0; u < RIF; u++) {
                         const int i = ib + u;
@@ -1458,7 +1461,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                             double acc = v[u];
 #pragma unroll
                             for (int pc = 0; pc < 16; pc++) if (pc < pb) acc -= piv[pc] * pcv[pc];
-                            A[(long long)i * nn + cb] = acc;
+                            A[(long long)i * ldh + cb] = acc;
                         }
                     }
                 }
@@ -1471,21 +1474,21 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     // barriers: the running vector lives in LDS, a row of L is one coalesced read (the next row is fetched while the
     // current one is applied), right-looking: x_i = y_i / L_ii, then y_t -= L[i][t] x_i over the row.
     auto solve_rows = [&](const double *Lc, int nn, double *out) {
-        for (int it = tid; it < nn; it += NT) colbuf[it] = Lc[(long long)nn * nn + it];
+        for (int it = tid; it < nn; it += NT) colbuf[it] = Lc[(long long)nn * ldh + it];
         __syncthreads();
         if (tid < 64) {
             const int lane = tid;
             constexpr int CH = 4;                       // columns [0, 256) of a row travel in registers
             double cur[CH], nxt[CH];
             auto fetch = [&](int i, double *dst) {
-                const double *row = Lc + (long long)i * nn;
+                const double *row = Lc + (long long)i * ldh;
 #pragma unroll
                 for (int c = 0; c < CH; c++) { const int t = lane + 64 * c; dst[c] = (t <= i && t < nn) ? row[t] : 0.0; }
             };
             fetch(nn - 1, cur);
             for (int i = nn - 1; i >= 0; i--) {
                 if (i > 0) fetch(i - 1, nxt);
-                const double *row = Lc + (long long)i * nn;
+                const double *row = Lc + (long long)i * ldh;
                 const int owner = i & 63, slot = i >> 6;
                 double dii = (slot < CH) ? 0.0 : row[i];
 #pragma unroll
@@ -1505,6 +1508,111 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         for (int it = tid; it < nn; it += NT) out[it] = colbuf[it];
         __syncthreads();
     };
+    // (B') the tiled factorisation of (A') for matrices that do not fit the registers: the running matrix stays in the L2
+    // workspace (as in (B)) and a thread takes the 8 x 8 tiles right of the block column one after the other — load, 512
+    // FMAs from two panel blocks, store. Same steps 1-3, same operations in the same order; the panel (block stride 73)
+    // must fit its 64 KB of LDS: up to 895 variables. (B) swept the trailing matrix with one LDS read per FMA.
+    auto chol_streamed = [&](double *A, int nn) -> bool {
+        double *pan = panel;
+        const int nr = nn + 1, nb = (nr + 7) >> 3;
+        bool okc = true;
+        for (int J = 0; J < nb; J++) {
+            const int rb0 = J * 8;
+            for (int it = tid; it < (nb * 8 - rb0) * 8; it += NT) {
+                const int row = rb0 + (it >> 3), c = it & 7, col = rb0 + c;
+                pan[(row >> 3) * TB + (row & 7) * TR + c] = (row < nr && col < nn && col <= row) ? A[(long long)row * ldh + col] : 0.0;
+            }
+            __syncthreads();
+            IPT(2);
+            {
+                double d[8][8], rl[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+                const double *pj = pan + J * TB;
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+#pragma unroll
+                    for (int c = 0; c <= r; c++) d[r][c] = pj[r * TR + c];
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    if (J * 8 + jj < nn) {
+                        double dpiv = d[jj][jj];
+                        if (!(dpiv > 0.0) || !isfinite(dpiv)) { okc = false; dpiv = 1.0; }
+                        const double l = sqrt(dpiv);
+                        d[jj][jj] = l;
+                        rl[jj] = 1.0 / l;
+#pragma unroll
+                        for (int r = jj + 1; r < 8; r++) d[r][jj] = div_by(d[r][jj], l, rl[jj]);
+#pragma unroll
+                        for (int c = jj + 1; c < 8; c++)
+#pragma unroll
+                            for (int r = c; r < 8; r++) d[r][c] -= d[r][jj] * d[c][jj];
+                    }
+                }
+                for (int row = (J + 1) * 8 + tid; row < nr; row += NT) {
+                    double *pr = pan + (row >> 3) * TB + (row & 7) * TR;
+                    double *hr = A + (long long)row * ldh + J * 8;
+                    double v[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) v[jj] = pr[jj];
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) {
+#pragma unroll
+                        for (int u = 0; u < jj; u++) v[jj] -= v[u] * d[jj][u];
+                        v[jj] = div_by(v[jj], d[jj][jj], rl[jj]);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) { pr[jj] = v[jj]; hr[jj] = v[jj]; }
+                }
+                if (tid == NT - 1) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+#pragma unroll
+                        for (int c = 0; c <= r; c++) {
+                            const int rw = J * 8 + r, cl = J * 8 + c;
+                            if (rw < nr && cl < nn) A[(long long)rw * ldh + cl] = d[r][c];
+                        }
+                }
+            }
+            __syncthreads();
+            IPT(6);
+            const int na = nb - J - 1, nt = na * (na + 1) / 2;
+            for (int tix = tid; tix < nt; tix += NT) {
+                int i = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5);
+                while ((i + 1) * (i + 2) / 2 <= tix) i++;
+                while (i * (i + 1) / 2 > tix) i--;
+                const int I = J + 1 + i, C = J + 1 + tix - i * (i + 1) / 2;
+                double *at = A + (long long)(I * 8) * ldh + C * 8;
+                double t[8][8];
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const int row = I * 8 + r, col = C * 8 + c;
+                        t[r][c] = at[(long long)r * ldh + c];
+                    }
+                const double *pi = pan + I * TB, *pc = pan + C * TB;
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    double li[8], lc[8];
+#pragma unroll
+                    for (int r = 0; r < 8; r++) { li[r] = pi[r * TR + jj]; lc[r] = pc[r * TR + jj]; }
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+#pragma unroll
+                        for (int c = 0; c < 8; c++) t[r][c] -= li[r] * lc[c];
+                }
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const int row = I * 8 + r, col = C * 8 + c;
+                        at[(long long)r * ldh + c] = t[r][c];
+                    }
+            }
+            __syncthreads();
+            IPT(7);
+        }
+        return okc;
+    };
     // PQNOptimizer::optimize with useHessian (src/pqn/pqn_optimizer.cpp:29-126)
     int newton_steps = 0;
     auto optimize = [&](double tol) {
@@ -1523,9 +1631,9 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                 IPT(2);
                 if (!hok) return;
             } else {
-                for (int it = tid; it < nx; it += NT) Hx[(long long)nx * nx + it] = -g[it];     // the right-hand side rides along as row nx
+                for (int it = tid; it < nx; it += NT) Hx[(long long)nx * ldh + it] = -g[it];     // the right-hand side rides along as row nx
                 __syncthreads();
-                const bool hok = chol_rows(Hx, nx);
+                const bool hok = hx_streamed ? chol_streamed(Hx, nx) : chol_rows(Hx, nx);
                 IPT(2);
                 if (!hok) return;
                 solve_rows(Hx, nx, dv);     // d = -(L L^T)^-1 g
@@ -1577,7 +1685,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
     }
 #ifdef SPG_IP_PROF
-    if (tid == 0) { long long tot = 0; for (int u = 0; u < 16; u++) tot += ipt[u]; printf("ipb %d %d %d %d %c %lld %lld %lld | %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld\n", k, E, nx, newton_steps, hx_tiled ? 'T' : hx_tiled2 ? 'U' : hx_lds ? 'A' : 'B', tot, ipt[2] + ipt[6] + ipt[7], ipt[3], ipt[0], ipt[1], ipt[2], ipt[3], ipt[4], ipt[5], ipt[6], ipt[7], ipt[8], ipt[9], ipt[10], ipt[11], ipt[12], ipt[13], ipt[14]); }
+    if (tid == 0) { long long tot = 0; for (int u = 0; u < 16; u++) tot += ipt[u]; printf("ipb %d %d %d %d %c %lld %lld %lld | %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld\n", k, E, nx, newton_steps, hx_tiled ? 'T' : hx_tiled2 ? 'U' : hx_streamed ? 'S' : hx_lds ? 'A' : 'B', tot, ipt[2] + ipt[6] + ipt[7], ipt[3], ipt[0], ipt[1], ipt[2], ipt[3], ipt[4], ipt[5], ipt[6], ipt[7], ipt[8], ipt[9], ipt[10], ipt[11], ipt[12], ipt[13], ipt[14]); }
     if (tid == 0 && blockIdx.x == 0) printf("ip prof k=%d E=%d nx=%d steps=%d mode %c: other %lld hessian %lld chol(trailing+rest) %lld solve %lld value %lld gradient %lld | panel load %lld panel factor %lld (cycles)\n", k, E, nx, newton_steps, hx_lds ? 'A' : 'B', ipt[0], ipt[1], ipt[2], ipt[3], ipt[4], ipt[5], ipt[6], ipt[7]);
 #endif
     bool okf = false;
