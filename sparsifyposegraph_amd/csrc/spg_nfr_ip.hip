@@ -1128,13 +1128,17 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             __syncthreads();
             return;
         }
-        for (long long it = tid; it < (long long)nx * nx; it += NT) {
-            const int s = (int)(it / nx), t = (int)(it - (long long)s * nx);
-            const int e = s / DD, jj = (s - e * DD) / D, ii = s - e * DD - jj * D;
-            const int e2 = t / DD, vv = (t - e2 * DD) / D, uu = t - e2 * DD - vv * D;
-            double v = P[(e2 * D + uu) * q + e * D + ii] * P[(e * D + jj) * q + e2 * D + vv];
-            if (e2 == e && chol_ok) v += rho * Xi[e * DD + uu * D + ii] * Xi[e * DD + jj * D + vv];
-            Hx[(long long)s * ldh + t] = v;
+        // (the lower triangle only: nothing reads the rest; (s, t) walk the matrix without a division)
+        for (int s = tid / nx, t = tid - (tid / nx) * nx; s < nx; ) {
+            if (t <= s) {
+                const int e = s / DD, jj = (s - e * DD) / D, ii = s - e * DD - jj * D;
+                const int e2 = t / DD, vv = (t - e2 * DD) / D, uu = t - e2 * DD - vv * D;
+                double v = P[(e2 * D + uu) * q + e * D + ii] * P[(e * D + jj) * q + e2 * D + vv];
+                if (e2 == e && chol_ok) v += rho * Xi[e * DD + uu * D + ii] * Xi[e * DD + jj * D + vv];
+                Hx[(long long)s * ldh + t] = v;
+            }
+            t += NT;
+            while (t >= nx) { t -= nx; s++; }
         }
         __syncthreads();
     };
