@@ -1186,6 +1186,72 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         __syncthreads();
         return true;
     };
+    // L^T x = y for a factor in packed LDS rows (PACKED) or in the workspace square, nn <= 64 CH: see chol_solve_tiled
+    auto solve_reg = [&](auto ch_c, auto packed_c, int nn, double *out) {
+        constexpr int CH = decltype(ch_c)::value;
+        constexpr bool PACKED = decltype(packed_c)::value;
+        // L^T x = y (y = row nn) by one wavefront, right-looking over the rows of L from the last: the running vector lives in
+        // registers (entries lane, lane + 64, ...), x_i is computed by every lane from lane reads, rows are fetched three
+        // ahead (they come from L2 when two tiles per thread are in use). Same operations as the LDS version in (A).
+        if (tid < 64) {
+            const int lane = tid;
+            const int nns = __builtin_amdgcn_readfirstlane(nn);       // the row loop runs on the scalar unit
+            const int lds_ = __builtin_amdgcn_readfirstlane(ldh);
+            const double *Lb = PACKED ? lds_pool : Hx;
+            auto srow = [&](int i) { return PACKED ? Lb + (long long)i * (i + 1) / 2 : Lb + (long long)i * lds_; };
+            double y[CH], dg[CH], rd[CH];       // the running vector, the diagonal of L and its reciprocals: entry u = lane + 64 c
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const int u = lane + 64 * c;
+                y[c] = (u < nns) ? srow(nns)[u] : 0.0;
+                dg[c] = (u < nns) ? srow(u)[u] : 1.0;
+                rd[c] = 1.0 / dg[c];
+            }
+            // chunks 0..CM of row i (entries beyond the diagonal are read as the diagonal entry and never used: no branches)
+            auto fetch = [&](int i, double *dst, auto cm_c) {
+                constexpr int CM = decltype(cm_c)::value;
+                const int ic = max(i, 0);
+                const double *row = srow(ic);
+#pragma unroll
+                for (int c = 0; c <= CM; c++) dst[c] = row[min(lane + 64 * c, ic)];
+            };
+            // row i of slot SL = i >> 6 (compile time): x_i from its owner's y, then y_u -= L[i][u] x_i for u < i
+            auto apply = [&](int i, const double *cur, auto sl_c) {
+                constexpr int SL = decltype(sl_c)::value;
+                const int owner = i & 63;
+                const double xi = div_by(read_lane(y[SL], owner), read_lane(dg[SL], owner), read_lane(rd[SL], owner));   // every lane computes the same x_i
+#pragma unroll
+                for (int c = 0; c < SL; c++) y[c] -= cur[c] * xi;
+                const double upd = y[SL] - cur[SL] * xi;
+                y[SL] = (lane < owner) ? upd : (lane == owner ? xi : y[SL]);
+            };
+            auto run_slot = [&](auto sl_c, int &i) {
+                constexpr int SL = decltype(sl_c)::value;
+                if ((i >> 6) != SL) return;
+                double r0[CH], r1[CH], r2[CH], r3[CH];
+                // rows down to a multiple of four, one at a time; then four rows in flight down to the slot's first row
+                while (((i + 1) & 3) != 0) { fetch(i, r0, sl_c); apply(i, r0, sl_c); i--; }
+                if ((i >> 6) != SL) return;
+                fetch(i, r0, sl_c); fetch(i - 1, r1, sl_c); fetch(i - 2, r2, sl_c); fetch(i - 3, r3, sl_c);
+                for (; i >= 64 * SL; i -= 4) {
+                    apply(i, r0, sl_c);     fetch(i - 4, r0, sl_c);
+                    apply(i - 1, r1, sl_c); fetch(i - 5, r1, sl_c);
+                    apply(i - 2, r2, sl_c); fetch(i - 6, r2, sl_c);
+                    apply(i - 3, r3, sl_c); fetch(i - 7, r3, sl_c);
+                }
+            };
+            int i = nns - 1;
+            auto run_all = [&](auto self, auto sl_c, int &ii) -> void {
+                constexpr int SL = decltype(sl_c)::value;
+                run_slot(sl_c, ii);
+                if constexpr (SL > 0) self(self, std::integral_constant<int, SL - 1>{}, ii);
+            };
+            run_all(run_all, std::integral_constant<int, CH - 1>{}, i);
+#pragma unroll
+            for (int c = 0; c < CH; c++) { const int u = lane + 64 * c; if (u < nns) out[u] = y[c]; }
+        }
+        __syncthreads();
+    };
     // (A') the same factorisation with the running matrix in REGISTERS: thread t owns the 8 x 8 tile (I, C), C <= I, of the
     // lower triangle (rows incl. the right-hand side row nn), 253 tiles at most, so nn + 1 <= 176. Per block column J:
     //   1. the owners of column J's tiles put their running values into the LDS panel (row stride 9, block stride 73:
@@ -1342,64 +1408,8 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
         IPT(2);
         if (!okc) return false;
-        // L^T x = y (y = row nn) by one wavefront, right-looking over the rows of L from the last: the running vector lives in
-        // registers (entries lane, lane + 64, ...), x_i is computed by every lane from lane reads, rows are fetched three
-        // ahead (they come from L2 when two tiles per thread are in use). Same operations as the LDS version in (A).
-        if (tid < 64) {
-            const int lane = tid;
-            const int nns = __builtin_amdgcn_readfirstlane(nn);       // the row loop runs on the scalar unit
-            const int lds_ = __builtin_amdgcn_readfirstlane(ldh);
-            auto srow = [&](int i) { return (NTL == 1) ? Lb + (long long)i * (i + 1) / 2 : Lb + (long long)i * lds_; };
-            double y[CH], dg[CH], rd[CH];       // the running vector, the diagonal of L and its reciprocals: entry u = lane + 64 c
-#pragma unroll
-            for (int c = 0; c < CH; c++) {
-                const int u = lane + 64 * c;
-                y[c] = (u < nns) ? srow(nns)[u] : 0.0;
-                dg[c] = (u < nns) ? srow(u)[u] : 1.0;
-                rd[c] = 1.0 / dg[c];
-            }
-            // chunks 0..CM of row i (entries beyond the diagonal are read as the diagonal entry and never used: no branches)
-            auto fetch = [&](int i, double *dst, auto cm_c) {
-                constexpr int CM = decltype(cm_c)::value;
-                const int ic = max(i, 0);
-                const double *row = srow(ic);
-#pragma unroll
-                for (int c = 0; c <= CM; c++) dst[c] = row[min(lane + 64 * c, ic)];
-            };
-            // row i of slot SL = i >> 6 (compile time): x_i from its owner's y, then y_u -= L[i][u] x_i for u < i
-            auto apply = [&](int i, const double *cur, auto sl_c) {
-                constexpr int SL = decltype(sl_c)::value;
-                const int owner = i & 63;
-                const double xi = div_by(read_lane(y[SL], owner), read_lane(dg[SL], owner), read_lane(rd[SL], owner));   // every lane computes the same x_i
-#pragma unroll
-                for (int c = 0; c < SL; c++) y[c] -= cur[c] * xi;
-                const double upd = y[SL] - cur[SL] * xi;
-                y[SL] = (lane < owner) ? upd : (lane == owner ? xi : y[SL]);
-            };
-            auto run_slot = [&](auto sl_c, int &i) {
-                constexpr int SL = decltype(sl_c)::value;
-                if ((i >> 6) != SL) return;
-                double r0[CH], r1[CH], r2[CH], r3[CH];
-                // rows down to a multiple of four, one at a time; then four rows in flight down to the slot's first row
-                while (((i + 1) & 3) != 0) { fetch(i, r0, sl_c); apply(i, r0, sl_c); i--; }
-                if ((i >> 6) != SL) return;
-                fetch(i, r0, sl_c); fetch(i - 1, r1, sl_c); fetch(i - 2, r2, sl_c); fetch(i - 3, r3, sl_c);
-                for (; i >= 64 * SL; i -= 4) {
-                    apply(i, r0, sl_c);     fetch(i - 4, r0, sl_c);
-                    apply(i - 1, r1, sl_c); fetch(i - 5, r1, sl_c);
-                    apply(i - 2, r2, sl_c); fetch(i - 6, r2, sl_c);
-                    apply(i - 3, r3, sl_c); fetch(i - 7, r3, sl_c);
-                }
-            };
-            int i = nns - 1;
-            if constexpr (CH > 3) run_slot(std::integral_constant<int, 3>{}, i);
-            run_slot(std::integral_constant<int, 2>{}, i);
-            run_slot(std::integral_constant<int, 1>{}, i);
-            run_slot(std::integral_constant<int, 0>{}, i);
-#pragma unroll
-            for (int c = 0; c < CH; c++) { const int u = lane + 64 * c; if (u < nns) out[u] = y[c]; }
-        }
-        __syncthreads();
+        if constexpr (NTL == 1) solve_reg(std::integral_constant<int, 3>{}, std::true_type{}, nn, out);
+        else solve_reg(std::integral_constant<int, 4>{}, std::false_type{}, nn, out);
         IPT(3);
         return true;
     };
@@ -1640,7 +1650,8 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                 const bool hok = hx_streamed ? chol_streamed(Hx, nx) : chol_rows(Hx, nx);
                 IPT(2);
                 if (!hok) return;
-                solve_rows(Hx, nx, dv);     // d = -(L L^T)^-1 g
+                if (hx_streamed && nx <= 511) solve_reg(std::integral_constant<int, 8>{}, std::false_type{}, nx, dv);
+                else solve_rows(Hx, nx, dv);     // d = -(L L^T)^-1 g
                 IPT(3);
             }
             double gd = 0, da = 0;
