@@ -270,6 +270,12 @@ int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, int n, const
  * (per-blanket chain latency ~ n^2.5, blankets resident per GPU from the LDS carve-up, exchange = latency + bytes /
  * link rate; constants in csrc/spg_host.cpp). spg_graph_set_shard_threshold(g, n >= 0) replaces it by "at least n
  * blankets" (0 = always; used by tests). */
+/* Which driver spg_graph_marginalize uses for a single-rank NFR Tree call at the stored estimates. Default (-1): the
+ * streaming driver on the HIP backend (one blanket = one item of the persistent worker kernel's queue, committed as its
+ * ready word arrives; blankets the worker does not take fall back to the batch driver), the batch driver on an injected
+ * backend. seed >= 0: tests — the streaming driver also runs on an injected backend, its "device" completing the
+ * blankets in flight in an order drawn from the seed (0: all, oldest first). seed = -2: never stream (A/B). */
+int spg_graph_set_stream_emulation(spg_graph *g, int seed);
 /* per-removed-vertex diagnostics of the last marginalize call, in processing order */
 int spg_graph_last_blanket_count(const spg_graph *g);
 int spg_graph_last_blankets(const spg_graph *g, int32_t *root_id, int32_t *round, int32_t *status,

@@ -128,14 +128,20 @@ struct spg_ctx {
     void *rccl = nullptr;         // communicator handle of csrc/spg_rccl.cpp (nullptr: single rank / no id given)
     int tag_counter = 0;          // ready tags are unique per context (its mailboxes are shared by all graphs)
     int linear_solver = 0;        // SPG_SOLVER_*: dense / block-sparse factorisation for optimize() and the global KLD
+    spg::StreamPort *sim_port = nullptr;   // tools/host_sim.cpp only: a simulated persistent worker behind an injected backend
     char err[768] = {0};
 };
 
-// 24 bytes; a pose-pose edge carries its two endpoints inline (vtx[0], vtx[1]) — the scheduler walks
-// edges by the million and would otherwise take a second cache miss per edge for the endpoint list;
-// an n-ary GLC edge keeps its vertices in spg_graph::everts at index vtx[0].
+// 32 bytes (two per cache line, never straddling one); a pose-pose edge carries its two endpoints inline (vtx[0],
+// vtx[1]) — the scheduler walks edges by the million and would otherwise take a second cache miss per edge for the
+// endpoint list; an n-ary GLC edge keeps its vertices in spg_graph::everts at index vtx[0].
+// `key` orders the edges of a blanket for the Hessian sum: the position the edge has in the REFERENCE's sequential
+// execution (insertion order; edges created by a removal come after everything that existed when the call began, in
+// removal-list order of their root, then in emission order) — the order g2o's edge set hands them out in the
+// sequential loop, and independent of the order in which this library happens to commit commuting removals.
 struct GEdge {
     int64_t off;
+    int64_t key;
     int32_t len;
     int32_t vtx[2];
     int16_t nv;
@@ -194,9 +200,28 @@ struct spg_graph {
     std::unordered_map<int32_t, int32_t> vidx;
     std::vector<uint8_t> valive;
     std::vector<int64_t> vpose;
-    // per vertex, one cache line: adjacency (live edge ids) + the scheduler's owner list
-    struct alignas(64) VRec { InlVec<int32_t, 6> adj; InlVec<struct OwnRefT, 3> own; };
+    // Per vertex, two cache lines. Line 0: adjacency — live edge ids, each with the far endpoint of a pose-pose edge
+    // (-1 for an n-ary edge), so that walking a neighbourhood reads no edge records. Line 1: the streaming driver's
+    // state of the vertex and what a hand-over needs of it (copies of vid[] / vpose[]).
+    struct AdjEnt { int32_t eid, other; operator int32_t() const { return eid; } };
+    struct SVtx {                                     // 32 bytes
+        int32_t pos;                                  // position in the removal list of the running call, -1 = not in it
+        uint8_t state, nown, lidx, pad_;              // SV_* ; registered blankets that contain the vertex: own[0 .. nown); index in the blanket being examined
+        int32_t own[4];
+        int32_t slot;                                 // SV_STABLE / SV_INFLIGHT: the slot that holds the vertex's blanket
+        int32_t stamp;                                // == spg_graph::sstamp: the vertex is in the blanket being examined
+    };
+    struct alignas(64) VRec {
+        InlVec<AdjEnt, 7> adj;
+        SVtx s;
+        int32_t id, pad_;
+        int64_t pose;
+        char spare_[16];
+        VRec() { s.pos = -1; s.state = 0; s.nown = 0; s.lidx = 0; s.pad_ = 0; s.slot = -1; s.stamp = 0; id = 0; pad_ = 0; pose = 0; }
+    };
     std::vector<VRec> vr;
+    std::vector<InlVec<struct OwnRefT, 3>> vown;      // batch scheduler: owners whose vertex set holds the vertex
+    int32_t sstamp = 0;
     std::vector<GEdge> edges;
     std::vector<int32_t> everts;
     int n_live_v = 0, n_live_e = 0;
@@ -250,6 +275,11 @@ struct spg_graph {
     } sub;
     std::vector<int32_t> live_rank;                   // edge id -> index among live edges (spg_graph_vertex_edges)
     long n_mutations = 0, live_rank_stamp = -1;       // bumped whenever an edge is added or dies
+    // canonical edge keys (GEdge::key): next key for an edge added by the caller; base of the running marginalisation
+    // (new edge e of the removal at list position p gets key_base + p * kKeyStride + e)
+    int64_t next_key = 0, key_base = 0;
+    static constexpr int64_t kKeyStride = 65536;
+    std::vector<int32_t> lpos;                        // vertex index -> position in the removal list of the running call, -1 otherwise
     // scheduler scratch
     std::vector<int32_t> vstamp, estamp;
     int32_t stamp = 0;
@@ -259,6 +289,19 @@ struct spg_graph {
     std::vector<double> s_cost;
     std::vector<int> s_first;
     std::vector<int64_t> s_chunk_len;
+    // ---- streaming driver (stream_marginalize below): per-vertex / per-slot / per-position state, kept between calls
+    static constexpr int kSOwn = 4, kSMaxV = 16, kSMaxE = 44;
+    struct SSlot {                                    // one blanket in flight
+        int32_t pos, root, nv, ne, n_new_max, tag, logi, bell;
+        int32_t launched, pad_;                       // 0: a reservation (the blanket of a waiting entry), 1: in flight
+        int64_t new_off, out_off;                     // out_off: emulated port only (out record in the arena), else -1
+        int32_t verts[kSMaxV];                        // removed vertex first, kept ones in ascending id
+        int32_t edges[kSMaxE];                        // ascending key
+    };
+    std::vector<SSlot> sslots;
+    std::vector<int32_t> s_free, s_fifo, s_fin, s_woken, s_ready, wl_next, wl_stable, wl_done;
+    int stream_emulation = -1;                        // tests (spg_graph_set_stream_emulation): >= 0 = completion-order seed
+    int stream_disabled = 0;                          // SPG_STREAM=0 or spg_graph_set_stream_emulation(g, -2)
 };
 
 static inline const int32_t *edge_verts(const spg_graph *g, const GEdge &e) {
@@ -481,13 +524,16 @@ extern "C" int spg_graph_add_vertex(spg_graph *g, int id, const double *pose) {
     g->vidx[id] = idx;
     g->valive.push_back(1);
     g->vr.emplace_back();
+    g->vown.emplace_back();
     g->vpose.push_back(arena_push(g, pose, g->ps));
+    g->vr.back().id = id;
+    g->vr.back().pose = g->vpose.back();
     g->n_live_v++;
     return 0;
 }
 
 static void quiesce_submission(spg_graph *g);
-static int add_edge_idx(spg_graph *g, int kind, int nv, const int32_t *vix, int64_t off, int32_t len) {
+static int add_edge_idx(spg_graph *g, int kind, int nv, const int32_t *vix, int64_t off, int32_t len, int64_t key = -1) {
     // the submission thread reads edges[] / everts[] of batches in its queue: never move them under it
     if (g->sub_active && (g->edges.size() == g->edges.capacity() || (nv != 2 && g->everts.size() + (size_t)nv > g->everts.capacity()))) {
         quiesce_submission(g);
@@ -496,6 +542,7 @@ static int add_edge_idx(spg_graph *g, int kind, int nv, const int32_t *vix, int6
     }
     GEdge e;
     e.kind = (int8_t)kind; e.nv = (int16_t)nv; e.len = len; e.off = off; e.alive = 1;
+    e.key = key >= 0 ? key : g->next_key++;
     if (nv == 2) { e.vtx[0] = vix[0]; e.vtx[1] = vix[1]; }
     else { e.vtx[0] = (int32_t)g->everts.size(); e.vtx[1] = 0; }
     int32_t eid = (int32_t)g->edges.size();
@@ -505,7 +552,7 @@ static int add_edge_idx(spg_graph *g, int kind, int nv, const int32_t *vix, int6
     for (int i = 0; i < nv; i++) {
         bool dup = false;
         for (int j = 0; j < i; j++) dup |= (vix[j] == vix[i]);
-        if (!dup) g->vr[vix[i]].adj.push_back(eid);
+        if (!dup) g->vr[vix[i]].adj.push_back({eid, (nv == 2 && kind == SPG_EDGE_BINARY) ? vix[1 - i] : -1});
     }
     g->n_live_e++;
     return eid;
@@ -971,7 +1018,8 @@ static void collect_edges(spg_graph *g, const int32_t *verts, int nverts, const 
             if (ok && (intra || hub)) out.push_back(eid);
         }
     }
-    std::sort(out.begin(), out.end());
+    // (ascending key = the reference's sequential edge order, whatever order commuting removals were committed in)
+    std::sort(out.begin(), out.end(), [g](int32_t a, int32_t b) { return g->edges[a].key < g->edges[b].key; });
 }
 
 static void new_edge_budget(const spg_options &o, int d, int k, int32_t &n_new_max, int32_t &n_new_vert_max, int64_t &new_len) {
@@ -1054,12 +1102,12 @@ static void schedule_round(spg_graph *g) {
         int32_t oid = owner_acquire(g, batch, off, len);
         const uint32_t gen = g->owners[oid].gen;
         const int32_t *set = owner_set(g, g->owners[oid]);
-        for (int32_t i = 0; i < len; i++) g->vr[set[i]].own.push_back({oid, gen});
+        for (int32_t i = 0; i < len; i++) g->vown[set[i]].push_back({oid, gen});
         return oid;
     };
     // live owners of x, dropping stale references on the way
     auto for_owners = [&](int32_t x, auto &&fn) {
-        auto &vo = g->vr[x].own;
+        auto &vo = g->vown[x];
         for (size_t i = 0; i < vo.size();) {
             const spg_graph::OwnRef r = vo[i];
             if (g->owners[r.oid].gen != r.gen) { vo[i] = vo.back(); vo.pop_back(); continue; }
@@ -1194,14 +1242,19 @@ extern "C" int spg_graph_marginalize_begin(spg_graph *g, const int32_t *which, i
     g->pending.clear();
     g->pend_head = 0;
     g->in_set.assign(g->vid.size(), 0);
+    g->lpos.assign(g->vid.size(), -1);
     for (int i = 0; i < n; i++) {
         auto it = g->vidx.find(which[i]);
         if (it == g->vidx.end() || !g->valive[it->second])
             return set_err(g->ctx, SPG_EINVAL, "vertex needs to exist in order to be marginalized");
         if (g->in_set[it->second]) continue;
         g->in_set[it->second] = 1;
+        g->lpos[it->second] = (int32_t)g->pending.size();
         g->pending.push_back(it->second);
     }
+    // keys of the edges this call creates: after everything that exists, ordered by list position of their root
+    g->key_base = g->next_key;
+    g->next_key = g->key_base + ((int64_t)g->pending.size() + 1) * spg_graph::kKeyStride;
     // room for the regions of the rounds to come (grown later if this estimate is short)
     if (int rc = arena_ensure(g, g->used * 3 + (1 << 20))) return rc;
     if (int rc = sync_device(g)) return rc;
@@ -1724,7 +1777,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
             vix.resize(nv);
             for (int i = 0; i < nv; i++) vix[i] = rverts[(int)rec[SPG_OUT_HDR + 4 * bd.n_new_max + vpos + i]];
             vpos += nv;
-            add_edge_idx(g, kind, nv, vix.data(), bd.new_off + rel, len);
+            add_edge_idx(g, kind, nv, vix.data(), bd.new_off + rel, len, g->key_base + (int64_t)g->lpos[r.root] * spg_graph::kKeyStride + e);
             g->stats.n_new_edges++;
         }
         PT(10);
@@ -1778,6 +1831,608 @@ static void move_blankets(spg_graph *g, Batch &a, size_t from, size_t to, Batch 
     }
 }
 
+
+// ================================================================================= streaming driver
+// The batch driver above hands the device ~50 blankets at a time and commits them as a unit; on graphs whose removals
+// form long dependent chains (ring lattices: 250 rounds of 200) the host then idles while a batch is in flight and the
+// device idles while the host commits and selects. Here ONE blanket is the unit: it is handed to the persistent worker
+// kernel as one queue item the moment the rule below allows it, and committed the moment its ready word arrives,
+// whatever else is in flight. Nothing is rescanned: a vertex that cannot go yet is parked on the ONE event that blocks
+// it (an earlier vertex being launched, or being committed) and looked at again when that event happens.
+//
+// Rule. Positions are indices into the removal list; a vertex is WAITING, INFLIGHT (handed over, not committed) or DONE
+// (committed: the host graph holds its effect). In the current host graph G, with X = N[v], WAITING v may be launched iff
+//   (A) no vertex of X \ {v} is an earlier list entry that is not DONE (and none is INFLIGHT at all);
+//   (B) for every x in X: every in-flight blanket that contains x contains no other vertex of X (and none contains v);
+//       and no neighbour of any x in X \ {v} is an earlier WAITING list entry;
+//   (C) no in-flight blanket of (B) that belongs to an earlier list entry contains a WAITING list entry earlier than v.
+// Why this is the sequential result (src/vertex_remover.cpp:83-140 removes in list order): two removals commute when
+// neither centre is in the other's blanket and the blankets share at most one vertex (header of this file). Take the
+// earlier not-DONE entries in list order and assume the first one, u, whose blanket AT ITS TURN meets X in a vertex it
+// does not meet now. The edge u - x it needs is created by a still earlier not-DONE removal whose blanket holds u and
+// x; that one meets X, so it is one of the in-flight blankets seen in (B); u is in it, earlier than v and not INFLIGHT
+// (an INFLIGHT vertex had no earlier not-DONE neighbour, (A)) — which (C) excludes. Hence the earlier removals that ever
+// touch X are exactly the in-flight ones of (B), with frozen blankets sharing one vertex with X, and nothing earlier
+// touches v, so X and its edges are what they will be at v's turn. (A vertex in flight was launched under the same
+// rule, so later entries that run before v were checked against v from their side.)
+// The earliest WAITING entry is only ever blocked by in-flight blankets, so the stream always makes progress.
+// tests/test_stream_scheduler.py drives this code on the CPU with adversarial completion orders against the oracle.
+#if defined(__x86_64__)
+#include <x86intrin.h>
+static inline uint64_t ticks_now() { return __rdtsc(); }
+#else
+static inline uint64_t ticks_now() { return (uint64_t)(now_s() * 1e9); }
+#endif
+
+namespace {
+enum : uint8_t { SV_WAITING = 0, SV_STABLE = 1, SV_INFLIGHT = 2, SV_DONE = 3 };
+constexpr int kStreamSlots = 2048;       // blankets in flight at most (the worker has 256 workgroups; the rest queue)
+constexpr int kStreamMailStride = 80;    // doubles per mailbox cell (>= SPG_OUT_LEN of the largest blanket a worker takes)
+
+struct Streamer {
+    spg_graph *g;
+    spg::StreamPort port;
+    const bool emulate;
+    const int D, ps, rec;
+    const int32_t P;                     // list positions
+    int32_t cursor = 0;                  // positions below it have been examined at least once
+    int32_t n_done = 0, n_inflight = 0, pending_bell = 0, bell_no = 0;
+    bool fallback = false;               // a blanket the worker does not take (or the arena is full): drain, then the batch driver
+    int rc = 0;
+    size_t fifo_head = 0;
+    int32_t cap_wait = -1;               // positions parked for a free slot
+    uint64_t rng;
+    double alg_bytes = 0;
+    uint64_t t_idle = 0;
+    void *arena_dev;
+
+    Streamer(spg_graph *g_, bool emu) : g(g_), emulate(emu), D(g_->d), ps(g_->ps), rec(g_->rec), P((int32_t)g_->pending.size()), arena_dev(g_->dev) {}
+
+    struct SvView { spg_graph::VRec *vr; spg_graph::SVtx &operator[](int32_t i) const { return vr[i].s; } };
+
+    long n_exam = 0, n_park[8] = {0};
+    // SPG_STREAM_PROF=1: TSC ticks per phase (poll, commit, examine -> parked, examine -> launch decision, packet, doorbell, late results)
+    const bool prof = [] { const char *e = getenv("SPG_STREAM_PROF"); return e && e[0] == '1'; }();
+    uint64_t pt[8] = {0}, pn[8] = {0}, pt_last = 0;
+    inline void P0() { if (prof) pt_last = ticks_now(); }
+    inline void P1(int i) { if (prof) { const uint64_t n = ticks_now(); pt[i] += n - pt_last; pn[i]++; pt_last = n; } }
+    void park(std::vector<int32_t> &heads, int32_t on, int32_t p) { g->wl_next[p] = heads[on]; heads[on] = p; }
+    void wake(std::vector<int32_t> &heads, int32_t on) {
+        for (int32_t p = heads[on]; p >= 0;) { const int32_t nx = g->wl_next[p]; g->s_woken.push_back(p); p = nx; }
+        heads[on] = -1;
+    }
+
+    // v passed (A): its blanket X is final as a vertex set. If it has to wait all the same, the set is registered like
+    // the blanket of a launched vertex (a reservation), so that later entries are checked against it instead of waiting
+    // for it; the slot becomes the blanket's own when it is launched. Without a free slot the vertex simply stays WAITING.
+    void reserve(const int32_t p, const int32_t *X, const int nX) {
+        const SvView sv{g->vr.data()};
+        const int32_t v = X[0];
+        if (sv[v].state != SV_WAITING || g->s_free.size() < 64) return;
+        for (int i = 0; i < nX; i++) if (sv[X[i]].nown == spg_graph::kSOwn) return;
+        const int32_t s = g->s_free.back(); g->s_free.pop_back();
+        spg_graph::SSlot &sl = g->sslots[s];
+        sl.pos = p; sl.root = v; sl.nv = nX; sl.ne = 0; sl.launched = 0; sl.logi = -1;
+        memcpy(sl.verts, X, sizeof(int32_t) * (size_t)nX);
+        for (int i = 0; i < nX; i++) { spg_graph::SVtx &sx = sv[X[i]]; sx.own[sx.nown++] = s; }
+        sv[v].state = SV_STABLE; sv[v].slot = s;
+        if (g->wl_stable[p] >= 0) wake(g->wl_stable, p);
+    }
+
+    int examine(const int32_t p) {
+        P0();
+        const int r = examine_impl(p);
+        P1(r ? 7 : 2);
+        return r;
+    }
+    // 1 = launched, 0 = parked / nothing to do
+    int examine_impl(const int32_t p) {
+        const SvView sv{g->vr.data()};
+        const int32_t v = g->pending[p];
+        if (sv[v].state != SV_WAITING && sv[v].state != SV_STABLE) return 0;
+        n_exam++;
+        spg_graph::VRec *const vr = g->vr.data();
+        const GEdge *const edges = g->edges.data();
+        const spg_graph::SSlot *const slots = g->sslots.data();
+        const int32_t st = ++g->sstamp;
+        int32_t X[spg_graph::kSMaxV];
+        int nX = 1;
+        int32_t mine = -1;                       // the slot of v's reservation
+        if (sv[v].state == SV_STABLE) {
+            mine = sv[v].slot;
+            nX = slots[mine].nv;
+            memcpy(X, slots[mine].verts, sizeof(int32_t) * (size_t)nX);
+            for (int i = 0; i < nX; i++) { sv[X[i]].stamp = st; sv[X[i]].lidx = (uint8_t)i; }
+        } else {
+            X[0] = v; sv[v].stamp = st;
+            for (const spg_graph::AdjEnt &a : vr[v].adj) {
+                const int32_t u = a.other;
+                if (u < 0) { fallback = true; return 0; }   // an n-ary edge: not for the worker
+                if (sv[u].stamp != st) {
+                    if (nX == spg_graph::kSMaxV) { fallback = true; return 0; }
+                    sv[u].stamp = st; X[nX++] = u;
+                }
+            }
+            const int k0 = nX - 1;
+            if (k0 < 1 || D * k0 > spg::kWorkerMaxN) { fallback = true; return 0; }
+            // (A)
+            for (int i = 1; i < nX; i++) {
+                const spg_graph::SVtx &sx = sv[X[i]];
+                // (a DONE entry that is still in the graph kept a status that forbids the graph update: it is inert)
+                if (sx.pos >= 0 && sx.state != SV_DONE && (sx.pos < p || sx.state == SV_INFLIGHT)) { n_park[0]++; park(g->wl_done, sx.pos, p); return 0; }
+            }
+            // kept vertices in ascending id (buildSubgraph's order, src/vertex_remover.cpp:349-356)
+            for (int i = 2; i < nX; i++) {
+                const int32_t x = X[i], idx = vr[x].id;
+                int j = i - 1;
+                for (; j >= 1 && vr[X[j]].id > idx; j--) X[j + 1] = X[j];
+                X[j + 1] = x;
+            }
+            for (int i = 0; i < nX; i++) sv[X[i]].lidx = (uint8_t)i;
+        }
+        const int k = nX - 1;
+        // (B), registered blankets (in flight, or reserved by an earlier entry that is itself waiting), and (C)
+        for (int j = 0; j < sv[v].nown; j++) if (sv[v].own[j] != mine) { n_park[1]++; park(g->wl_done, slots[sv[v].own[j]].pos, p); return 0; }
+        int32_t hs[spg_graph::kSMaxV * spg_graph::kSOwn];
+        int nh = 0;
+        for (int i = 1; i < nX; i++) {
+            const spg_graph::SVtx &sx = sv[X[i]];
+            for (int j = 0; j < sx.nown; j++) {
+                const int32_t s = sx.own[j];
+                if (s == mine) continue;
+                if (!slots[s].launched && slots[s].pos > p) continue;   // a later entry's reservation: it is checked against v, not v against it
+                for (int h = 0; h < nh; h++) if (hs[h] == s) { n_park[2]++; reserve(p, X, nX); park(g->wl_done, slots[s].pos, p); return 0; }
+                hs[nh++] = s;
+            }
+        }
+        for (int h = 0; h < nh; h++) {
+            const spg_graph::SSlot &o = slots[hs[h]];
+            if (o.pos > p) continue;
+            for (int i = 0; i < o.nv; i++) {
+                const spg_graph::SVtx &sy = sv[o.verts[i]];
+                if (sy.pos >= 0 && sy.pos < p && sy.state == SV_WAITING) { n_park[3]++; reserve(p, X, nX); park(g->wl_done, o.pos, p); return 0; }
+            }
+        }
+        // (B), entries without a final blanket, fused with markovBlanketEdges (src/vertex_remover.cpp:225-251): one pass over
+        // the adjacency of X \ {v}; no edge record is read (the far endpoints are in the adjacency entries)
+        int32_t E[spg_graph::kSMaxE];
+        int ne = 0;
+        for (int i = 1; i < nX; i++) {
+            for (const spg_graph::AdjEnt &a : vr[X[i]].adj) {
+                const int32_t y = a.other;
+                if (y < 0) { fallback = true; return 0; }
+                const spg_graph::SVtx &sy = sv[y];
+                if (sy.stamp == st) {
+                    const int j = sy.lidx;
+                    if (j == 0 || j >= i) {   // every blanket edge once: from its kept end, or from the lower-numbered of two kept ends
+                        if (ne == spg_graph::kSMaxE) { fallback = true; return 0; }
+                        E[ne++] = a.eid;
+                    }
+                } else if (sy.pos >= 0 && sy.pos < p && sy.state == SV_WAITING) { n_park[4]++; reserve(p, X, nX); park(g->wl_stable, sy.pos, p); return 0; }
+            }
+        }
+        const int words = spg::kPktHdr + nX + 4 * ne;
+        if (words > spg::kPktWords) { fallback = true; return 0; }
+        if (mine < 0) {
+            for (int i = 0; i < nX; i++) if (sv[X[i]].nown == spg_graph::kSOwn) { park(g->wl_done, slots[sv[X[i]].own[0]].pos, p); return 0; }
+            if (g->s_free.empty()) { g->wl_next[p] = cap_wait; cap_wait = p; return 0; }
+        }
+        // ---- launch
+        const int n_new_max = k - 1, n_new_vert_max = 2 * (k - 1);
+        const int64_t new_len = (int64_t)n_new_max * rec, out_len = emulate ? SPG_OUT_LEN(n_new_max, n_new_vert_max) : 0;
+        if (g->used + new_len + out_len > g->cap) { fallback = true; return 0; }
+        // ascending key = the reference's sequential edge order
+        for (int i = 1; i < ne; i++) {
+            const int32_t eid = E[i]; const int64_t key = edges[eid].key;
+            int j = i - 1;
+            for (; j >= 0 && edges[E[j]].key > key; j--) E[j + 1] = E[j];
+            E[j + 1] = eid;
+        }
+        int32_t s = mine;
+        if (s < 0) { s = g->s_free.back(); g->s_free.pop_back(); }
+        spg_graph::SSlot &sl = g->sslots[s];
+        sl.pos = p; sl.root = v; sl.nv = nX; sl.ne = ne; sl.n_new_max = n_new_max; sl.logi = -1; sl.bell = bell_no + 1; sl.launched = 1;
+        sl.tag = (++g->ctx->tag_counter & 0x3fffffff) + 1;
+        sl.out_off = emulate ? g->used : -1;
+        sl.new_off = g->used + out_len;
+        g->used += new_len + out_len;
+        memcpy(sl.verts, X, sizeof(int32_t) * (size_t)nX);
+        memcpy(sl.edges, E, sizeof(int32_t) * (size_t)ne);
+        if (mine < 0) for (int i = 0; i < nX; i++) { spg_graph::SVtx &sx = sv[X[i]]; sx.own[sx.nown++] = s; }
+        sv[v].state = SV_INFLIGHT; sv[v].slot = s;
+        P1(3);
+        if (!emulate) {
+            unsigned long long pkt[spg::kPktWords];
+            auto pack = [](int lo, int hi) { return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)hi << 32); };
+            const spg_options &o = g->opts;
+            pkt[0] = (unsigned long long)(uintptr_t)arena_dev;
+            pkt[1] = port.d_mail;
+            pkt[2] = 0;
+            pkt[3] = (unsigned long long)((int64_t)s * port.mail_stride); pkt[4] = (unsigned long long)sl.new_off; pkt[5] = (unsigned long long)(int64_t)-1;
+            pkt[6] = pack(nX, 1); pkt[7] = pack(ne, n_new_max); pkt[8] = pack(n_new_vert_max, 0);
+            pkt[9] = pack(o.topology, o.flags); pkt[10] = pack(o.lin_point, sl.tag);
+            memcpy(&pkt[11], &o.chord_ratio, 8);
+            pkt[12] = pack(words, 2 * ne);
+            int w = spg::kPktHdr;
+            for (int i = 0; i < nX; i++) pkt[w++] = (unsigned long long)vr[X[i]].pose;
+            int32_t *evp = (int32_t *)(pkt + spg::kPktHdr + nX + 3 * ne);
+            double by = 8.0 * ps * nX + 12.0 + 8.0 * (double)new_len;
+            for (int i = 0; i < ne; i++) {
+                const GEdge &e = edges[E[i]];
+                spg_edge_ref er;
+                er.off = e.off; er.len = e.len; er.kind = e.kind; er.vbegin = 2 * i; er.nv = 2;
+                memcpy(&pkt[w], &er, 24);
+                w += 3;
+                evp[2 * i] = sv[e.vtx[0]].lidx; evp[2 * i + 1] = sv[e.vtx[1]].lidx;
+                by += 8.0 + 8.0 * e.len;
+            }
+            alg_bytes += by;
+            unsigned long long *dst = port.pkt + (size_t)s * spg::kPktWords;
+            memcpy(dst, pkt, (size_t)words * 8);                                                  // through the BAR (write-combined)
+            port.q->item[(port.tail + (unsigned long long)pending_bell) % spg::kQCap] = (unsigned long long)(uintptr_t)dst;
+        }
+        P1(4);
+        pending_bell++;
+        n_inflight++;
+        g->s_fifo.push_back(s);
+        if (g->wl_stable[p] >= 0) wake(g->wl_stable, p);
+        return 1;
+    }
+
+    void ring() {
+        if (!pending_bell) return;
+        P0();
+        if (!emulate) {
+            std::atomic_thread_fence(std::memory_order_release);
+#if defined(__x86_64__)
+            __builtin_ia32_sfence();   // packets and item words have left the write-combining buffers before the doorbell
+#endif
+            port.tail += (unsigned long long)pending_bell;
+            for (int c = 0; c < port.bells; c++) port.q->tail[c * spg::kBellStride] = port.tail;
+#if defined(__x86_64__)
+            __builtin_ia32_sfence();
+#endif
+        }
+        pending_bell = 0;
+        bell_no++;
+        g->stats.n_batches++;
+        P1(5);
+    }
+
+    // updateInputGraph (src/vertex_remover.cpp:500-546) for the blanket in slot s, whose out record is `recd`
+    void commit(const int32_t s, const double *recd, const bool final_seen) {
+        const SvView sv{g->vr.data()};
+        spg_graph::SSlot &sl = g->sslots[s];
+        const int32_t p = sl.pos, v = sl.root;
+        const int status = (int)recd[0], inf = (int)recd[1], n_new = (int)recd[4];
+        sl.logi = (int32_t)g->log.size();
+        g->log.push_back({g->vid[v], sl.bell, status, inf, recd[2], recd[3]});
+        g->stats.max_blanket = std::max(g->stats.max_blanket, sl.nv);
+        const bool fine = (status == SPG_OK || status == SPG_ST_KLD_NOT_PD);
+        if (!fine) g->stats.n_bad_status++;
+        else {
+            for (int i = 0; i < sl.ne; i++) {
+                const int32_t eid = sl.edges[i];
+                GEdge &e = g->edges[eid];
+                e.alive = 0;
+                for (int t = 0; t < 2; t++) {
+                    auto &av = g->vr[e.vtx[t]].adj;
+                    for (size_t j = 0; j < av.size(); j++) if (av[j] == eid) { av[j] = av.back(); av.pop_back(); break; }
+                }
+            }
+            g->n_mutations += sl.ne + 1;
+            g->n_live_e -= sl.ne;
+            g->valive[v] = 0;
+            g->vr[v].adj.clear();
+            g->n_live_v--;
+            g->stats.n_removed++;
+            const int64_t key0 = g->key_base + (int64_t)p * spg_graph::kKeyStride;
+            int vpos = 0;
+            for (int e = 0; e < n_new; e++) {
+                const int kind = (int)recd[SPG_OUT_HDR + 4 * e + 0];
+                const int64_t rel = (int64_t)recd[SPG_OUT_HDR + 4 * e + 1];
+                const int32_t len = (int32_t)recd[SPG_OUT_HDR + 4 * e + 2];
+                const int nv = (int)recd[SPG_OUT_HDR + 4 * e + 3];
+                int32_t vix[2] = {sl.verts[(int)recd[SPG_OUT_HDR + 4 * sl.n_new_max + vpos]], sl.verts[(int)recd[SPG_OUT_HDR + 4 * sl.n_new_max + vpos + 1]]};
+                vpos += nv;
+                add_edge_idx(g, kind, 2, vix, sl.new_off + rel, len, key0 + e);
+            }
+            g->stats.n_new_edges += n_new;
+        }
+        for (int i = 0; i < sl.nv; i++) {
+            spg_graph::SVtx &sx = sv[sl.verts[i]];
+            for (int j = 0; j < sx.nown; j++) if (sx.own[j] == s) { sx.own[j] = sx.own[--sx.nown]; break; }
+        }
+        sv[v].state = SV_DONE;
+        n_done++;
+        n_inflight--;
+        if (final_seen) harvest(s, recd);
+        else g->s_fin.push_back(s);
+        if (g->wl_done[p] >= 0) wake(g->wl_done, p);
+    }
+    // the KLD tail of a committed blanket has landed (final word): late results, then the slot is free again
+    void harvest(const int32_t s, const double *recd) {
+        spg_graph::SSlot &sl = g->sslots[s];
+        BlanketLog &lg = g->log[sl.logi];
+        lg.kld = recd[2]; lg.min_gap = recd[3]; lg.status = (int32_t)recd[0];
+        if (std::isfinite(recd[2])) g->stats.kld_sum += recd[2];
+        g->s_free.push_back(s);
+        for (int32_t q = cap_wait; q >= 0;) { const int32_t nx = g->wl_next[q]; g->s_woken.push_back(q); q = nx; }
+        cap_wait = -1;
+    }
+
+    inline const double *cell(int32_t s) const { return port.h_mail + (size_t)s * (size_t)port.mail_stride; }
+
+    // blankets whose ready (or final) word has arrived, among the oldest `window` in flight. Tickets are served in
+    // order and blankets take about the same time, so results arrive nearly in launch order: the scan stops after
+    // `giveup` unfinished entries in a row (every 16th call looks at the whole window).
+    void poll_hip(int window, int giveup) {
+        std::vector<int32_t> &fifo = g->s_fifo, &ready = g->s_ready;
+        while (fifo_head < fifo.size() && fifo[fifo_head] < 0) fifo_head++;
+        int seen = 0, misses = 0;
+        for (size_t i = fifo_head; i < fifo.size() && seen < window && misses < giveup; i++) {
+            const int32_t s = fifo[i];
+            if (s < 0) continue;
+            seen++;
+            const volatile double *c = cell(s);
+            const double w = c[5], tagd = (double)g->sslots[s].tag;
+            if (w == 4503599627370496.0 + tagd || w == 4503599627370496.0 + 4294967296.0 + tagd) {
+                for (int l = 8; l < 40; l += 8) __builtin_prefetch((const void *)(c + l));
+                ready.push_back(s);
+                fifo[i] = -1;
+                misses = 0;
+            } else misses++;
+        }
+        if (fifo_head > 4096 && fifo_head * 2 > fifo.size()) { fifo.erase(fifo.begin(), fifo.begin() + (long)fifo_head); fifo_head = 0; }
+    }
+
+    // Emulated device (injected backend; tests): "complete" a subset of the in-flight blankets, chosen and ordered by the
+    // seed, by running them as one round of the backend; their out records land in the arena.
+    int poll_emulated() {
+        std::vector<int32_t> &fifo = g->s_fifo, &ready = g->s_ready;
+        std::vector<int32_t> live;
+        for (size_t i = fifo_head; i < fifo.size(); i++) if (fifo[i] >= 0) live.push_back((int32_t)i);
+        if (live.empty()) { fifo.clear(); fifo_head = 0; return 0; }
+        auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+        size_t take = live.size();
+        if (g->stream_emulation > 0) {
+            take = 1 + (size_t)(next() % live.size());
+            for (size_t i = 0; i + 1 < live.size(); i++) std::swap(live[i], live[i + (size_t)(next() % (live.size() - i))]);
+        }
+        live.resize(take);
+        std::vector<spg_blanket_desc> blk(take);
+        std::vector<int64_t> vpo;
+        std::vector<spg_edge_ref> er;
+        std::vector<int32_t> ev;
+        for (size_t t = 0; t < take; t++) {
+            const spg_graph::SSlot &sl = g->sslots[fifo[live[t]]];
+            spg_blanket_desc &bd = blk[t];
+            memset(&bd, 0, sizeof bd);
+            bd.vert_begin = (int32_t)vpo.size(); bd.n_vert = sl.nv; bd.n_remove = 1;
+            bd.edge_begin = (int32_t)er.size(); bd.n_edge = sl.ne;
+            bd.n_new_max = sl.n_new_max; bd.n_new_vert_max = 2 * sl.n_new_max;
+            bd.new_off = sl.new_off; bd.new_len = (int64_t)sl.n_new_max * rec; bd.out_off = sl.out_off; bd.tinfo_off = -1;
+            for (int i = 0; i < sl.nv; i++) { vpo.push_back(g->vpose[sl.verts[i]]); g->lidx[sl.verts[i]] = i; }
+            for (int i = 0; i < sl.ne; i++) {
+                const GEdge &e = g->edges[sl.edges[i]];
+                spg_edge_ref r; r.off = e.off; r.len = e.len; r.kind = e.kind; r.vbegin = (int32_t)ev.size(); r.nv = 2;
+                ev.push_back(g->lidx[e.vtx[0]]); ev.push_back(g->lidx[e.vtx[1]]);
+                er.push_back(r);
+            }
+        }
+        spg_round_desc rd{};
+        rd.opts = &g->opts; rd.n_blankets = (int32_t)take; rd.first = 0; rd.count = (int32_t)take;
+        rd.blankets = blk.data(); rd.vert_pose_off = vpo.data(); rd.edges = er.data(); rd.edge_vert = ev.data();
+        rd.n_vert_total = (int64_t)vpo.size(); rd.n_edge_total = (int64_t)er.size(); rd.n_edge_vert_total = (int64_t)ev.size();
+        rd.mail_base = 0; rd.mail_len = 0; rd.slot = 0; rd.tag = ++g->ctx->tag_counter;
+        if (int r = g->ctx->be.run_round(g->ctx->be.user, g->dev, &rd)) return r;
+        if (int r = g->ctx->be.synchronize(g->ctx->be.user)) return r;
+        for (size_t t = 0; t < take; t++) {
+            const int32_t s = fifo[live[t]];
+            const spg_graph::SSlot &sl = g->sslots[s];
+            const int64_t olen = SPG_OUT_LEN(sl.n_new_max, 2 * sl.n_new_max);
+            if (int r = g->ctx->be.download(g->ctx->be.user, g->host.data() + sl.out_off, (char *)g->dev + sl.out_off * 8, olen)) return r;
+            ready.push_back(s);
+            fifo[live[t]] = -1;
+        }
+        while (fifo_head < fifo.size() && fifo[fifo_head] < 0) fifo_head++;
+        return 0;
+    }
+
+    int run() {
+        const uint64_t t_begin = ticks_now();
+        const double s_begin = now_s();
+        uint64_t last_progress = t_begin, idle_since = 0;
+        unsigned n_polls = 0;
+        std::vector<int32_t> &woken = g->s_woken, &ready = g->s_ready, &fin = g->s_fin;
+        size_t fin_head = 0;
+        for (;;) {
+            // ---- results
+            ready.clear();
+            P0();
+            if (emulate) { if ((rc = poll_emulated()) != 0) return rc; }
+            else if (n_inflight) poll_hip(n_inflight <= 256 ? n_inflight : 256, (++n_polls & 15) ? 10 : 256);
+            P1(0);
+            const bool got = !ready.empty();
+            if (got && idle_since) { t_idle += ticks_now() - idle_since; idle_since = 0; }
+            for (size_t ri = 0; ri < ready.size(); ri++) {
+                const int32_t s = ready[ri];
+                const double *recd = emulate ? g->host.data() + g->sslots[s].out_off : cell(s);
+                const bool fin_now = emulate || recd[5] == 4503599627370496.0 + 4294967296.0 + (double)g->sslots[s].tag;
+                P0();
+                commit(s, recd, fin_now);
+                P1(1);
+                if (!fallback) {
+                    // (woken entries are examined oldest first: a launch may be what the next one waits for)
+                    for (size_t wi = 0; wi < woken.size(); wi++) examine(woken[wi]);
+                    if (pending_bell >= 6) ring();
+                }
+                woken.clear();
+            }
+            // ---- late results (final words) of committed blankets, in bulk: each is a line the device has rewritten since the
+            // commit read it (a miss), nothing waits for them, and taken 64 at a time the misses overlap
+            if (!emulate && (fin.size() - fin_head >= 192 || g->s_free.size() < 256)) {
+                P0();
+                const size_t n = std::min<size_t>(64, fin.size() - fin_head);
+                for (size_t i = 0; i < n; i++) __builtin_prefetch((const void *)cell(fin[fin_head + i]));
+                for (size_t i = 0; i < n; i++) {
+                    const int32_t s = fin[fin_head];
+                    const volatile double *c = cell(s);
+                    if (c[5] != 4503599627370496.0 + 4294967296.0 + (double)g->sslots[s].tag) break;
+                    harvest(s, (const double *)c);
+                    fin_head++;
+                }
+                if (fin_head > 8192) { fin.erase(fin.begin(), fin.begin() + (long)fin_head); fin_head = 0; }
+                P1(6);
+                if (!woken.empty()) {
+                    if (!fallback) for (size_t wi = 0; wi < woken.size(); wi++) examine(woken[wi]);
+                    woken.clear();
+                }
+            }
+            // ---- list entries nobody has looked at yet: a few per turn, more when the device leaves the host idle
+            if (!fallback && cursor < P) {
+                int budget = got ? 4 : 32;
+                while (cursor < P && budget-- > 0 && !fallback) {
+                    examine(cursor++);
+                    if (!woken.empty()) { for (size_t wi = 0; wi < woken.size() && !fallback; wi++) examine(woken[wi]); woken.clear(); }
+                }
+            }
+            ring();
+            if (n_done == P) break;
+            if (fallback && n_inflight == 0) break;
+            if (got || cursor < P) { last_progress = ticks_now(); continue; }
+            // ---- nothing arrived and nothing to examine: the host waits for the device
+            {
+                const uint64_t t1 = ticks_now();
+                if (!idle_since) idle_since = t1;
+                if (n_inflight == 0 && fin_head == fin.size()) {
+                    // nothing in flight, list not exhausted, nothing woken: every remaining entry is parked on an entry that never
+                    // ran — cannot happen (the earliest WAITING entry only waits for blankets in flight); leave through the batch driver
+                    fallback = true;
+                    break;
+                }
+                if (((t1 - last_progress) >> 35) != 0) {   // ~ 10 s without a result
+                    set_err(g->ctx, SPG_EHIP, "streaming driver: no blanket completed within 10 s");
+                    return SPG_EHIP;
+                }
+            }
+        }
+        // ---- drain: every committed blanket's final word (its slot, packet and mailbox cell are reused by the next call)
+        if (!emulate) {
+            const double t0 = now_s();
+            for (; fin_head < fin.size(); fin_head++) {
+                const int32_t s = fin[fin_head];
+                const volatile double *c = cell(s);
+                uint32_t spins = 0;
+                while (c[5] != 4503599627370496.0 + 4294967296.0 + (double)g->sslots[s].tag) {
+                    if ((++spins & 0xfff) == 0 && now_s() - t0 > 10.0) { set_err(g->ctx, SPG_EHIP, "streaming driver: a blanket's KLD tail did not complete within 10 s"); return SPG_EHIP; }
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+                harvest(s, (const double *)c);
+            }
+            woken.clear();
+        }
+        fin.clear();
+        if (idle_since) { t_idle += ticks_now() - idle_since; idle_since = 0; }
+        const uint64_t t_end = ticks_now();
+        const double secs = now_s() - s_begin;
+        const double idle = (t_end > t_begin) ? secs * (double)t_idle / (double)(t_end - t_begin) : 0.0;
+        g->stats.device_seconds += idle;
+        g->stats.host_seconds += secs - idle;
+        g->stats.schedule_seconds += secs - idle;   // (selection, commit and hand-over are one loop here; SPG_STREAM_PROF splits them)
+        if (prof) {
+            const char *nm[8] = {"poll", "commit", "examine: parked", "examine: launch decision", "packet", "doorbell", "late results", "launch tail"};
+            const double tps = (double)(t_end - t_begin) / secs;
+            for (int i = 0; i < 8; i++) fprintf(stderr, "stream prof %-26s %8llu x %8.1f ns = %8.3f ms\n", nm[i], (unsigned long long)pn[i], pn[i] ? 1e9 * (double)pt[i] / tps / (double)pn[i] : 0.0, 1e3 * (double)pt[i] / tps);
+        }
+        return 0;
+    }
+};
+}  // namespace
+
+// Runs the removal list of the open marginalisation (spg_graph_marginalize_begin) through the streaming driver.
+// Returns 0 = list exhausted, 1 = the rest of the list (g->pending from g->pend_head) is left to the batch driver
+// (a blanket the persistent worker does not take, arena full, or no streaming on this backend), < 0 error.
+static int stream_marginalize(spg_graph *g) {
+    const spg_options &o = g->opts;
+    static const bool env_off = [] { const char *e = getenv("SPG_STREAM"); return e && e[0] == '0'; }();
+    spg::StreamPort *const sim = g->ctx->is_hip ? nullptr : g->ctx->sim_port;
+    const bool emulate = !g->ctx->is_hip && !sim;
+    if (env_off || g->stream_disabled) return 1;
+    if (emulate && g->stream_emulation < 0) return 1;
+    if (g->nranks != 1 || o.algorithm != SPG_ALG_NFR || o.topology != SPG_TOPO_TREE || o.lin_point != SPG_LIN_GLOBAL || o.flags != 0) return 1;
+    const int32_t P = (int32_t)g->pending.size();
+    if (P < (emulate ? 1 : 64)) return 1;   // a handful of removals (online decimation): one plain launch is cheaper than starting the worker
+    Streamer S(g, emulate);
+    if (sim) {
+        if (sim->slots < kStreamSlots || sim->mail_stride < kStreamMailStride) return 1;
+        S.port = *sim;
+    } else if (!emulate) {
+        int prc = spg::hip_stream_open(&g->ctx->be, g->d, kStreamSlots, kStreamMailStride, &S.port);
+        if (prc < 0) { snprintf(g->ctx->err, sizeof g->ctx->err, "%s", spg::hip_backend_error(&g->ctx->be)); return prc; }
+        if (prc > 0) return 1;
+    }
+    // state
+    const size_t V = g->vid.size();
+    (void)V;
+    for (int32_t p = 0; p < P; p++) { spg_graph::SVtx &x = g->vr[g->pending[p]].s; x.pos = p; x.state = SV_WAITING; x.nown = 0; }
+    if (g->sstamp > 0x7f000000) { for (auto &r : g->vr) r.s.stamp = 0; g->sstamp = 0; }
+    g->wl_next.assign((size_t)P, -1); g->wl_stable.assign((size_t)P, -1); g->wl_done.assign((size_t)P, -1);
+    if (g->sslots.size() < (size_t)kStreamSlots) g->sslots.resize(kStreamSlots);
+    g->s_free.clear();
+    for (int s = kStreamSlots - 1; s >= 0; s--) g->s_free.push_back(s);
+    g->s_fifo.clear(); g->s_fin.clear(); g->s_woken.clear(); g->s_ready.clear();
+    next_stamp(g);
+    if (g->lidx.size() < V) g->lidx.resize(V, -1);
+    if ((int64_t)g->host.size() < g->cap) g->host.resize((size_t)g->cap);
+    S.rng = 0x9E3779B97F4A7C15ULL ^ ((uint64_t)(g->stream_emulation > 0 ? g->stream_emulation : 1) * 0xD1B54A32D192ED03ULL);
+    const int64_t used0 = g->used;
+    const int rc = S.run();
+    if (sim) sim->tail = S.port.tail;
+    else if (!emulate) spg::hip_stream_close(&g->ctx->be, &S.port, S.alg_bytes, (long long)S.n_done);
+    // what the stream produced in the arena is device-only until someone asks for it
+    if (g->used > used0) {
+        g->dev_synced = g->used;
+        if (!emulate && !sim) {
+            if (g->stale_hi <= g->stale_lo) { g->stale_lo = used0; g->stale_hi = g->used; }
+            else { g->stale_lo = std::min(g->stale_lo, used0); g->stale_hi = std::max(g->stale_hi, g->used); }
+        } else {
+            // injected backend: the mirror is filled from the backend's arena right away (tests read edges next)
+            if (int r = g->ctx->be.download(g->ctx->be.user, g->host.data() + used0, (char *)g->dev + used0 * 8, g->used - used0)) return r;
+        }
+    }
+    g->stats.n_rounds = S.bell_no;
+    g->round_no = S.bell_no;
+    // list entries the stream did not finish, in list order, for the batch driver
+    size_t left = 0;
+    for (int32_t p = 0; p < P; p++) {
+        const int32_t v = g->pending[p];
+        spg_graph::SVtx &sq = g->vr[v].s;
+        if (sq.state == SV_STABLE) {   // a reservation that was never launched (the stream handed over to the batch driver)
+            const spg_graph::SSlot &sl = g->sslots[sq.slot];
+            for (int i = 0; i < sl.nv; i++) {
+                spg_graph::SVtx &sx = g->vr[sl.verts[i]].s;
+                for (int j = 0; j < sx.nown; j++) if (sx.own[j] == sq.slot) { sx.own[j] = sx.own[--sx.nown]; break; }
+            }
+        }
+        const bool done = sq.state == SV_DONE;
+        sq.pos = -1; sq.nown = 0; sq.state = SV_WAITING;
+        if (!done) g->pending[left++] = v;
+    }
+    g->pending.resize(left);
+    g->pend_head = 0;
+    if (getenv("SPG_TRACE"))
+        fprintf(stderr, "spg trace: streaming driver: %d list entries, %d committed in %d doorbells, %zu left to the batch driver (examined up to entry %d)\n",
+                P, S.n_done, S.bell_no, left, S.cursor);
+    if (getenv("SPG_TRACE"))
+        fprintf(stderr, "spg trace: streaming driver: %ld examinations; parked on: earlier neighbour %ld, own blanket %ld, two shared vertices %ld, waiting member of a touching blanket %ld, waiting 2-hop neighbour %ld\n",
+                S.n_exam, S.n_park[0], S.n_park[1], S.n_park[2], S.n_park[3], S.n_park[4]);
+    if (rc) return rc;
+    return left ? 1 : 0;
+}
+
 extern "C" int spg_graph_marginalize(spg_graph *g, const int32_t *which, int n, const spg_options *opts, spg_marg_stats *stats) {
     return spg_graph_marginalize_ranks(g, which, n, opts, 0, 1, nullptr, nullptr, stats);
 }
@@ -1794,6 +2449,15 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
     if (rc) return rc;
     const char *env = getenv("SPG_NO_PIPELINE");
     g->pipelined = g->ctx->be.synchronize_slot && g->ctx->be.mailbox_slot && !(env && env[0] == '1');
+    // single rank, NFR Tree at the stored estimates: blanket by blanket through the persistent worker (streaming driver);
+    // whatever it leaves (rc 1: blankets the worker does not take) goes through the batch driver below
+    int stream_rc = 1;
+    if (nranks == 1 && !exchange) stream_rc = stream_marginalize(g);
+    if (stream_rc <= 0) {
+        int rc2 = spg_graph_marginalize_end(g, stats);
+        if (stats && g->ctx->is_hip) stats->n_launches -= launches0;
+        return stream_rc < 0 ? stream_rc : rc2;
+    }
     auto do_exchange = [&](Batch &b) -> int {
         if (!b.rinfo.exchange) return 0;
         double tx = now_s();
@@ -1927,6 +2591,21 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
     int rc2 = spg_graph_marginalize_end(g, stats);
     if (stats && g->ctx->is_hip) stats->n_launches -= launches0;
     return rc < 0 ? rc : rc2;
+}
+
+// tools/host_sim.cpp (declared in csrc/spg_internal.h, not part of the public ABI): the streaming driver of a context
+// with an injected backend talks to this port — host memory, with a thread of the tool playing the persistent worker.
+extern "C" int spg_debug_set_stream_port(spg_ctx *c, void *port) {
+    if (!c || c->is_hip) return SPG_EINVAL;
+    c->sim_port = (spg::StreamPort *)port;
+    return 0;
+}
+
+extern "C" int spg_graph_set_stream_emulation(spg_graph *g, int seed) {
+    if (!g) return SPG_EINVAL;
+    g->stream_disabled = seed <= -2;
+    g->stream_emulation = seed < 0 ? -1 : seed;
+    return 0;
 }
 
 extern "C" int spg_graph_last_blanket_count(const spg_graph *g) { return g ? (int)g->log.size() : 0; }

@@ -19,6 +19,39 @@ void hip_backend_profile_read_worker(spg_backend *b, double *ms, double *bytes, 
 void hip_backend_profile_read_big(spg_backend *b, double *ms, double *flops, long long *count, int *nmax);
 int hip_backend_end_of_call(spg_backend *b);   // the persistent worker retires (end of a marginalisation)
 
+// ---- queue of the persistent worker kernel (blanket_worker, spg_kernels.hip): fine-grained device memory the host
+// fills through the PCIe BAR. Shared by the batch hand-over of hip_run_round and by the streaming driver of spg_host.cpp.
+constexpr int kQCap = 16384;          // queue slots (more items than this are never in flight)
+constexpr int kPktHdr = 13;
+constexpr int kPktWords = 192;        // largest packet a worker stages (1.5 KB of LDS); larger blankets are launched
+constexpr int kPktStride = 64;        // the first pass reads 64 words blindly (packets are kPktWords apart)
+constexpr int kWorkerMaxN = 36;       // largest target dimension n = d*k a worker takes (LDS of the worker is sized for it)
+constexpr int kBells = 16, kBellStride = 512;   // doorbell copies, 4 KB apart (idle workgroups poll: spread them over channels)
+struct WorkQ {
+    unsigned long long stop;          // 1: leave when no published item is left (host)
+    unsigned long long pad[7];
+    unsigned long long tail[kBells * kBellStride];   // items published (host writes every copy in use)
+    unsigned long long item[kQCap];   // device address of the packet of item i (mod kQCap)
+};
+
+// What the streaming driver (spg_host.cpp: one blanket = one queue item, committed as its ready word arrives) needs from
+// a backend with a persistent worker: the packet ring and the queue (both written through the BAR) and a pinned host
+// mailbox with one out-record cell per in-flight blanket.
+struct StreamPort {
+    unsigned long long *pkt = nullptr;        // `slots` packets of kPktWords words (device memory, host-writable)
+    WorkQ *q = nullptr;                       // the worker's queue (device memory, host-writable)
+    unsigned long long tail = 0;              // host copy of q->tail (items published so far)
+    int bells = 1;
+    const double *h_mail = nullptr;           // pinned host mailbox: cell s = h_mail + s * mail_stride
+    unsigned long long d_mail = 0;            // the same buffer in the device's address space
+    int mail_stride = 0, slots = 0;
+};
+// Starts (or keeps) the persistent worker for pose dimension D and sizes the stream's packet ring / mailbox.
+// 0 = ready, 1 = no streaming on this backend (no large BAR, worker disabled): take the batch driver, < 0 error.
+int hip_stream_open(spg_backend *b, int D, int slots, int mail_stride, StreamPort *out);
+// the blankets the stream handed to the worker (profile accounting of the worker run) and the host's tail copy
+void hip_stream_close(spg_backend *b, const StreamPort *port, double alg_bytes, long long blankets);
+
 // Dense global KLD (spg_dense.hip). Host-staged description of one graph for the dense assembly.
 struct DenseGraphIn {
     int D = 0, nv = 0, ne = 0;
@@ -80,3 +113,6 @@ int rccl_allgather_f64(void *handle, void *arena, int64_t region_off, int64_t ch
 void rccl_comm_destroy(void *handle);
 
 }  // namespace spg
+
+// tools/host_sim.cpp only (host-side timing of the streaming driver against a simulated device); not in include/spg.h
+extern "C" int spg_debug_set_stream_port(spg_ctx *ctx, void *stream_port);

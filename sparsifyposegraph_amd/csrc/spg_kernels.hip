@@ -1443,18 +1443,8 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
 //   [9] topology | flags << 32    [10] lin_point | tag << 32     [11] chord_ratio (f64 bits)
 //   [12] n_words | 0              then vpo[n_vert] (i64), er[n_edge] (spg_edge_ref, 3 words each, vbegin relative to the
 //   packet's ev), ev (i32 pairs)
-constexpr int kQCap = 16384;          // queue slots (items in flight are bounded by the host's four launch slots)
-constexpr int kPktHdr = 13;
-constexpr int kPktWords = 192;        // largest packet a worker stages (1.5 KB of LDS); larger blankets are launched
-constexpr int kPktStride = 64;        // the first pass reads 64 words blindly (packets are kPktWords apart)
-constexpr int kWorkerMaxN = 36;       // largest target dimension n = d*k a worker takes (LDS of the worker is sized for it)
-constexpr int kBells = 16, kBellStride = 512;   // doorbell copies, 4 KB apart (idle workgroups poll: spread them over channels)
-struct WorkQ {
-    unsigned long long stop;          // 1: leave when no published item is left (host)
-    unsigned long long pad[7];
-    unsigned long long tail[kBells * kBellStride];   // items published (host writes every copy in use)
-    unsigned long long item[kQCap];   // device address of the packet of item i (mod kQCap)
-};
+using spg::kQCap; using spg::kPktHdr; using spg::kPktWords; using spg::kPktStride; using spg::kWorkerMaxN; using spg::kBells; using spg::kBellStride;
+using spg::WorkQ;
 
 __device__ __forceinline__ unsigned long long load_sys(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1550,7 +1540,8 @@ __global__ void __launch_bounds__(128) blanket_worker(WorkQ *q, unsigned long lo
 // =================================================================================== HIP backend
 namespace spg {
 
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(err, sizeof err, "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return SPG_EHIP; } } while (0)
+// (`err` is HipBackend::err, 512 bytes, as the member array or through a char * alias)
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(err, (size_t)512, "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return SPG_EHIP; } } while (0)
 
 struct HipBackend {
     int device = 0;
@@ -1609,6 +1600,9 @@ struct HipBackend {
         std::chrono::steady_clock::time_point last_push;
     } worker;
     int batches_in_call = 0;                          // batches since the last full synchronisation
+    // streaming driver (hip_stream_open): its own packet ring (fine-grained device memory) and pinned mailbox
+    void *st_pkt = nullptr, *st_hmail = nullptr, *st_dmail = nullptr;
+    size_t c_st_pkt = 0, c_st_mail = 0;
     int worker_cooldown = 0;                          // batches to go before the worker is considered again
     double prof_big_ms = 0, prof_big_flops = 0;       // large-blanket dense pipeline (always accumulated)
     long long prof_big_count = 0;
@@ -2318,6 +2312,8 @@ void hip_backend_destroy(spg_backend *b) {
     if (hb->worker.ev_a) (void)hipEventDestroy(hb->worker.ev_a);
     if (hb->worker.ev_b) (void)hipEventDestroy(hb->worker.ev_b);
     if (hb->worker.stream) (void)hipStreamDestroy(hb->worker.stream);
+    if (hb->st_pkt) (void)hipFree(hb->st_pkt);
+    if (hb->st_hmail) (void)hipHostFree(hb->st_hmail);
     for (auto &S : hb->slots) {
         if (S.d_pkt) (void)hipFree(S.d_pkt);
         (void)hipStreamSynchronize(S.stream);
@@ -2359,6 +2355,58 @@ void hip_backend_profile_read_big(spg_backend *b, double *ms, double *flops, lon
     if (!hb) return;
     *ms = hb->prof_big_ms; *flops = hb->prof_big_flops; *count = hb->prof_big_count; *nmax = hb->prof_big_nmax;
 }
+int hip_stream_open(spg_backend *b, int D, int slots, int mail_stride, StreamPort *out) {
+    HipBackend *hb = (HipBackend *)b->user;
+    if (!hb || !out || slots < 1 || slots > kQCap / 2 || (D != 3 && D != 6)) return SPG_EINVAL;
+    char *err = hb->err;
+    static const bool worker_env = [] { const char *e = getenv("SPG_WORKER"); return !(e && e[0] == '0'); }();
+    if (!worker_env || !hb->large_bar || hb->worker.disabled || hb->force_one_wave) return 1;
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != hb->device) HIPCHK(hipSetDevice(hb->device));
+    }
+    // nothing of an earlier batch may still be running on the launch slots (their kernels would queue behind the worker)
+    for (auto &S : hb->slots) if (S.busy || S.wait_ev || !S.finals.empty()) { if (int rcw = hb->wait_slot(S)) return rcw; drain_profile(hb, S); }
+    const size_t need_pkt = (size_t)slots * kPktWords * 8, need_mail = (size_t)slots * (size_t)mail_stride * 8;
+    if (need_pkt > hb->c_st_pkt || need_mail > hb->c_st_mail) {
+        if (int rc2 = hb->worker_stop()) return rc2;   // hipFree waits for the device: nothing may be spinning on it
+        if (need_pkt > hb->c_st_pkt) {
+            if (hb->st_pkt) { HIPCHK(hipFree(hb->st_pkt)); hb->st_pkt = nullptr; hb->c_st_pkt = 0; }
+            if (hipExtMallocWithFlags(&hb->st_pkt, need_pkt, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); hb->st_pkt = nullptr; return 1; }
+            hb->c_st_pkt = need_pkt;
+        }
+        if (need_mail > hb->c_st_mail) {
+            if (hb->st_hmail) { HIPCHK(hipHostFree(hb->st_hmail)); hb->st_hmail = nullptr; hb->c_st_mail = 0; }
+            HIPCHK(hipHostMalloc(&hb->st_hmail, need_mail, hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer(&hb->st_dmail, hb->st_hmail, 0));
+            memset(hb->st_hmail, 0, need_mail);   // a fresh mailbox never looks ready
+            hb->c_st_mail = need_mail;
+        }
+    }
+    int wrc = hb->worker_start(D, SPG_ALG_NFR);
+    if (wrc) return wrc;
+    if (hb->worker.disabled) return 1;
+    hb->batches_in_call += 3;   // (batches that follow in this call may go to the running worker right away)
+    out->pkt = (unsigned long long *)hb->st_pkt;
+    out->q = hb->worker.q;
+    out->tail = hb->worker.tail;
+    out->bells = hb->worker.bells;
+    out->h_mail = (const double *)hb->st_hmail;
+    out->d_mail = (unsigned long long)(uintptr_t)hb->st_dmail;
+    out->mail_stride = mail_stride;
+    out->slots = slots;
+    return 0;
+}
+
+void hip_stream_close(spg_backend *b, const StreamPort *port, double alg_bytes, long long blankets) {
+    HipBackend *hb = (HipBackend *)b->user;
+    if (!hb || !port) return;
+    hb->worker.tail = port->tail;
+    hb->worker.bytes += alg_bytes;
+    hb->worker.blankets += blankets;
+    hb->worker.last_push = std::chrono::steady_clock::now();
+}
+
 int hip_backend_end_of_call(spg_backend *b) {
     HipBackend *hb = (HipBackend *)b->user;
     if (!hb) return 0;

@@ -255,6 +255,11 @@ class GraphWrapperHIP:
     def set_shard_threshold(self, min_blankets):
         check(self.L.spg_graph_set_shard_threshold(self.h, int(min_blankets)), self.ctx.h, "set_shard_threshold")
 
+    def set_stream_emulation(self, seed):
+        """-1: default drivers; >= 0: streaming driver on an injected backend, completion order from the seed (tests);
+        -2: never use the streaming driver (A/B against the batch driver)."""
+        check(self.L.spg_graph_set_stream_emulation(self.h, int(seed)), self.ctx.h, "set_stream_emulation")
+
     def round_prepare(self):
         info = abi.RoundInfo()
         rc = check(self.L.spg_graph_round_prepare(self.h, C.byref(info)), self.ctx.h, "round_prepare")

@@ -74,6 +74,7 @@ SYMBOLS = {
     "spg_graph_chi2": (C.c_int, [C.c_void_p, _f64p]),
     "spg_graph_marginalize_begin": (C.c_int, [C.c_void_p, _i32p, C.c_int, C.POINTER(abi.Options), C.c_int, C.c_int]),
     "spg_graph_set_shard_threshold": (C.c_int, [C.c_void_p, C.c_int]),
+    "spg_graph_set_stream_emulation": (C.c_int, [C.c_void_p, C.c_int]),
     "spg_graph_round_prepare": (C.c_int, [C.c_void_p, C.POINTER(abi.RoundInfo)]),
     "spg_graph_round_compute": (C.c_int, [C.c_void_p]),
     "spg_graph_round_commit": (C.c_int, [C.c_void_p]),
