@@ -198,30 +198,39 @@ struct spg_graph {
     int d = 0, ps = 0, rec = 0;
     std::vector<int32_t> vid;
     std::unordered_map<int32_t, int32_t> vidx;
+    // direct id -> index table next to the hash map, kept while the ids are small non-negative integers (g2o files number
+    // their vertices 0, 1, 2, ...): the 50 000 lookups of a removal list cost 2 ms of a 19 ms marginalisation through the map
+    std::vector<int32_t> vdirect;
+    bool vdirect_ok = true;
+    int32_t index_of(int32_t id) const {
+        if (vdirect_ok) return (id >= 0 && (size_t)id < vdirect.size()) ? vdirect[(size_t)id] : -1;
+        auto it = vidx.find(id);
+        return it == vidx.end() ? -1 : it->second;
+    }
     std::vector<uint8_t> valive;
     std::vector<int64_t> vpose;
     // Per vertex, two cache lines. Line 0: adjacency — live edge ids, each with the far endpoint of a pose-pose edge
     // (-1 for an n-ary edge), so that walking a neighbourhood reads no edge records. Line 1: the streaming driver's
     // state of the vertex and what a hand-over needs of it (copies of vid[] / vpose[]).
     struct AdjEnt { int32_t eid, other; operator int32_t() const { return eid; } };
-    struct SVtx {                                     // 32 bytes
-        int32_t pos;                                  // position in the removal list of the running call, -1 = not in it
-        uint8_t state, nown, lidx, pad_;              // SV_* ; registered blankets that contain the vertex: own[0 .. nown); index in the blanket being examined
+    struct SVtx {                                     // 24 bytes
+        int32_t nown;                                 // registered blankets (in flight or reserved) that contain the vertex: own[0 .. nown)
         int32_t own[4];
         int32_t slot;                                 // SV_STABLE / SV_INFLIGHT: the slot that holds the vertex's blanket
-        int32_t stamp;                                // == spg_graph::sstamp: the vertex is in the blanket being examined
     };
     struct alignas(64) VRec {
         InlVec<AdjEnt, 7> adj;
         SVtx s;
         int32_t id, pad_;
         int64_t pose;
-        char spare_[16];
-        VRec() { s.pos = -1; s.state = 0; s.nown = 0; s.lidx = 0; s.pad_ = 0; s.slot = -1; s.stamp = 0; id = 0; pad_ = 0; pose = 0; }
+        char spare_[24];
+        VRec() { s.nown = 0; s.slot = -1; id = 0; pad_ = 0; pose = 0; }
     };
     std::vector<VRec> vr;
     std::vector<InlVec<struct OwnRefT, 3>> vown;      // batch scheduler: owners whose vertex set holds the vertex
-    int32_t sstamp = 0;
+    // list position and state of every vertex in one small array (4 bytes per vertex: it stays in L2 while the per-vertex
+    // records stream through): -1 = not in the removal list of the running call, else (position << 2) | SV_*
+    std::vector<int32_t> cst;
     std::vector<GEdge> edges;
     std::vector<int32_t> everts;
     int n_live_v = 0, n_live_e = 0;
@@ -293,7 +302,9 @@ struct spg_graph {
     static constexpr int kSOwn = 4, kSMaxV = 16, kSMaxE = 44;
     struct SSlot {                                    // one blanket in flight
         int32_t pos, root, nv, ne, n_new_max, tag, logi, bell;
-        int32_t launched, pad_;                       // 0: a reservation (the blanket of a waiting entry), 1: in flight
+        int32_t launched;                             // 0: a reservation (the blanket of a waiting entry), 1: in flight
+        int32_t npend, pend[3];                       // the blanket's other vertices that are list entries (-1: more than 3, look at all)
+        int32_t mcell;                                // its mailbox cell: cells are handed out in launch order, so the host polls and reads sequential memory
         int64_t new_off, out_off;                     // out_off: emulated port only (out record in the arena), else -1
         int32_t verts[kSMaxV];                        // removed vertex first, kept ones in ascending id
         int32_t edges[kSMaxE];                        // ascending key
@@ -522,6 +533,10 @@ extern "C" int spg_graph_add_vertex(spg_graph *g, int id, const double *pose) {
     int32_t idx = (int32_t)g->vid.size();
     g->vid.push_back(id);
     g->vidx[id] = idx;
+    if (g->vdirect_ok) {
+        if (id < 0 || (size_t)id > 8 * g->vid.size() + 4096) { g->vdirect_ok = false; g->vdirect.clear(); g->vdirect.shrink_to_fit(); }
+        else { if ((size_t)id >= g->vdirect.size()) g->vdirect.resize(std::max<size_t>((size_t)id + 1, g->vdirect.size() * 2), -1); g->vdirect[(size_t)id] = idx; }
+    }
     g->valive.push_back(1);
     g->vr.emplace_back();
     g->vown.emplace_back();
@@ -1244,19 +1259,21 @@ extern "C" int spg_graph_marginalize_begin(spg_graph *g, const int32_t *which, i
     g->in_set.assign(g->vid.size(), 0);
     g->lpos.assign(g->vid.size(), -1);
     for (int i = 0; i < n; i++) {
-        auto it = g->vidx.find(which[i]);
-        if (it == g->vidx.end() || !g->valive[it->second])
+        const int32_t vi = g->index_of(which[i]);
+        if (vi < 0 || !g->valive[vi])
             return set_err(g->ctx, SPG_EINVAL, "vertex needs to exist in order to be marginalized");
-        if (g->in_set[it->second]) continue;
-        g->in_set[it->second] = 1;
-        g->lpos[it->second] = (int32_t)g->pending.size();
-        g->pending.push_back(it->second);
+        if (g->in_set[vi]) continue;
+        g->in_set[vi] = 1;
+        g->lpos[vi] = (int32_t)g->pending.size();
+        g->pending.push_back(vi);
     }
     // keys of the edges this call creates: after everything that exists, ordered by list position of their root
     g->key_base = g->next_key;
     g->next_key = g->key_base + ((int64_t)g->pending.size() + 1) * spg_graph::kKeyStride;
-    // room for the regions of the rounds to come (grown later if this estimate is short)
-    if (int rc = arena_ensure(g, g->used * 3 + (1 << 20))) return rc;
+    // room for the regions of the rounds to come (grown later if this estimate is short). An arena that was reserved for
+    // the job (spg_graph_reserve: 2.5x or more of what is in use) is left alone: growing means a new allocation, a device
+    // synchronisation and the whole graph uploaded again (1.2 ms of a 19 ms marginalisation of the 100k-pose graph)
+    if (g->cap < g->used * 5 / 2 + (1 << 16)) if (int rc = arena_ensure(g, g->used * 3 + (1 << 20))) return rc;
     if (int rc = sync_device(g)) return rc;
     g->active = true;
     for (int i = 0; i < spg_graph::NB; i++) { g->bt[i].round_open = false; g->bt[i].slot = i; }
@@ -1876,10 +1893,13 @@ struct Streamer {
     const int D, ps, rec;
     const int32_t P;                     // list positions
     int32_t cursor = 0;                  // positions below it have been examined at least once
+    int32_t prefetched_to = 0;
     int32_t n_done = 0, n_inflight = 0, pending_bell = 0, bell_no = 0;
     bool fallback = false;               // a blanket the worker does not take (or the arena is full): drain, then the batch driver
     int rc = 0;
-    size_t fifo_head = 0;
+    uint32_t launch_seq = 0, poll_seq = 0;  // HIP port: blankets launched so far; the oldest launch whose result has not been taken
+    std::vector<int32_t> cell_slot;         // mailbox cell -> slot of the blanket whose record it holds / will hold, -1 = free, -2 = taken (committed, not harvested)
+    size_t fifo_head = 0, edge_cap = 0;     // edge_cap: two threads — the edge array must not grow past its capacity
     int32_t cap_wait = -1;               // positions parked for a free slot
     uint64_t rng;
     double alg_bytes = 0;
@@ -1902,21 +1922,73 @@ struct Streamer {
         heads[on] = -1;
     }
 
+    // index of y in X[0 .. nX) or -1. (Branch-free forms of this search, of the two small sorts and of the list removals were
+    // measured on the bench workload: every one of them slower than the early-exit loops — 19.4 -> 20.6 -> 22.7 ms per step.)
+    static inline int find(const int32_t *X, const int nX, const int32_t y) { for (int i = 0; i < nX; i++) if (X[i] == y) return i; return -1; }
+    static inline void adj_remove(InlVec<spg_graph::AdjEnt, 7> &av, const int32_t eid) {
+        for (size_t j = 0; j < av.size(); j++) if (av[j].eid == eid) { av[j] = av.back(); av.pop_back(); break; }
+    }
+    inline void set_pend(spg_graph::SSlot &sl, const int32_t *X, const int nX) {
+        const int32_t *const cst = g->cst.data();
+        sl.npend = 0;
+        for (int i = 1; i < nX; i++) if (cst[X[i]] >= 0) { if (sl.npend == 3) { sl.npend = -1; break; } sl.pend[sl.npend++] = X[i]; }
+    }
+
     // v passed (A): its blanket X is final as a vertex set. If it has to wait all the same, the set is registered like
     // the blanket of a launched vertex (a reservation), so that later entries are checked against it instead of waiting
     // for it; the slot becomes the blanket's own when it is launched. Without a free slot the vertex simply stays WAITING.
     void reserve(const int32_t p, const int32_t *X, const int nX) {
         const SvView sv{g->vr.data()};
         const int32_t v = X[0];
-        if (sv[v].state != SV_WAITING || g->s_free.size() < 64) return;
+        if ((g->cst[v] & 3) != SV_WAITING || g->s_free.size() < 64) return;
         for (int i = 0; i < nX; i++) if (sv[X[i]].nown == spg_graph::kSOwn) return;
         const int32_t s = g->s_free.back(); g->s_free.pop_back();
         spg_graph::SSlot &sl = g->sslots[s];
         sl.pos = p; sl.root = v; sl.nv = nX; sl.ne = 0; sl.launched = 0; sl.logi = -1;
         memcpy(sl.verts, X, sizeof(int32_t) * (size_t)nX);
+        set_pend(sl, X, nX);
         for (int i = 0; i < nX; i++) { spg_graph::SVtx &sx = sv[X[i]]; sx.own[sx.nown++] = s; }
-        sv[v].state = SV_STABLE; sv[v].slot = s;
+        g->cst[v] = (p << 2) | SV_STABLE; sv[v].slot = s;
         if (g->wl_stable[p] >= 0) wake(g->wl_stable, p);
+    }
+
+    // The queue item of the blanket in slot s (layout: spg_kernels.hip, blanket_worker), written through the BAR, and its
+    // item word; `ahead` = items written since the last doorbell. Reads the slot, the poses' offsets and the blanket
+    // edges' records' locations (all immutable once the slot is handed over).
+    void build_packet(const int32_t s, const int ahead) {
+        const spg_graph::SSlot &sl = g->sslots[s];
+        const spg_graph::VRec *const vr = g->vr.data();
+        const GEdge *const edges = g->edges.data();
+        const int nX = sl.nv, ne = sl.ne, n_new_max = sl.n_new_max;
+        const int words = spg::kPktHdr + nX + 4 * ne;
+        unsigned long long pkt[spg::kPktWords];
+        auto pack = [](int lo, int hi) { return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)hi << 32); };
+        const spg_options &o = g->opts;
+        pkt[0] = (unsigned long long)(uintptr_t)arena_dev;
+        pkt[1] = port.d_mail;
+        pkt[2] = 0;
+        pkt[3] = (unsigned long long)((int64_t)sl.mcell * port.mail_stride); pkt[4] = (unsigned long long)sl.new_off; pkt[5] = (unsigned long long)(int64_t)-1;
+        pkt[6] = pack(nX, 1); pkt[7] = pack(ne, n_new_max); pkt[8] = pack(2 * n_new_max, 0);
+        pkt[9] = pack(o.topology, o.flags); pkt[10] = pack(o.lin_point, sl.tag);
+        memcpy(&pkt[11], &o.chord_ratio, 8);
+        pkt[12] = pack(words, 2 * ne);
+        int w = spg::kPktHdr;
+        for (int i = 0; i < nX; i++) pkt[w++] = (unsigned long long)vr[sl.verts[i]].pose;
+        int32_t *evp = (int32_t *)(pkt + spg::kPktHdr + nX + 3 * ne);
+        double by = 8.0 * ps * nX + 12.0 + 8.0 * (double)n_new_max * rec;
+        for (int i = 0; i < ne; i++) {
+            const GEdge &e = edges[sl.edges[i]];
+            spg_edge_ref er;
+            er.off = e.off; er.len = e.len; er.kind = e.kind; er.vbegin = 2 * i; er.nv = 2;
+            memcpy(&pkt[w], &er, 24);
+            w += 3;
+            evp[2 * i] = find(sl.verts, nX, e.vtx[0]); evp[2 * i + 1] = find(sl.verts, nX, e.vtx[1]);
+            by += 8.0 + 8.0 * e.len;
+        }
+        alg_bytes += by;
+        unsigned long long *dst = port.pkt + (size_t)s * spg::kPktWords;
+        memcpy(dst, pkt, (size_t)words * 8);                                                  // through the BAR (write-combined)
+        port.q->item[(port.tail + (unsigned long long)ahead) % spg::kQCap] = (unsigned long long)(uintptr_t)dst;
     }
 
     int examine(const int32_t p) {
@@ -1928,38 +2000,53 @@ struct Streamer {
     // 1 = launched, 0 = parked / nothing to do
     int examine_impl(const int32_t p) {
         const SvView sv{g->vr.data()};
+        int32_t *const cst = g->cst.data();
         const int32_t v = g->pending[p];
-        if (sv[v].state != SV_WAITING && sv[v].state != SV_STABLE) return 0;
+        const int vstate = cst[v] & 3;
+        if (vstate != SV_WAITING && vstate != SV_STABLE) return 0;
         n_exam++;
         spg_graph::VRec *const vr = g->vr.data();
         const GEdge *const edges = g->edges.data();
         const spg_graph::SSlot *const slots = g->sslots.data();
-        const int32_t st = ++g->sstamp;
         int32_t X[spg_graph::kSMaxV];
         int nX = 1;
         int32_t mine = -1;                       // the slot of v's reservation
-        if (sv[v].state == SV_STABLE) {
+        if (vstate == SV_STABLE) {
             mine = sv[v].slot;
             nX = slots[mine].nv;
             memcpy(X, slots[mine].verts, sizeof(int32_t) * (size_t)nX);
-            for (int i = 0; i < nX; i++) { sv[X[i]].stamp = st; sv[X[i]].lidx = (uint8_t)i; }
         } else {
-            X[0] = v; sv[v].stamp = st;
+            X[0] = v;
             for (const spg_graph::AdjEnt &a : vr[v].adj) {
                 const int32_t u = a.other;
                 if (u < 0) { fallback = true; return 0; }   // an n-ary edge: not for the worker
-                if (sv[u].stamp != st) {
+                if (find(X, nX, u) < 0) {
                     if (nX == spg_graph::kSMaxV) { fallback = true; return 0; }
-                    sv[u].stamp = st; X[nX++] = u;
+                    X[nX++] = u;
                 }
             }
             const int k0 = nX - 1;
             if (k0 < 1 || D * k0 > spg::kWorkerMaxN) { fallback = true; return 0; }
             // (A)
             for (int i = 1; i < nX; i++) {
-                const spg_graph::SVtx &sx = sv[X[i]];
+                const int32_t c = cst[X[i]];
                 // (a DONE entry that is still in the graph kept a status that forbids the graph update: it is inert)
-                if (sx.pos >= 0 && sx.state != SV_DONE && (sx.pos < p || sx.state == SV_INFLIGHT)) { n_park[0]++; park(g->wl_done, sx.pos, p); return 0; }
+                if (c >= 0 && (c & 3) != SV_DONE && ((c >> 2) < p || (c & 3) == SV_INFLIGHT)) {
+                    n_park[0]++;
+                    park(g->wl_done, c >> 2, p);
+                    // first look at v (the list cursor runs well ahead of the results): pull what its launch will read — its
+                    // neighbours' records and its edges' records, cold in DRAM until now — towards the shared cache
+                    if (p >= prefetched_to) {
+                        prefetched_to = p + 1;
+                        __builtin_prefetch((const char *)&vr[v] + 64);
+                        for (const spg_graph::AdjEnt &a : vr[v].adj) {
+                            __builtin_prefetch(&edges[a.eid]);
+                            __builtin_prefetch(&vr[a.other]);
+                            __builtin_prefetch((const char *)&vr[a.other] + 64);
+                        }
+                    }
+                    return 0;
+                }
             }
             // kept vertices in ascending id (buildSubgraph's order, src/vertex_remover.cpp:349-356)
             for (int i = 2; i < nX; i++) {
@@ -1968,7 +2055,6 @@ struct Streamer {
                 for (; j >= 1 && vr[X[j]].id > idx; j--) X[j + 1] = X[j];
                 X[j + 1] = x;
             }
-            for (int i = 0; i < nX; i++) sv[X[i]].lidx = (uint8_t)i;
         }
         const int k = nX - 1;
         // (B), registered blankets (in flight, or reserved by an earlier entry that is itself waiting), and (C)
@@ -1988,27 +2074,32 @@ struct Streamer {
         for (int h = 0; h < nh; h++) {
             const spg_graph::SSlot &o = slots[hs[h]];
             if (o.pos > p) continue;
-            for (int i = 0; i < o.nv; i++) {
-                const spg_graph::SVtx &sy = sv[o.verts[i]];
-                if (sy.pos >= 0 && sy.pos < p && sy.state == SV_WAITING) { n_park[3]++; reserve(p, X, nX); park(g->wl_done, o.pos, p); return 0; }
+            const int32_t *mem = o.npend >= 0 ? o.pend : o.verts + 1;
+            const int nmem = o.npend >= 0 ? o.npend : o.nv - 1;
+            for (int i = 0; i < nmem; i++) {
+                const int32_t c = cst[mem[i]];
+                if (c >= 0 && (c & 3) == SV_WAITING && (c >> 2) < p) { n_park[3]++; reserve(p, X, nX); park(g->wl_done, o.pos, p); return 0; }
             }
         }
         // (B), entries without a final blanket, fused with markovBlanketEdges (src/vertex_remover.cpp:225-251): one pass over
-        // the adjacency of X \ {v}; no edge record is read (the far endpoints are in the adjacency entries)
+        // the adjacency of X \ {v}; no edge record is read (the far endpoints are in the adjacency entries) and no
+        // per-vertex record of a vertex outside X (list positions and states come from the compact array)
         int32_t E[spg_graph::kSMaxE];
         int ne = 0;
         for (int i = 1; i < nX; i++) {
             for (const spg_graph::AdjEnt &a : vr[X[i]].adj) {
                 const int32_t y = a.other;
                 if (y < 0) { fallback = true; return 0; }
-                const spg_graph::SVtx &sy = sv[y];
-                if (sy.stamp == st) {
-                    const int j = sy.lidx;
+                const int j = find(X, nX, y);
+                if (j >= 0) {
                     if (j == 0 || j >= i) {   // every blanket edge once: from its kept end, or from the lower-numbered of two kept ends
                         if (ne == spg_graph::kSMaxE) { fallback = true; return 0; }
                         E[ne++] = a.eid;
                     }
-                } else if (sy.pos >= 0 && sy.pos < p && sy.state == SV_WAITING) { n_park[4]++; reserve(p, X, nX); park(g->wl_stable, sy.pos, p); return 0; }
+                } else {
+                    const int32_t c = cst[y];
+                    if (c >= 0 && (c & 3) == SV_WAITING && (c >> 2) < p) { n_park[4]++; reserve(p, X, nX); park(g->wl_stable, c >> 2, p); return 0; }
+                }
             }
         }
         const int words = spg::kPktHdr + nX + 4 * ne;
@@ -2017,10 +2108,12 @@ struct Streamer {
             for (int i = 0; i < nX; i++) if (sv[X[i]].nown == spg_graph::kSOwn) { park(g->wl_done, slots[sv[X[i]].own[0]].pos, p); return 0; }
             if (g->s_free.empty()) { g->wl_next[p] = cap_wait; cap_wait = p; return 0; }
         }
+        if (!emulate && cell_slot[launch_seq & (uint32_t)(port.slots - 1)] != -1) { g->wl_next[p] = cap_wait; cap_wait = p; return 0; }   // the next mailbox cell still holds an unharvested record
         // ---- launch
         const int n_new_max = k - 1, n_new_vert_max = 2 * (k - 1);
         const int64_t new_len = (int64_t)n_new_max * rec, out_len = emulate ? SPG_OUT_LEN(n_new_max, n_new_vert_max) : 0;
         if (g->used + new_len + out_len > g->cap) { fallback = true; return 0; }
+        if (edge_cap && g->edges.size() + (size_t)n_new_max + 64 > edge_cap) { fallback = true; return 0; }
         // ascending key = the reference's sequential edge order
         for (int i = 1; i < ne; i++) {
             const int32_t eid = E[i]; const int64_t key = edges[eid].key;
@@ -2033,48 +2126,31 @@ struct Streamer {
         spg_graph::SSlot &sl = g->sslots[s];
         sl.pos = p; sl.root = v; sl.nv = nX; sl.ne = ne; sl.n_new_max = n_new_max; sl.logi = -1; sl.bell = bell_no + 1; sl.launched = 1;
         sl.tag = (++g->ctx->tag_counter & 0x3fffffff) + 1;
+        sl.mcell = (int32_t)(launch_seq & (uint32_t)(port.slots - 1));
+        if (!emulate) { cell_slot[sl.mcell] = s; launch_seq++; }
         sl.out_off = emulate ? g->used : -1;
         sl.new_off = g->used + out_len;
         g->used += new_len + out_len;
-        memcpy(sl.verts, X, sizeof(int32_t) * (size_t)nX);
         memcpy(sl.edges, E, sizeof(int32_t) * (size_t)ne);
-        if (mine < 0) for (int i = 0; i < nX; i++) { spg_graph::SVtx &sx = sv[X[i]]; sx.own[sx.nown++] = s; }
-        sv[v].state = SV_INFLIGHT; sv[v].slot = s;
-        P1(3);
-        if (!emulate) {
-            unsigned long long pkt[spg::kPktWords];
-            auto pack = [](int lo, int hi) { return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)hi << 32); };
-            const spg_options &o = g->opts;
-            pkt[0] = (unsigned long long)(uintptr_t)arena_dev;
-            pkt[1] = port.d_mail;
-            pkt[2] = 0;
-            pkt[3] = (unsigned long long)((int64_t)s * port.mail_stride); pkt[4] = (unsigned long long)sl.new_off; pkt[5] = (unsigned long long)(int64_t)-1;
-            pkt[6] = pack(nX, 1); pkt[7] = pack(ne, n_new_max); pkt[8] = pack(n_new_vert_max, 0);
-            pkt[9] = pack(o.topology, o.flags); pkt[10] = pack(o.lin_point, sl.tag);
-            memcpy(&pkt[11], &o.chord_ratio, 8);
-            pkt[12] = pack(words, 2 * ne);
-            int w = spg::kPktHdr;
-            for (int i = 0; i < nX; i++) pkt[w++] = (unsigned long long)vr[X[i]].pose;
-            int32_t *evp = (int32_t *)(pkt + spg::kPktHdr + nX + 3 * ne);
-            double by = 8.0 * ps * nX + 12.0 + 8.0 * (double)new_len;
-            for (int i = 0; i < ne; i++) {
-                const GEdge &e = edges[E[i]];
-                spg_edge_ref er;
-                er.off = e.off; er.len = e.len; er.kind = e.kind; er.vbegin = 2 * i; er.nv = 2;
-                memcpy(&pkt[w], &er, 24);
-                w += 3;
-                evp[2 * i] = sv[e.vtx[0]].lidx; evp[2 * i + 1] = sv[e.vtx[1]].lidx;
-                by += 8.0 + 8.0 * e.len;
-            }
-            alg_bytes += by;
-            unsigned long long *dst = port.pkt + (size_t)s * spg::kPktWords;
-            memcpy(dst, pkt, (size_t)words * 8);                                                  // through the BAR (write-combined)
-            port.q->item[(port.tail + (unsigned long long)pending_bell) % spg::kQCap] = (unsigned long long)(uintptr_t)dst;
+        if (mine < 0) {
+            memcpy(sl.verts, X, sizeof(int32_t) * (size_t)nX);
+            set_pend(sl, X, nX);
+            for (int i = 0; i < nX; i++) { spg_graph::SVtx &sx = sv[X[i]]; sx.own[sx.nown++] = s; }
         }
+        cst[v] = (p << 2) | SV_INFLIGHT; sv[v].slot = s;
+        P1(3);
+        if (threaded) {
+            // the I/O thread writes the packet, rings the doorbell and watches the mailbox cell
+            io.lq[io.l_head_local++ & (IoShared::LQ - 1)] = s;
+            n_inflight++;
+            if (g->wl_stable[p] >= 0) wake(g->wl_stable, p);
+            return 1;
+        }
+        if (!emulate) build_packet(s, pending_bell);
         P1(4);
         pending_bell++;
         n_inflight++;
-        g->s_fifo.push_back(s);
+        if (emulate) g->s_fifo.push_back(s);
         if (g->wl_stable[p] >= 0) wake(g->wl_stable, p);
         return 1;
     }
@@ -2115,10 +2191,8 @@ struct Streamer {
                 const int32_t eid = sl.edges[i];
                 GEdge &e = g->edges[eid];
                 e.alive = 0;
-                for (int t = 0; t < 2; t++) {
-                    auto &av = g->vr[e.vtx[t]].adj;
-                    for (size_t j = 0; j < av.size(); j++) if (av[j] == eid) { av[j] = av.back(); av.pop_back(); break; }
-                }
+                adj_remove(g->vr[e.vtx[0]].adj, eid);
+                if (e.vtx[1] != e.vtx[0]) adj_remove(g->vr[e.vtx[1]].adj, eid);
             }
             g->n_mutations += sl.ne + 1;
             g->n_live_e -= sl.ne;
@@ -2143,7 +2217,7 @@ struct Streamer {
             spg_graph::SVtx &sx = sv[sl.verts[i]];
             for (int j = 0; j < sx.nown; j++) if (sx.own[j] == s) { sx.own[j] = sx.own[--sx.nown]; break; }
         }
-        sv[v].state = SV_DONE;
+        g->cst[v] = (p << 2) | SV_DONE;
         n_done++;
         n_inflight--;
         if (final_seen) harvest(s, recd);
@@ -2156,34 +2230,54 @@ struct Streamer {
         BlanketLog &lg = g->log[sl.logi];
         lg.kld = recd[2]; lg.min_gap = recd[3]; lg.status = (int32_t)recd[0];
         if (std::isfinite(recd[2])) g->stats.kld_sum += recd[2];
+        if (!emulate) cell_slot[sl.mcell] = -1;
         g->s_free.push_back(s);
         for (int32_t q = cap_wait; q >= 0;) { const int32_t nx = g->wl_next[q]; g->s_woken.push_back(q); q = nx; }
         cap_wait = -1;
     }
 
-    inline const double *cell(int32_t s) const { return port.h_mail + (size_t)s * (size_t)port.mail_stride; }
+    inline const double *cell(int32_t s) const { return port.h_mail + (size_t)g->sslots[s].mcell * (size_t)port.mail_stride; }
 
-    // blankets whose ready (or final) word has arrived, among the oldest `window` in flight. Tickets are served in
-    // order and blankets take about the same time, so results arrive nearly in launch order: the scan stops after
-    // `giveup` unfinished entries in a row (every 16th call looks at the whole window).
-    void poll_hip(int window, int giveup) {
-        std::vector<int32_t> &fifo = g->s_fifo, &ready = g->s_ready;
-        while (fifo_head < fifo.size() && fifo[fifo_head] < 0) fifo_head++;
-        int seen = 0, misses = 0;
-        for (size_t i = fifo_head; i < fifo.size() && seen < window && misses < giveup; i++) {
-            const int32_t s = fifo[i];
-            if (s < 0) continue;
-            seen++;
-            const volatile double *c = cell(s);
-            const double w = c[5], tagd = (double)g->sslots[s].tag;
-            if (w == 4503599627370496.0 + tagd || w == 4503599627370496.0 + 4294967296.0 + tagd) {
-                for (int l = 8; l < 40; l += 8) __builtin_prefetch((const void *)(c + l));
-                ready.push_back(s);
-                fifo[i] = -1;
-                misses = 0;
-            } else misses++;
+    // Blankets whose ready (or final) word has arrived. Mailbox cells are handed out in launch order and tickets are served
+    // in that order, so results land nearly in sequence in sequential memory: the scan starts at the oldest launch not
+    // taken yet and stops after `giveup` unfinished cells in a row (every 16th call looks at everything in flight).
+    void poll_hip(int giveup) {
+        std::vector<int32_t> &ready = g->s_ready;
+        const uint32_t mask = (uint32_t)(port.slots - 1);
+        while (poll_seq != launch_seq && cell_slot[poll_seq & mask] < 0) poll_seq++;
+        int misses = 0;
+        for (uint32_t q0 = poll_seq; q0 != launch_seq && misses < giveup;) {
+            // the ready words of the next 16 cells are loaded before any is looked at: the lines the device has just written
+            // miss the caches, and behind a branch per cell those misses would be taken one after the other
+            const uint32_t nq = std::min<uint32_t>(16, launch_seq - q0);
+            double w[16];
+            for (uint32_t i = 0; i < nq; i++) w[i] = ((const volatile double *)(port.h_mail + (size_t)((q0 + i) & mask) * (size_t)port.mail_stride))[5];
+            for (uint32_t i = 0; i < nq; i++) {
+                const uint32_t q = q0 + i;
+                const int32_t s = cell_slot[q & mask];
+                if (s < 0) continue;
+                const double tagd = (double)g->sslots[s].tag;
+                if (w[i] == 4503599627370496.0 + tagd || w[i] == 4503599627370496.0 + 4294967296.0 + tagd) {
+                    const double *c = port.h_mail + (size_t)(q & mask) * (size_t)port.mail_stride;
+                    for (int l = 8; l < 40; l += 8) __builtin_prefetch((const void *)(c + l));
+                    __builtin_prefetch(&g->sslots[s]); __builtin_prefetch((const char *)&g->sslots[s] + 64); __builtin_prefetch((const char *)&g->sslots[s] + 128);
+                    ready.push_back(s);
+                    cell_slot[q & mask] = -2;
+                    misses = 0;
+                } else misses++;
+            }
+            q0 += nq;
         }
-        if (fifo_head > 4096 && fifo_head * 2 > fifo.size()) { fifo.erase(fifo.begin(), fifo.begin() + (long)fifo_head); fifo_head = 0; }
+        // the ready words the next call will look at first: on their way while this call's results are committed (a cell the
+        // device has not written yet comes in stale and is invalidated by the write; one it has written is a hit next time)
+        {
+            uint32_t q = poll_seq;
+            for (int n = 0; q != launch_seq && n < 12; q++) {
+                if (cell_slot[q & mask] < 0) continue;
+                __builtin_prefetch((const void *)(port.h_mail + (size_t)(q & mask) * (size_t)port.mail_stride));
+                n++;
+            }
+        }
     }
 
     // Emulated device (injected backend; tests): "complete" a subset of the in-flight blankets, chosen and ordered by the
@@ -2239,6 +2333,227 @@ struct Streamer {
         return 0;
     }
 
+    // ---- two host threads (the default on the HIP backend; SPG_STREAM_THREADS=1 keeps everything on one): this one — the
+    // graph thread — commits and selects; the I/O thread writes packets and doorbells through the BAR, polls the mailbox and
+    // hands the out records over in a ring of ordinary memory. What they share: slots (written by the graph thread before it
+    // publishes the slot id, read-only from then until the commit), the immutable parts of vertices and edge records, and
+    // the two rings below, every index on a cache line of its own.
+    struct IoShared {
+        static constexpr uint32_t LQ = 4096, RQ = 2048, RSTRIDE = 88;   // launch ring (slot ids); result ring (entries of RSTRIDE doubles: slot, final flag, out record)
+        alignas(64) std::atomic<uint32_t> l_tail{0};     // graph thread: slot ids published
+        alignas(64) std::atomic<uint32_t> l_head{0};     // I/O thread: slot ids taken
+        alignas(64) std::atomic<uint32_t> r_tail{0};     // I/O thread: results published
+        alignas(64) std::atomic<uint32_t> r_head{0};     // graph thread: results taken
+        alignas(64) std::atomic<int> stop{0};
+        alignas(64) std::atomic<int> error{0};
+        alignas(64) uint32_t l_head_local = 0;            // graph thread's private write index of lq
+        int32_t lq[LQ];
+        std::vector<double> rq;                           // RQ * RSTRIDE doubles
+        long doorbells = 0;
+        char pad_[64];
+    } io;
+    bool threaded = false;
+    std::thread io_thread;
+
+    void io_main() {
+        std::vector<int32_t> fifo;
+        size_t head = 0;
+        unsigned n_polls = 0;
+        int bell_pending = 0;
+        uint32_t l_head = 0, r_tail = 0;
+        const double READY = 4503599627370496.0, FINAL = 4503599627370496.0 + 4294967296.0;
+        uint64_t last_progress = ticks_now();
+        for (;;) {
+            // ---- hand-overs: every slot id the graph thread has published
+            const uint32_t lt = io.l_tail.load(std::memory_order_acquire);
+            while (l_head != lt) {
+                const int32_t s = io.lq[l_head++ & (IoShared::LQ - 1)];
+                build_packet(s, bell_pending);
+                bell_pending++;
+                fifo.push_back(s);
+            }
+            if (bell_pending) {
+                io.l_head.store(l_head, std::memory_order_release);
+                std::atomic_thread_fence(std::memory_order_release);
+#if defined(__x86_64__)
+                __builtin_ia32_sfence();
+#endif
+                port.tail += (unsigned long long)bell_pending;
+                for (int c = 0; c < port.bells; c++) port.q->tail[c * spg::kBellStride] = port.tail;
+#if defined(__x86_64__)
+                __builtin_ia32_sfence();
+#endif
+                bell_pending = 0;
+                io.doorbells++;
+            }
+            // ---- results: ready (or final) words among the oldest blankets in flight, copied into the result ring
+            while (head < fifo.size() && fifo[head] < 0) head++;
+            const int giveup = (++n_polls & 15) ? 10 : 256;
+            int seen = 0, misses = 0;
+            bool got = false;
+            for (size_t i = head; i < fifo.size() && seen < 256 && misses < giveup; i++) {
+                const int32_t s = fifo[i];
+                if (s < 0) continue;
+                seen++;
+                const volatile double *c = cell(s);
+                const double w = c[5], tagd = (double)g->sslots[s].tag;
+                if (w == READY + tagd || w == FINAL + tagd) {
+                    const int nm = g->sslots[s].n_new_max, olen = SPG_OUT_LEN(nm, 2 * nm);
+                    double *e = io.rq.data() + (size_t)(r_tail & (IoShared::RQ - 1)) * IoShared::RSTRIDE;
+                    // (the ring has a cell per slot: it cannot be full)
+                    e[0] = (double)s; e[1] = (w == FINAL + tagd) ? 1.0 : 0.0;
+                    memcpy(e + 2, (const double *)c, sizeof(double) * (size_t)olen);
+                    r_tail++;
+                    fifo[i] = -1;
+                    misses = 0;
+                    got = true;
+                } else misses++;
+            }
+            if (got) { io.r_tail.store(r_tail, std::memory_order_release); last_progress = ticks_now(); }
+            if (head > 4096 && head * 2 > fifo.size()) { fifo.erase(fifo.begin(), fifo.begin() + (long)head); head = 0; }
+            if (io.stop.load(std::memory_order_acquire) && l_head == io.l_tail.load(std::memory_order_acquire)) {
+                bool live = false;
+                for (size_t i = head; i < fifo.size(); i++) live |= fifo[i] >= 0;
+                if (!live) break;
+            }
+            if (!got && lt == l_head && head < fifo.size() && ((ticks_now() - last_progress) >> 35) != 0) { io.error.store(1); break; }   // ~10 s without a result
+        }
+    }
+
+    int run_threaded() {
+        const uint64_t t_begin = ticks_now();
+        const double s_begin = now_s();
+        uint64_t idle_since = 0;
+        std::vector<int32_t> &woken = g->s_woken, &fin = g->s_fin;
+        size_t fin_head = 0;
+        io.rq.resize((size_t)IoShared::RQ * IoShared::RSTRIDE);
+        threaded = true;
+        io_thread = std::thread([this] { io_main(); });
+#if defined(__linux__)
+        // both threads on one L3: the slot lines one writes and the other reads, and the result ring, move through the shared
+        // cache. Best effort: the graph thread stays where it is for the duration of the call, the I/O thread goes next to it
+        // (cores of a group of 8 share an L3 on the hosts this runs on).
+        cpu_set_t old_mask;
+        bool repin = false;
+        static const bool pin = [] { const char *e = getenv("SPG_PIN_THREADS"); return !(e && e[0] == '0'); }();
+        if (pin && sched_getaffinity(0, sizeof old_mask, &old_mask) == 0) {
+            const int cpu = sched_getcpu();
+            if (cpu >= 0) {
+                for (int d = 1; d < 8; d++) {
+                    const int cand = (cpu & ~7) | ((cpu + d) & 7);
+                    if (cand < CPU_SETSIZE && CPU_ISSET(cand, &old_mask)) {
+                        cpu_set_t one; CPU_ZERO(&one); CPU_SET(cand, &one);
+                        (void)pthread_setaffinity_np(io_thread.native_handle(), sizeof one, &one);
+                        CPU_ZERO(&one); CPU_SET(cpu, &one);
+                        repin = sched_setaffinity(0, sizeof one, &one) == 0;
+                        break;
+                    }
+                }
+            }
+        }
+#endif
+        uint32_t r_head = 0, l_pub = 0;
+        auto publish = [&]() {
+            if (io.l_head_local != l_pub) { l_pub = io.l_head_local; io.l_tail.store(l_pub, std::memory_order_release); bell_no++; }
+        };
+        int err = 0;
+        for (;;) {
+            const uint32_t rt = io.r_tail.load(std::memory_order_acquire);
+            const bool got = rt != r_head;
+            if (got && idle_since) { t_idle += ticks_now() - idle_since; idle_since = 0; }
+            while (r_head != rt) {
+                const double *e = io.rq.data() + (size_t)(r_head & (IoShared::RQ - 1)) * IoShared::RSTRIDE;
+                __builtin_prefetch(e + IoShared::RSTRIDE); __builtin_prefetch(e + IoShared::RSTRIDE + 8);
+                const int32_t s = (int32_t)e[0];
+                P0();
+                commit(s, e + 2, e[1] != 0.0);
+                P1(1);
+                r_head++;
+                if (!fallback) {
+                    for (size_t wi = 0; wi < woken.size(); wi++) examine(woken[wi]);
+                    if (io.l_head_local - l_pub >= 4) publish();
+                }
+                woken.clear();
+            }
+            if (got) io.r_head.store(r_head, std::memory_order_release);
+            // late results, in bulk (see run())
+            if (fin.size() - fin_head >= 192 || g->s_free.size() < 256 || (cap_wait >= 0 && fin_head < fin.size())) {
+                P0();
+                const size_t n = std::min<size_t>(64, fin.size() - fin_head);
+                for (size_t i = 0; i < n; i++) __builtin_prefetch((const void *)cell(fin[fin_head + i]));
+                for (size_t i = 0; i < n; i++) {
+                    const int32_t s = fin[fin_head];
+                    const volatile double *c = cell(s);
+                    if (c[5] != 4503599627370496.0 + 4294967296.0 + (double)g->sslots[s].tag) break;
+                    harvest(s, (const double *)c);
+                    fin_head++;
+                }
+                if (fin_head > 8192) { fin.erase(fin.begin(), fin.begin() + (long)fin_head); fin_head = 0; }
+                P1(6);
+                if (!woken.empty()) {
+                    if (!fallback) for (size_t wi = 0; wi < woken.size(); wi++) examine(woken[wi]);
+                    woken.clear();
+                }
+            }
+            if (!fallback && cursor < P) {
+                int budget = got ? 4 : 32;
+                while (cursor < P && budget-- > 0 && !fallback) {
+                    examine(cursor++);
+                    if (!woken.empty()) { for (size_t wi = 0; wi < woken.size() && !fallback; wi++) examine(woken[wi]); woken.clear(); }
+                }
+            }
+            publish();
+            if (n_done == P) break;
+            if (fallback && n_inflight == 0) break;
+            if (io.error.load(std::memory_order_relaxed)) { err = SPG_EHIP; break; }
+            if (got || cursor < P) continue;
+            if (!idle_since) idle_since = ticks_now();
+            if (n_inflight == 0 && fin_head == fin.size()) { fallback = true; break; }   // (cannot happen: see run())
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        io.stop.store(1, std::memory_order_release);
+        io_thread.join();
+        threaded = false;
+#if defined(__linux__)
+        if (repin) (void)sched_setaffinity(0, sizeof old_mask, &old_mask);
+#endif
+        g->stats.n_batches += (int32_t)io.doorbells;
+        if (err || io.error.load()) { set_err(g->ctx, SPG_EHIP, "streaming driver: no blanket completed within 10 s"); return SPG_EHIP; }
+        // drain the final words
+        {
+            const double t0 = now_s();
+            for (; fin_head < fin.size(); fin_head++) {
+                const int32_t s = fin[fin_head];
+                const volatile double *c = cell(s);
+                uint32_t spins = 0;
+                while (c[5] != 4503599627370496.0 + 4294967296.0 + (double)g->sslots[s].tag) {
+                    if ((++spins & 0xfff) == 0 && now_s() - t0 > 10.0) { set_err(g->ctx, SPG_EHIP, "streaming driver: a blanket's KLD tail did not complete within 10 s"); return SPG_EHIP; }
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+                harvest(s, (const double *)c);
+            }
+            woken.clear();
+        }
+        fin.clear();
+        if (idle_since) { t_idle += ticks_now() - idle_since; idle_since = 0; }
+        const uint64_t t_end = ticks_now();
+        const double secs = now_s() - s_begin;
+        const double idle = (t_end > t_begin) ? secs * (double)t_idle / (double)(t_end - t_begin) : 0.0;
+        g->stats.device_seconds += idle;
+        g->stats.host_seconds += secs - idle;
+        g->stats.schedule_seconds += secs - idle;
+        if (prof) {
+            const char *nm[8] = {"poll", "commit", "examine: parked", "examine: launch decision", "packet", "doorbell", "late results", "launch tail"};
+            const double tps = (double)(t_end - t_begin) / secs;
+            for (int i = 0; i < 8; i++) fprintf(stderr, "stream prof %-26s %8llu x %8.1f ns = %8.3f ms\n", nm[i], (unsigned long long)pn[i], pn[i] ? 1e9 * (double)pt[i] / tps / (double)pn[i] : 0.0, 1e3 * (double)pt[i] / tps);
+        }
+        return 0;
+    }
+
     int run() {
         const uint64_t t_begin = ticks_now();
         const double s_begin = now_s();
@@ -2251,10 +2566,13 @@ struct Streamer {
             ready.clear();
             P0();
             if (emulate) { if ((rc = poll_emulated()) != 0) return rc; }
-            else if (n_inflight) poll_hip(n_inflight <= 256 ? n_inflight : 256, (++n_polls & 15) ? 10 : 256);
+            else if (n_inflight) poll_hip((++n_polls & 15) ? 10 : 1 << 20);
             P1(0);
             const bool got = !ready.empty();
             if (got && idle_since) { t_idle += ticks_now() - idle_since; idle_since = 0; }
+            // every result that has arrived is committed before anything is examined: a woken entry often waits for two or
+            // three of them (its column's predecessor and that one's neighbours), and looking at it between their commits
+            // only parks it again
             for (size_t ri = 0; ri < ready.size(); ri++) {
                 const int32_t s = ready[ri];
                 const double *recd = emulate ? g->host.data() + g->sslots[s].out_off : cell(s);
@@ -2262,16 +2580,18 @@ struct Streamer {
                 P0();
                 commit(s, recd, fin_now);
                 P1(1);
-                if (!fallback) {
-                    // (woken entries are examined oldest first: a launch may be what the next one waits for)
-                    for (size_t wi = 0; wi < woken.size(); wi++) examine(woken[wi]);
-                    if (pending_bell >= 6) ring();
-                }
-                woken.clear();
             }
+            if (!fallback) {
+                // (woken entries are examined in the order of their wake-up: a launch may be what the next one waits for)
+                for (size_t wi = 0; wi < woken.size(); wi++) {
+                    examine(woken[wi]);
+                    if (pending_bell >= 8) ring();
+                }
+            }
+            woken.clear();
             // ---- late results (final words) of committed blankets, in bulk: each is a line the device has rewritten since the
             // commit read it (a miss), nothing waits for them, and taken 64 at a time the misses overlap
-            if (!emulate && (fin.size() - fin_head >= 192 || g->s_free.size() < 256)) {
+            if (!emulate && (fin.size() - fin_head >= 192 || g->s_free.size() < 256 || (cap_wait >= 0 && fin_head < fin.size()))) {
                 P0();
                 const size_t n = std::min<size_t>(64, fin.size() - fin_head);
                 for (size_t i = 0; i < n; i++) __builtin_prefetch((const void *)cell(fin[fin_head + i]));
@@ -2376,9 +2696,8 @@ static int stream_marginalize(spg_graph *g) {
     }
     // state
     const size_t V = g->vid.size();
-    (void)V;
-    for (int32_t p = 0; p < P; p++) { spg_graph::SVtx &x = g->vr[g->pending[p]].s; x.pos = p; x.state = SV_WAITING; x.nown = 0; }
-    if (g->sstamp > 0x7f000000) { for (auto &r : g->vr) r.s.stamp = 0; g->sstamp = 0; }
+    if (g->cst.size() < V) g->cst.resize(V, -1);
+    for (int32_t p = 0; p < P; p++) { g->cst[g->pending[p]] = (p << 2) | SV_WAITING; g->vr[g->pending[p]].s.nown = 0; }
     g->wl_next.assign((size_t)P, -1); g->wl_stable.assign((size_t)P, -1); g->wl_done.assign((size_t)P, -1);
     if (g->sslots.size() < (size_t)kStreamSlots) g->sslots.resize(kStreamSlots);
     g->s_free.clear();
@@ -2389,7 +2708,19 @@ static int stream_marginalize(spg_graph *g) {
     if ((int64_t)g->host.size() < g->cap) g->host.resize((size_t)g->cap);
     S.rng = 0x9E3779B97F4A7C15ULL ^ ((uint64_t)(g->stream_emulation > 0 ? g->stream_emulation : 1) * 0xD1B54A32D192ED03ULL);
     const int64_t used0 = g->used;
-    const int rc = S.run();
+    if (!emulate) S.cell_slot.assign((size_t)S.port.slots, -1);
+    static const bool one_thread = [] { const char *e = getenv("SPG_STREAM_THREADS"); return !(e && e[0] == '2'); }();   // (two threads: measured slower)
+    // (the edge and log containers must not move while the I/O thread reads edge records: room for everything this call can add)
+    bool two = !emulate && !one_thread;
+    if (two) {
+        const size_t need_e = g->edges.size() + (size_t)P * 4 + 1024, need_l = g->log.size() + (size_t)P + 16;
+        if (g->edges.capacity() < need_e) g->edges.reserve(need_e);
+        if (g->log.capacity() < need_l) g->log.reserve(need_l);
+        S.edge_cap = g->edges.capacity();
+    }
+    const double t_setup = now_s();
+    const int rc = two ? S.run_threaded() : S.run();
+    const double t_ran = now_s();
     if (sim) sim->tail = S.port.tail;
     else if (!emulate) spg::hip_stream_close(&g->ctx->be, &S.port, S.alg_bytes, (long long)S.n_done);
     // what the stream produced in the arena is device-only until someone asks for it
@@ -2410,19 +2741,22 @@ static int stream_marginalize(spg_graph *g) {
     for (int32_t p = 0; p < P; p++) {
         const int32_t v = g->pending[p];
         spg_graph::SVtx &sq = g->vr[v].s;
-        if (sq.state == SV_STABLE) {   // a reservation that was never launched (the stream handed over to the batch driver)
+        const int vst = g->cst[v] & 3;
+        if (vst == SV_STABLE) {   // a reservation that was never launched (the stream handed over to the batch driver)
             const spg_graph::SSlot &sl = g->sslots[sq.slot];
             for (int i = 0; i < sl.nv; i++) {
                 spg_graph::SVtx &sx = g->vr[sl.verts[i]].s;
                 for (int j = 0; j < sx.nown; j++) if (sx.own[j] == sq.slot) { sx.own[j] = sx.own[--sx.nown]; break; }
             }
         }
-        const bool done = sq.state == SV_DONE;
-        sq.pos = -1; sq.nown = 0; sq.state = SV_WAITING;
+        const bool done = vst == SV_DONE;
+        g->cst[v] = -1; sq.nown = 0;
         if (!done) g->pending[left++] = v;
     }
     g->pending.resize(left);
     g->pend_head = 0;
+    if (getenv("SPG_TRACE"))
+        fprintf(stderr, "spg trace: streaming driver: run %.3f ms, tear-down %.3f ms\n", 1e3 * (t_ran - t_setup), 1e3 * (now_s() - t_ran));
     if (getenv("SPG_TRACE"))
         fprintf(stderr, "spg trace: streaming driver: %d list entries, %d committed in %d doorbells, %zu left to the batch driver (examined up to entry %d)\n",
                 P, S.n_done, S.bell_no, left, S.cursor);
@@ -2445,8 +2779,10 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
     if (builtin && (!g->ctx->rccl || g->ctx->nranks != nranks || g->ctx->rank != rank))
         return set_err(g->ctx, SPG_EINVAL, "spg_graph_marginalize_ranks: no exchange callback and the context has no matching RCCL communicator (spg_ctx_create_ranks)");
     int launches0 = (g && g->ctx->is_hip) ? spg::hip_backend_launches(&g->ctx->be) : 0;
+    const double t_call = now_s();
     int rc = spg_graph_marginalize_begin(g, which, n, opts, rank, nranks);
     if (rc) return rc;
+    const double t_begun = now_s();
     const char *env = getenv("SPG_NO_PIPELINE");
     g->pipelined = g->ctx->be.synchronize_slot && g->ctx->be.mailbox_slot && !(env && env[0] == '1');
     // single rank, NFR Tree at the stored estimates: blanket by blanket through the persistent worker (streaming driver);
@@ -2454,7 +2790,9 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
     int stream_rc = 1;
     if (nranks == 1 && !exchange) stream_rc = stream_marginalize(g);
     if (stream_rc <= 0) {
+        const double t_streamed = now_s();
         int rc2 = spg_graph_marginalize_end(g, stats);
+        if (getenv("SPG_TRACE")) fprintf(stderr, "spg trace: marginalize: begin %.3f ms, stream %.3f ms, end %.3f ms\n", 1e3 * (t_begun - t_call), 1e3 * (t_streamed - t_begun), 1e3 * (now_s() - t_streamed));
         if (stats && g->ctx->is_hip) stats->n_launches -= launches0;
         return stream_rc < 0 ? stream_rc : rc2;
     }
