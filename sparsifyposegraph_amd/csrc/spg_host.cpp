@@ -1884,7 +1884,7 @@ static inline uint64_t ticks_now() { return (uint64_t)(now_s() * 1e9); }
 namespace {
 enum : uint8_t { SV_WAITING = 0, SV_STABLE = 1, SV_INFLIGHT = 2, SV_DONE = 3 };
 constexpr int kStreamSlots = 2048;       // blankets in flight at most (the worker has 256 workgroups; the rest queue)
-constexpr int kStreamMailStride = 80;    // doubles per mailbox cell (>= SPG_OUT_LEN of the largest blanket a worker takes)
+constexpr int kStreamMailStride = 8;     // doubles per mailbox cell: the compact out record of the worker (flags bit 20, spg_kernels.hip publish()) is one cache line
 
 struct Streamer {
     spg_graph *g;
@@ -1899,7 +1899,7 @@ struct Streamer {
     int rc = 0;
     uint32_t launch_seq = 0, poll_seq = 0;  // HIP port: blankets launched so far; the oldest launch whose result has not been taken
     std::vector<int32_t> cell_slot;         // mailbox cell -> slot of the blanket whose record it holds / will hold, -1 = free, -2 = taken (committed, not harvested)
-    size_t fifo_head = 0, edge_cap = 0;     // edge_cap: two threads — the edge array must not grow past its capacity
+    size_t fifo_head = 0;
     int32_t cap_wait = -1;               // positions parked for a free slot
     uint64_t rng;
     double alg_bytes = 0;
@@ -1969,7 +1969,7 @@ struct Streamer {
         pkt[2] = 0;
         pkt[3] = (unsigned long long)((int64_t)sl.mcell * port.mail_stride); pkt[4] = (unsigned long long)sl.new_off; pkt[5] = (unsigned long long)(int64_t)-1;
         pkt[6] = pack(nX, 1); pkt[7] = pack(ne, n_new_max); pkt[8] = pack(2 * n_new_max, 0);
-        pkt[9] = pack(o.topology, o.flags); pkt[10] = pack(o.lin_point, sl.tag);
+        pkt[9] = pack(o.topology, o.flags | (1 << 20)); pkt[10] = pack(o.lin_point, sl.tag);   // bit 20: compact out record
         memcpy(&pkt[11], &o.chord_ratio, 8);
         pkt[12] = pack(words, 2 * ne);
         int w = spg::kPktHdr;
@@ -2113,7 +2113,6 @@ struct Streamer {
         const int n_new_max = k - 1, n_new_vert_max = 2 * (k - 1);
         const int64_t new_len = (int64_t)n_new_max * rec, out_len = emulate ? SPG_OUT_LEN(n_new_max, n_new_vert_max) : 0;
         if (g->used + new_len + out_len > g->cap) { fallback = true; return 0; }
-        if (edge_cap && g->edges.size() + (size_t)n_new_max + 64 > edge_cap) { fallback = true; return 0; }
         // ascending key = the reference's sequential edge order
         for (int i = 1; i < ne; i++) {
             const int32_t eid = E[i]; const int64_t key = edges[eid].key;
@@ -2139,14 +2138,8 @@ struct Streamer {
         }
         cst[v] = (p << 2) | SV_INFLIGHT; sv[v].slot = s;
         P1(3);
-        if (threaded) {
-            // the I/O thread writes the packet, rings the doorbell and watches the mailbox cell
-            io.lq[io.l_head_local++ & (IoShared::LQ - 1)] = s;
-            n_inflight++;
-            if (g->wl_stable[p] >= 0) wake(g->wl_stable, p);
-            return 1;
-        }
         if (!emulate) build_packet(s, pending_bell);
+        if (helper) hp.cell_tag[sl.mcell] = (uint32_t)sl.tag;
         P1(4);
         pending_bell++;
         n_inflight++;
@@ -2172,6 +2165,7 @@ struct Streamer {
         pending_bell = 0;
         bell_no++;
         g->stats.n_batches++;
+        if (helper) hp.launches.store(launch_seq, std::memory_order_release);
         P1(5);
     }
 
@@ -2201,15 +2195,26 @@ struct Streamer {
             g->n_live_v--;
             g->stats.n_removed++;
             const int64_t key0 = g->key_base + (int64_t)p * spg_graph::kKeyStride;
-            int vpos = 0;
-            for (int e = 0; e < n_new; e++) {
-                const int kind = (int)recd[SPG_OUT_HDR + 4 * e + 0];
-                const int64_t rel = (int64_t)recd[SPG_OUT_HDR + 4 * e + 1];
-                const int32_t len = (int32_t)recd[SPG_OUT_HDR + 4 * e + 2];
-                const int nv = (int)recd[SPG_OUT_HDR + 4 * e + 3];
-                int32_t vix[2] = {sl.verts[(int)recd[SPG_OUT_HDR + 4 * sl.n_new_max + vpos]], sl.verts[(int)recd[SPG_OUT_HDR + 4 * sl.n_new_max + vpos + 1]]};
-                vpos += nv;
-                add_edge_idx(g, kind, 2, vix, sl.new_off + rel, len, key0 + e);
+            if (!emulate) {
+                // compact record: endpoint pairs as 4-bit local indices, edge e in byte e of words [6] / [7]; records of `rec` doubles back to back
+                uint64_t w[2];
+                memcpy(w, recd + 6, 16);
+                for (int e = 0; e < n_new; e++) {
+                    const unsigned pr = (unsigned)(w[e >> 3] >> (8 * (e & 7))) & 0xffu;
+                    int32_t vix[2] = {sl.verts[pr & 15u], sl.verts[pr >> 4]};
+                    add_edge_idx(g, SPG_EDGE_BINARY, 2, vix, sl.new_off + (int64_t)e * rec, rec, key0 + e);
+                }
+            } else {
+                int vpos = 0;
+                for (int e = 0; e < n_new; e++) {
+                    const int kind = (int)recd[SPG_OUT_HDR + 4 * e + 0];
+                    const int64_t rel = (int64_t)recd[SPG_OUT_HDR + 4 * e + 1];
+                    const int32_t len = (int32_t)recd[SPG_OUT_HDR + 4 * e + 2];
+                    const int nv = (int)recd[SPG_OUT_HDR + 4 * e + 3];
+                    int32_t vix[2] = {sl.verts[(int)recd[SPG_OUT_HDR + 4 * sl.n_new_max + vpos]], sl.verts[(int)recd[SPG_OUT_HDR + 4 * sl.n_new_max + vpos + 1]]};
+                    vpos += nv;
+                    add_edge_idx(g, kind, 2, vix, sl.new_off + rel, len, key0 + e);
+                }
             }
             g->stats.n_new_edges += n_new;
         }
@@ -2259,7 +2264,7 @@ struct Streamer {
                 const double tagd = (double)g->sslots[s].tag;
                 if (w[i] == 4503599627370496.0 + tagd || w[i] == 4503599627370496.0 + 4294967296.0 + tagd) {
                     const double *c = port.h_mail + (size_t)(q & mask) * (size_t)port.mail_stride;
-                    for (int l = 8; l < 40; l += 8) __builtin_prefetch((const void *)(c + l));
+                    (void)c;
                     __builtin_prefetch(&g->sslots[s]); __builtin_prefetch((const char *)&g->sslots[s] + 64); __builtin_prefetch((const char *)&g->sslots[s] + 128);
                     ready.push_back(s);
                     cell_slot[q & mask] = -2;
@@ -2333,226 +2338,117 @@ struct Streamer {
         return 0;
     }
 
-    // ---- two host threads (the default on the HIP backend; SPG_STREAM_THREADS=1 keeps everything on one): this one — the
-    // graph thread — commits and selects; the I/O thread writes packets and doorbells through the BAR, polls the mailbox and
-    // hands the out records over in a ring of ordinary memory. What they share: slots (written by the graph thread before it
-    // publishes the slot id, read-only from then until the commit), the immutable parts of vertices and edge records, and
-    // the two rings below, every index on a cache line of its own.
-    struct IoShared {
-        static constexpr uint32_t LQ = 4096, RQ = 2048, RSTRIDE = 88;   // launch ring (slot ids); result ring (entries of RSTRIDE doubles: slot, final flag, out record)
-        alignas(64) std::atomic<uint32_t> l_tail{0};     // graph thread: slot ids published
-        alignas(64) std::atomic<uint32_t> l_head{0};     // I/O thread: slot ids taken
-        alignas(64) std::atomic<uint32_t> r_tail{0};     // I/O thread: results published
-        alignas(64) std::atomic<uint32_t> r_head{0};     // graph thread: results taken
+    // ---- poll helper (on by default for lists of 4096 entries or more; SPG_STREAM_THREADS=1 switches it off): a second host thread does nothing but watch the
+    // mailbox and copy each record that has arrived — one cache line — into a ring of ordinary memory, so that the graph
+    // thread reads results from the neighbouring core's cache instead of taking a miss on device-written memory per poll.
+    // It touches no graph data: all it needs is the number of launches so far and the tag each cell will show.
+    struct Helper {
+        static constexpr uint32_t RQ = 4096;
+        alignas(64) std::atomic<uint32_t> launches{0};   // graph thread: cells [0, launches) have been handed out (their tags are in cell_tag)
+        alignas(64) std::atomic<uint32_t> r_tail{0};     // helper: results published
         alignas(64) std::atomic<int> stop{0};
-        alignas(64) std::atomic<int> error{0};
-        alignas(64) uint32_t l_head_local = 0;            // graph thread's private write index of lq
-        int32_t lq[LQ];
-        std::vector<double> rq;                           // RQ * RSTRIDE doubles
-        long doorbells = 0;
+        alignas(64) uint32_t r_head = 0;                  // graph thread
+        std::vector<double> rq;                           // RQ entries of 8 doubles: the compact record, word [5] = 2 * launch number + final flag
+        std::vector<uint32_t> cell_tag;
         char pad_[64];
-    } io;
-    bool threaded = false;
-    std::thread io_thread;
+    } hp;
+    bool helper = false;
+    std::thread helper_thread;
+    std::vector<const double *> ready_rec;               // helper mode: ring entry of each slot in g->s_ready
 
-    void io_main() {
-        std::vector<int32_t> fifo;
-        size_t head = 0;
-        unsigned n_polls = 0;
-        int bell_pending = 0;
-        uint32_t l_head = 0, r_tail = 0;
+    void helper_main() {
+        const uint32_t mask = (uint32_t)(port.slots - 1);
+        std::vector<uint8_t> pend((size_t)port.slots, 0);
+        uint32_t head = 0, seen = 0, r_tail = 0;
+        unsigned n = 0;
         const double READY = 4503599627370496.0, FINAL = 4503599627370496.0 + 4294967296.0;
-        uint64_t last_progress = ticks_now();
-        for (;;) {
-            // ---- hand-overs: every slot id the graph thread has published
-            const uint32_t lt = io.l_tail.load(std::memory_order_acquire);
-            while (l_head != lt) {
-                const int32_t s = io.lq[l_head++ & (IoShared::LQ - 1)];
-                build_packet(s, bell_pending);
-                bell_pending++;
-                fifo.push_back(s);
-            }
-            if (bell_pending) {
-                io.l_head.store(l_head, std::memory_order_release);
-                std::atomic_thread_fence(std::memory_order_release);
-#if defined(__x86_64__)
-                __builtin_ia32_sfence();
-#endif
-                port.tail += (unsigned long long)bell_pending;
-                for (int c = 0; c < port.bells; c++) port.q->tail[c * spg::kBellStride] = port.tail;
-#if defined(__x86_64__)
-                __builtin_ia32_sfence();
-#endif
-                bell_pending = 0;
-                io.doorbells++;
-            }
-            // ---- results: ready (or final) words among the oldest blankets in flight, copied into the result ring
-            while (head < fifo.size() && fifo[head] < 0) head++;
-            const int giveup = (++n_polls & 15) ? 10 : 256;
-            int seen = 0, misses = 0;
+        while (!hp.stop.load(std::memory_order_acquire)) {
+            const uint32_t lp = hp.launches.load(std::memory_order_acquire);
+            while (seen != lp) { pend[seen & mask] = 1; seen++; }
+            while (head != seen && !pend[head & mask]) head++;
+            const int giveup = (++n & 15) ? 10 : 1 << 20;
+            int misses = 0;
             bool got = false;
-            for (size_t i = head; i < fifo.size() && seen < 256 && misses < giveup; i++) {
-                const int32_t s = fifo[i];
-                if (s < 0) continue;
-                seen++;
-                const volatile double *c = cell(s);
-                const double w = c[5], tagd = (double)g->sslots[s].tag;
-                if (w == READY + tagd || w == FINAL + tagd) {
-                    const int nm = g->sslots[s].n_new_max, olen = SPG_OUT_LEN(nm, 2 * nm);
-                    double *e = io.rq.data() + (size_t)(r_tail & (IoShared::RQ - 1)) * IoShared::RSTRIDE;
-                    // (the ring has a cell per slot: it cannot be full)
-                    e[0] = (double)s; e[1] = (w == FINAL + tagd) ? 1.0 : 0.0;
-                    memcpy(e + 2, (const double *)c, sizeof(double) * (size_t)olen);
-                    r_tail++;
-                    fifo[i] = -1;
-                    misses = 0;
-                    got = true;
-                } else misses++;
+            for (uint32_t q0 = head; q0 != seen && misses < giveup;) {
+                const uint32_t nq = std::min<uint32_t>(16, seen - q0);
+                double w[16];
+                for (uint32_t i = 0; i < nq; i++) w[i] = ((const volatile double *)(port.h_mail + (size_t)((q0 + i) & mask) * (size_t)port.mail_stride))[5];
+                for (uint32_t i = 0; i < nq; i++) {
+                    const uint32_t q = q0 + i;
+                    if (!pend[q & mask]) continue;
+                    const double tagd = (double)hp.cell_tag[q & mask];
+                    if (w[i] == READY + tagd || w[i] == FINAL + tagd) {
+                        double *e = hp.rq.data() + (size_t)(r_tail & (Helper::RQ - 1)) * 8;
+                        memcpy(e, port.h_mail + (size_t)(q & mask) * (size_t)port.mail_stride, 64);
+                        e[5] = (double)(2.0 * (double)q + (w[i] == FINAL + tagd ? 1.0 : 0.0));
+                        r_tail++;
+                        pend[q & mask] = 0;
+                        misses = 0;
+                        got = true;
+                    } else misses++;
+                }
+                q0 += nq;
             }
-            if (got) { io.r_tail.store(r_tail, std::memory_order_release); last_progress = ticks_now(); }
-            if (head > 4096 && head * 2 > fifo.size()) { fifo.erase(fifo.begin(), fifo.begin() + (long)head); head = 0; }
-            if (io.stop.load(std::memory_order_acquire) && l_head == io.l_tail.load(std::memory_order_acquire)) {
-                bool live = false;
-                for (size_t i = head; i < fifo.size(); i++) live |= fifo[i] >= 0;
-                if (!live) break;
-            }
-            if (!got && lt == l_head && head < fifo.size() && ((ticks_now() - last_progress) >> 35) != 0) { io.error.store(1); break; }   // ~10 s without a result
+            if (got) hp.r_tail.store(r_tail, std::memory_order_release);
         }
     }
-
-    int run_threaded() {
-        const uint64_t t_begin = ticks_now();
-        const double s_begin = now_s();
-        uint64_t idle_since = 0;
-        std::vector<int32_t> &woken = g->s_woken, &fin = g->s_fin;
-        size_t fin_head = 0;
-        io.rq.resize((size_t)IoShared::RQ * IoShared::RSTRIDE);
-        threaded = true;
-        io_thread = std::thread([this] { io_main(); });
+    void take_helper_results() {
+        const uint32_t rt = hp.r_tail.load(std::memory_order_acquire);
+        const uint32_t mask = (uint32_t)(port.slots - 1);
+        ready_rec.clear();
+        while (hp.r_head != rt) {
+            const double *e = hp.rq.data() + (size_t)(hp.r_head & (Helper::RQ - 1)) * 8;
+            __builtin_prefetch(e + 8); __builtin_prefetch(e + 16);
+            const uint32_t q = (uint32_t)((uint64_t)e[5] >> 1);
+            const int32_t s = cell_slot[q & mask];
+            g->s_ready.push_back(s);
+            ready_rec.push_back(e);
+            cell_slot[q & mask] = -2;
+            __builtin_prefetch(&g->sslots[s]); __builtin_prefetch((const char *)&g->sslots[s] + 64); __builtin_prefetch((const char *)&g->sslots[s] + 128);
+            hp.r_head++;
+        }
+    }
+    // The helper is only used when it can sit on a core that shares an L3 with this thread's (cores of a group of 8 do on
+    // the hosts this runs on) and both can be pinned for the duration of the call: across L3s the ring costs more than the
+    // polls it saves. Returns false (nothing started) otherwise.
+    bool helper_start() {
 #if defined(__linux__)
-        // both threads on one L3: the slot lines one writes and the other reads, and the result ring, move through the shared
-        // cache. Best effort: the graph thread stays where it is for the duration of the call, the I/O thread goes next to it
-        // (cores of a group of 8 share an L3 on the hosts this runs on).
-        cpu_set_t old_mask;
-        bool repin = false;
         static const bool pin = [] { const char *e = getenv("SPG_PIN_THREADS"); return !(e && e[0] == '0'); }();
-        if (pin && sched_getaffinity(0, sizeof old_mask, &old_mask) == 0) {
-            const int cpu = sched_getcpu();
-            if (cpu >= 0) {
-                for (int d = 1; d < 8; d++) {
-                    const int cand = (cpu & ~7) | ((cpu + d) & 7);
-                    if (cand < CPU_SETSIZE && CPU_ISSET(cand, &old_mask)) {
-                        cpu_set_t one; CPU_ZERO(&one); CPU_SET(cand, &one);
-                        (void)pthread_setaffinity_np(io_thread.native_handle(), sizeof one, &one);
-                        CPU_ZERO(&one); CPU_SET(cpu, &one);
-                        repin = sched_setaffinity(0, sizeof one, &one) == 0;
-                        break;
-                    }
-                }
-            }
+        if (!pin || sched_getaffinity(0, sizeof old_mask, &old_mask) != 0) return false;
+        const int cpu = sched_getcpu();
+        int cand = -1;
+        for (int d = 1; cpu >= 0 && d < 8 && cand < 0; d++) {
+            const int c = (cpu & ~7) | ((cpu + d) & 7);
+            if (c < CPU_SETSIZE && CPU_ISSET(c, &old_mask)) cand = c;
         }
+        if (cand < 0) return false;
+        cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpu, &one);
+        if (sched_setaffinity(0, sizeof one, &one) != 0) return false;
+        repin = true;
+        hp.rq.resize((size_t)Helper::RQ * 8);
+        hp.cell_tag.assign((size_t)port.slots, 0);
+        helper = true;
+        helper_thread = std::thread([this] { helper_main(); });
+        CPU_ZERO(&one); CPU_SET(cand, &one);
+        (void)pthread_setaffinity_np(helper_thread.native_handle(), sizeof one, &one);
+        return true;
+#else
+        return false;
 #endif
-        uint32_t r_head = 0, l_pub = 0;
-        auto publish = [&]() {
-            if (io.l_head_local != l_pub) { l_pub = io.l_head_local; io.l_tail.store(l_pub, std::memory_order_release); bell_no++; }
-        };
-        int err = 0;
-        for (;;) {
-            const uint32_t rt = io.r_tail.load(std::memory_order_acquire);
-            const bool got = rt != r_head;
-            if (got && idle_since) { t_idle += ticks_now() - idle_since; idle_since = 0; }
-            while (r_head != rt) {
-                const double *e = io.rq.data() + (size_t)(r_head & (IoShared::RQ - 1)) * IoShared::RSTRIDE;
-                __builtin_prefetch(e + IoShared::RSTRIDE); __builtin_prefetch(e + IoShared::RSTRIDE + 8);
-                const int32_t s = (int32_t)e[0];
-                P0();
-                commit(s, e + 2, e[1] != 0.0);
-                P1(1);
-                r_head++;
-                if (!fallback) {
-                    for (size_t wi = 0; wi < woken.size(); wi++) examine(woken[wi]);
-                    if (io.l_head_local - l_pub >= 4) publish();
-                }
-                woken.clear();
-            }
-            if (got) io.r_head.store(r_head, std::memory_order_release);
-            // late results, in bulk (see run())
-            if (fin.size() - fin_head >= 192 || g->s_free.size() < 256 || (cap_wait >= 0 && fin_head < fin.size())) {
-                P0();
-                const size_t n = std::min<size_t>(64, fin.size() - fin_head);
-                for (size_t i = 0; i < n; i++) __builtin_prefetch((const void *)cell(fin[fin_head + i]));
-                for (size_t i = 0; i < n; i++) {
-                    const int32_t s = fin[fin_head];
-                    const volatile double *c = cell(s);
-                    if (c[5] != 4503599627370496.0 + 4294967296.0 + (double)g->sslots[s].tag) break;
-                    harvest(s, (const double *)c);
-                    fin_head++;
-                }
-                if (fin_head > 8192) { fin.erase(fin.begin(), fin.begin() + (long)fin_head); fin_head = 0; }
-                P1(6);
-                if (!woken.empty()) {
-                    if (!fallback) for (size_t wi = 0; wi < woken.size(); wi++) examine(woken[wi]);
-                    woken.clear();
-                }
-            }
-            if (!fallback && cursor < P) {
-                int budget = got ? 4 : 32;
-                while (cursor < P && budget-- > 0 && !fallback) {
-                    examine(cursor++);
-                    if (!woken.empty()) { for (size_t wi = 0; wi < woken.size() && !fallback; wi++) examine(woken[wi]); woken.clear(); }
-                }
-            }
-            publish();
-            if (n_done == P) break;
-            if (fallback && n_inflight == 0) break;
-            if (io.error.load(std::memory_order_relaxed)) { err = SPG_EHIP; break; }
-            if (got || cursor < P) continue;
-            if (!idle_since) idle_since = ticks_now();
-            if (n_inflight == 0 && fin_head == fin.size()) { fallback = true; break; }   // (cannot happen: see run())
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
-        io.stop.store(1, std::memory_order_release);
-        io_thread.join();
-        threaded = false;
+    }
+    void helper_stop() {
+        if (!helper) return;
+        hp.stop.store(1, std::memory_order_release);
+        helper_thread.join();
+        helper = false;
 #if defined(__linux__)
         if (repin) (void)sched_setaffinity(0, sizeof old_mask, &old_mask);
 #endif
-        g->stats.n_batches += (int32_t)io.doorbells;
-        if (err || io.error.load()) { set_err(g->ctx, SPG_EHIP, "streaming driver: no blanket completed within 10 s"); return SPG_EHIP; }
-        // drain the final words
-        {
-            const double t0 = now_s();
-            for (; fin_head < fin.size(); fin_head++) {
-                const int32_t s = fin[fin_head];
-                const volatile double *c = cell(s);
-                uint32_t spins = 0;
-                while (c[5] != 4503599627370496.0 + 4294967296.0 + (double)g->sslots[s].tag) {
-                    if ((++spins & 0xfff) == 0 && now_s() - t0 > 10.0) { set_err(g->ctx, SPG_EHIP, "streaming driver: a blanket's KLD tail did not complete within 10 s"); return SPG_EHIP; }
-#if defined(__x86_64__)
-                    __builtin_ia32_pause();
-#endif
-                }
-                harvest(s, (const double *)c);
-            }
-            woken.clear();
-        }
-        fin.clear();
-        if (idle_since) { t_idle += ticks_now() - idle_since; idle_since = 0; }
-        const uint64_t t_end = ticks_now();
-        const double secs = now_s() - s_begin;
-        const double idle = (t_end > t_begin) ? secs * (double)t_idle / (double)(t_end - t_begin) : 0.0;
-        g->stats.device_seconds += idle;
-        g->stats.host_seconds += secs - idle;
-        g->stats.schedule_seconds += secs - idle;
-        if (prof) {
-            const char *nm[8] = {"poll", "commit", "examine: parked", "examine: launch decision", "packet", "doorbell", "late results", "launch tail"};
-            const double tps = (double)(t_end - t_begin) / secs;
-            for (int i = 0; i < 8; i++) fprintf(stderr, "stream prof %-26s %8llu x %8.1f ns = %8.3f ms\n", nm[i], (unsigned long long)pn[i], pn[i] ? 1e9 * (double)pt[i] / tps / (double)pn[i] : 0.0, 1e3 * (double)pt[i] / tps);
-        }
-        return 0;
     }
+#if defined(__linux__)
+    cpu_set_t old_mask;
+    bool repin = false;
+#endif
 
     int run() {
         const uint64_t t_begin = ticks_now();
@@ -2566,7 +2462,9 @@ struct Streamer {
             ready.clear();
             P0();
             if (emulate) { if ((rc = poll_emulated()) != 0) return rc; }
-            else if (n_inflight) poll_hip((++n_polls & 15) ? 10 : 1 << 20);
+            else if (n_inflight) {
+                if (helper) take_helper_results(); else poll_hip((++n_polls & 15) ? 10 : 1 << 20);
+            }
             P1(0);
             const bool got = !ready.empty();
             if (got && idle_since) { t_idle += ticks_now() - idle_since; idle_since = 0; }
@@ -2575,8 +2473,8 @@ struct Streamer {
             // only parks it again
             for (size_t ri = 0; ri < ready.size(); ri++) {
                 const int32_t s = ready[ri];
-                const double *recd = emulate ? g->host.data() + g->sslots[s].out_off : cell(s);
-                const bool fin_now = emulate || recd[5] == 4503599627370496.0 + 4294967296.0 + (double)g->sslots[s].tag;
+                const double *recd = emulate ? g->host.data() + g->sslots[s].out_off : (helper ? ready_rec[ri] : cell(s));
+                const bool fin_now = emulate || (helper ? (((uint64_t)recd[5]) & 1) != 0 : recd[5] == 4503599627370496.0 + 4294967296.0 + (double)g->sslots[s].tag);
                 P0();
                 commit(s, recd, fin_now);
                 P1(1);
@@ -2709,17 +2607,13 @@ static int stream_marginalize(spg_graph *g) {
     S.rng = 0x9E3779B97F4A7C15ULL ^ ((uint64_t)(g->stream_emulation > 0 ? g->stream_emulation : 1) * 0xD1B54A32D192ED03ULL);
     const int64_t used0 = g->used;
     if (!emulate) S.cell_slot.assign((size_t)S.port.slots, -1);
-    static const bool one_thread = [] { const char *e = getenv("SPG_STREAM_THREADS"); return !(e && e[0] == '2'); }();   // (two threads: measured slower)
-    // (the edge and log containers must not move while the I/O thread reads edge records: room for everything this call can add)
-    bool two = !emulate && !one_thread;
-    if (two) {
-        const size_t need_e = g->edges.size() + (size_t)P * 4 + 1024, need_l = g->log.size() + (size_t)P + 16;
-        if (g->edges.capacity() < need_e) g->edges.reserve(need_e);
-        if (g->log.capacity() < need_l) g->log.reserve(need_l);
-        S.edge_cap = g->edges.capacity();
-    }
+    // second host thread that only polls the mailbox (SPG_STREAM_THREADS=1: none); the simulated port of tools/host_sim.cpp
+    // gets one only on request (=2): its "device" is a thread as well
+    static const int want_helper = [] { const char *e = getenv("SPG_STREAM_THREADS"); return e ? atoi(e) : 0; }();
+    if (!emulate && (want_helper == 2 || (want_helper == 0 && !sim)) && P >= 4096) (void)S.helper_start();
     const double t_setup = now_s();
-    const int rc = two ? S.run_threaded() : S.run();
+    const int rc = S.run();
+    S.helper_stop();
     const double t_ran = now_s();
     if (sim) sim->tail = S.port.tail;
     else if (!emulate) spg::hip_stream_close(&g->ctx->be, &S.port, S.alg_bytes, (long long)S.n_done);

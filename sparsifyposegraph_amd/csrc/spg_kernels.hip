@@ -238,8 +238,21 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             T.sync();   // recbuf is complete
             const int nrec = n_new * REC;
             for (int it = tid; it < nrec; it += NT) strec<true>(arena + bd.new_off + it, recbuf[it]);
+            // compact out record (streaming driver, flags bit 20): ONE cache line — the six header words, then the new edges'
+            // endpoint pairs as local vertex indices, 4 bits each, edge e in byte e of words [6] (e < 8) and [7]; the edge
+            // table is implied (pose-pose records of REC doubles, back to back at new_off). The host polls, reads and later
+            // re-reads (KLD, final word) a single line per blanket instead of five.
+            const bool compact = (a.flags >> 20) & 1;
             if (tid == 0) {
                 orl[0] = (double)status; orl[1] = (double)info; orl[2] = kld; orl[3] = min_gap; orl[4] = (double)n_new; orl[5] = 0.0;
+                if (compact) {
+                    unsigned long long w0 = 0, w1 = 0;
+                    for (int e = 0; e < n_new; e++) {
+                        const unsigned long long pr = (unsigned long long)((m + pairs[2 * e]) & 15) | ((unsigned long long)((m + pairs[2 * e + 1]) & 15) << 4);
+                        if (e < 8) w0 |= pr << (8 * e); else w1 |= pr << (8 * (e - 8));
+                    }
+                    orl[6] = __longlong_as_double((long long)w0); orl[7] = __longlong_as_double((long long)w1);
+                } else
                 for (int e = 0; e < n_new; e++) {
                     orl[SPG_OUT_HDR + 4 * e + 0] = (double)SPG_EDGE_BINARY;
                     orl[SPG_OUT_HDR + 4 * e + 1] = (double)(e * REC);
@@ -251,7 +264,7 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
             }
             wait_stores();   // this lane's record stores have been acknowledged
             T.sync();        // ... everybody's; orl is complete
-            const int olen = SPG_OUT_HDR + 4 * bd.n_new_max + 2 * n_new;
+            const int olen = compact ? 8 : SPG_OUT_HDR + 4 * bd.n_new_max + 2 * n_new;
             if (tid < 64) {   // (wave 0; olen <= 42 for the blankets a worker takes)
                 for (int t = tid; t < olen; t += 64) if (t != 5) strec<true>(orec + t, orl[t]);
                 wait_stores();   // wave 0's stores are out before its lane 0 raises the ready word

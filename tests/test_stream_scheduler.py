@@ -88,3 +88,43 @@ def test_stream_then_more_calls_keep_edge_order(ictx):
     st = hg.marginalizeNoOptimize(second, opts)
     assert st["n_bad_status"] == 0
     assert util.compare_edge_sets(6, og.edges(), hg.edges(), rtol=0.0) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------- on the GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", ["1", "0"])
+def test_gpu_stream_equals_batch_driver_and_oracle(threads, hip_ctx, monkeypatch):
+    """The product on the MI355X: the streaming driver (persistent worker fed one blanket at a time; with and without the
+    poll helper thread) against (a) the batch driver on the same device — bit for bit, since both sum a blanket's edges in
+    key order and the kernels are the same — and (b) the strictly sequential oracle to the north star's 1e-9."""
+    monkeypatch.setenv("SPG_STREAM_THREADS", threads)
+    g = g2o_io.synth_sphere(n_poses=20000, ring=200)
+    which = np.array([i for i in range(4, 20000) if i % 2], np.int32)
+    opts = abi.make_options(6)
+    a = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+    sa = a.marginalizeNoOptimize(which, opts)
+    b = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+    b.set_stream_emulation(-2)   # never stream: the batch driver
+    sb = b.marginalizeNoOptimize(which, opts)
+    assert sa["n_removed"] == sb["n_removed"] == len(which) and sa["n_bad_status"] == sb["n_bad_status"] == 0
+    assert sa["n_batches"] > 4 * sb["n_batches"]            # (it did stream: thousands of doorbells against ~200 batches)
+    assert util.compare_edge_sets(6, b.edges(), a.edges(), rtol=0.0) == 0.0
+    assert sa["kld_sum"] == pytest.approx(sb["kld_sum"], rel=1e-13)
+    og = oracle_lib.OracleGraph.from_dict(g)
+    assert og.marginalize(which, opts) == 0
+    util.compare_edge_sets(6, og.edges(), a.edges(), rtol=util.RTOL)
+    kref = float(np.nansum(og.blankets()["kld"]))
+    assert abs(kref - sa["kld_sum"]) <= util.RTOL * max(1.0, abs(kref))
+
+
+@pytest.mark.gpu
+def test_gpu_stream_hands_over_on_large_blankets(hip_ctx):
+    """parking.g2o (hubs with twenty neighbours): the stream takes what the worker takes, the batch driver the rest; the
+    result is the fixture's whatever the split."""
+    g, which, opts, gold_edges, gold_bl, gold_vids = util.load_golden("parking_full_nfr_tree")
+    hg = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+    st = hg.marginalizeNoOptimize(np.asarray(which, np.int32), opts)
+    assert st["n_bad_status"] == 0 and st["n_removed"] == len(which)
+    ids, _ = hg.vertices()
+    assert np.array_equal(ids, gold_vids)
+    util.compare_edge_sets(6, gold_edges, hg.edges(), rtol=util.RTOL)

@@ -70,7 +70,15 @@ struct Sim {
             if (f == g_table.end()) { fprintf(stderr, "host_sim: no recorded result for root pose offset %lld\n", (long long)key); abort(); }
             const Rec &r = f->second;
             memcpy(arena + (int64_t)pk[4], r.recs.data(), r.recs.size() * 8);
-            for (size_t i = 0; i < r.out.size(); i++) if (i != 5) cell[i] = r.out[i];
+            // the worker's compact record (flags bit 20): six header words + the endpoint pairs as 4-bit local indices
+            const int n_new = (int)r.out[4], n_new_max = (int)((pk[7] >> 32) & 0xffffffffu);
+            unsigned long long w[2] = {0, 0};
+            for (int e = 0; e < n_new; e++) {
+                const unsigned long long pr = (unsigned long long)((int)r.out[SPG_OUT_HDR + 4 * n_new_max + 2 * e] & 15) | ((unsigned long long)((int)r.out[SPG_OUT_HDR + 4 * n_new_max + 2 * e + 1] & 15) << 4);
+                w[e >> 3] |= pr << (8 * (e & 7));
+            }
+            for (int i = 0; i < 5; i++) cell[i] = r.out[i];
+            memcpy(cell + 6, w, 16);
             std::atomic_thread_fence(std::memory_order_release);
             ((volatile double *)cell)[5] = SPG_READY_WORD(tag);
         } else {
@@ -134,7 +142,7 @@ int main(int argc, char **argv) {
     // ---- replay through the streaming driver against the simulated worker
     Sim sim;
     sim.latency = lat; sim.final_lag = flag;
-    const int slots = 2048, stride = 80;
+    const int slots = 2048, stride = 8;
     static spg::WorkQ wq;
     memset(&wq, 0, sizeof wq);
     std::vector<unsigned long long> pkt((size_t)slots * spg::kPktWords);
