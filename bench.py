@@ -7,11 +7,14 @@ conflict-free rounds + the per-blanket HIP kernel + graph update. Inputs (poses 
 resident in HBM before the timed region starts; per batch only int descriptors go up and the
 per-blanket output records come back.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path partitions by graph — the reference's own
-parallelism is one whole job per thread (src/evaluate.cpp:413-433) — so every rank sparsifies ITS OWN 100k-pose graph
-(same generator, rank-dependent seed), no data-path collective, `value` = nodes all ranks removed / max-over-ranks
-time, "scaling": "weak". The one-graph-on-N-GPUs view (replicas, batches sharded + RCCL all-gather when the cost model
-says it pays: never on this workload, whose rounds are ~200 blankets deep-chained) is reported under `multi_gpu`.
+N > 1 (launched by torch.distributed.run, one rank per GPU): `value` is the ONE-graph figure the north star names — the
+same 100k-pose graph replicated on every rank, marginalised through spg_graph_marginalize_ranks with the library's own
+policy and its built-in RCCL all-gather (spg_ctx_create_ranks). On this workload the policy never exchanges: its batches
+are ~200 independent blankets, each a 40 us dependent chain however they are split, so every rank computes the whole
+graph (its own streaming driver) and the figure is FLAT in N by design ("scaling": "strong"). What N GPUs do buy —
+N graphs at once, the reference's own job-level parallelism (src/evaluate.cpp:413-433) — is reported as
+`multi_gpu.independent_graphs`; `multi_gpu.wide_rounds` is a graph whose batches ARE wide enough to be sharded
+(~50 000 blankets each) and drives the RCCL exchange, with the ranks the communicator saw.
 
 `--config parking`: BASELINE config 4 (parking.g2o, NFR Tree, sparsity 2; graph from tests/golden) with the same
 contract; at N > 1 the ranks share one replicated graph and the line carries `exchanged_batches` / bytes all-gathered.
@@ -105,6 +108,7 @@ def main():
     from sparsifyposegraph_amd.parallel import marginalize_sharded
 
     ctx = Context(local_rank)  # raises without a gfx950 device: no CPU fallback
+
     if numa_note and os.environ.get("SPG_BENCH_PIN_CORE", "0") == "1":
         # optional (measured inconclusive on shared hosts, hence off): the runtime's helper threads exist now and
         # keep the whole node; the graph thread itself stays on one core of it (rank-dependent)
@@ -119,8 +123,8 @@ def main():
         g, which, *_ = _util.load_golden("parking_full_nfr_tree")
         which = np.asarray(which, np.int32)
     else:
-        # N > 1: one graph per rank (weak scaling), same generator, rank-dependent noise seed
-        g = g2o_io.synth_sphere(n_poses=args.poses, ring=args.ring, seed=20240611 + rank)
+        # N > 1: the SAME graph on every rank (replicas of one graph)
+        g = g2o_io.synth_sphere(n_poses=args.poses, ring=args.ring)
         last = int(g["ids"][-1])
         which = np.array(globalDecimate(last, last, DecimateOptions(args.sparsity)), np.int32)
     opts = abi.make_options(6, abi.ALG_NFR, abi.TOPO_TREE, abi.LIN_GLOBAL if args.lin_point == "global" else abi.LIN_LOCAL)
@@ -133,12 +137,17 @@ def main():
         hg.reserve(arena_need)  # uploads poses + edge records: resident in HBM before timing
         replicas.append(hg)
 
-    shared_graph = world > 1 and args.config == "parking"   # one replicated graph, sharded by the library's policy
+    shared_graph = world > 1   # one replicated graph, the library's policy decides what is sharded + exchanged
+
+    def run_on(hg, w, builtin=False):
+        if world == 1:
+            return hg.marginalizeNoOptimize(w, opts)
+        if builtin:   # the library's own RCCL communicator (context from spg_ctx_create_ranks)
+            return hg.marginalize_ranks(w, opts, rank, world)
+        return marginalize_sharded(hg, w, opts, device=device)   # exchange (if the policy ever asks for one) through torch.distributed
 
     def run(hg):
-        if shared_graph:
-            return marginalize_sharded(hg, which, opts, device=device)
-        return hg.marginalizeNoOptimize(which, opts)
+        return run_on(hg, which)
 
     def fence():
         ctx.synchronize()
@@ -168,7 +177,27 @@ def main():
     # N > 1 only, outside the timed region of `value`: the one-graph views, each guarded so that a failure costs a
     # field, not the bench line.
     multi = {}
+    extras_guard = None
     if world > 1 and args.config == "synthetic":
+        # The extra run below drives RCCL inside the library across GPUs — a path no one-GPU box can rehearse. If it hangs,
+        # the headline measured above must not be lost with it: after 5 minutes rank 0 prints the line without the extra
+        # and every rank leaves.
+        import threading
+
+        def _bail():
+            if rank == 0:
+                removed0 = stats["n_removed"]
+                print(json.dumps({"metric": "nodes_marginalized_per_s", "value": removed0 * args.steps / dt, "unit": "nodes/s", "n_gpus": world,
+                                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True,
+                                  "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                                  "config": {"workload": f"synthetic SE3 sphere-spiral pose graph, {args.poses} poses, NFR Tree, globalDecimate sparsity {args.sparsity}, one replicated graph on {world} GPUs",
+                                             "note": "multi_gpu.wide_rounds did not finish within 300 s and was abandoned; roofline / cpu_baseline are N = 1 fields"},
+                                  "multi_gpu": {"wide_rounds": {"error": "timeout after 300 s (RCCL inside the library across GPUs: never rehearsed, one-GPU boxes)"}}}), flush=True)
+            os._exit(0)
+        extras_guard = threading.Timer(300.0, _bail)
+        extras_guard.daemon = True
+        extras_guard.start()
+
         def timed(fn, reps):
             fence()
             t1 = time.perf_counter()
@@ -180,39 +209,46 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item()), res
         try:
-            # (1) ONE 100k-pose graph replicated on all ranks, the library's default sharding policy (cost model): its
-            #     rounds are ~200 blankets, so nothing is worth an exchange and every rank computes everything
-            g0 = g2o_io.synth_sphere(n_poses=args.poses, ring=args.ring)
-            reps = [GraphWrapperHIP.from_dict(g0, ctx=ctx) for _ in range(2)]
-            for hg in reps:
-                hg.reserve(arena_need)
-            it = iter(reps)
-            secs, st1 = timed(lambda: marginalize_sharded(next(it), which, opts, device=device), len(reps))
-            multi["one_graph_replicated"] = {"value": st1["n_removed"] * len(reps) / secs, "unit": "nodes/s", "scaling": "strong",
-                                             "exchanged_batches": st1["n_exchanged"], "batches": st1["n_batches"],
-                                             "what": "the same single graph on every rank; batches sharded + all-gathered only when the cost model says it pays"}
-        except Exception as e:
-            multi["one_graph_replicated"] = {"error": str(e)[:200]}
-        try:
             # (2) a graph whose rounds are wide (2 rings of 100 000 poses: ~50k independent blankets per
             #     batch), so that every batch IS sharded over the ranks and all-gathered (RCCL over xGMI)
+            # ... through the library's OWN communicator (spg_ctx_create_ranks: ncclCommInitRank inside libspg_hip.so, rank 0's
+            # unique id handed round through torch's store), falling back to torch's all-gather behind the exchange callback
+            ctx2, rccl_note = ctx, None
+            if not rehearse:
+                from sparsifyposegraph_amd.lib import get_unique_id
+                try:
+                    store = dist.distributed_c10d._get_default_store()
+                    if rank == 0:
+                        store.set("spg_unique_id", get_unique_id())
+                    ctx2 = Context.ranks(local_rank, rank, world, bytes(store.get("spg_unique_id")))
+                except Exception as e:
+                    rccl_note = f"spg_ctx_create_ranks failed ({str(e)[:120]}): exchange through torch.distributed instead"
+            builtin = ctx2 is not ctx
             gw = g2o_io.synth_sphere(n_poses=200000, ring=100000)
             ww = np.array([i for i in range(4, 200000) if i % 2], np.int32)
-            hw = [GraphWrapperHIP.from_dict(gw, ctx=ctx) for _ in range(2)]
+            hw = [GraphWrapperHIP.from_dict(gw, ctx=ctx2) for _ in range(2)]
             for hg in hw:
                 hg.reserve(int(len(gw["ids"]) * 7 + len(gw["edge_ij"]) * 28) * 3)
             itw = iter(hw)
-            secs, stw = timed(lambda: marginalize_sharded(next(itw), ww, opts, device=device), len(hw))
+            secs, stw = timed(lambda: run_on(next(itw), ww, builtin), len(hw))
             multi["wide_rounds"] = {"value": stw["n_removed"] * len(hw) / secs, "unit": "nodes/s", "scaling": "strong",
                                     "removed": stw["n_removed"], "batches": stw["n_batches"], "exchanged_batches": stw["n_exchanged"],
                                     "exchanged_bytes": stw["exchanged_bytes"], "exchange_seconds": stw["exchange_seconds"], "kld_sum": stw["kld_sum"],
+                                    "ranks_seen_by_rccl": ctx2.nranks() if builtin else None,
+                                    "exchange": "library: spg_ctx_create_ranks + in-place ncclAllGather" if builtin else "torch.distributed all_gather_into_tensor behind the exchange callback", "note": rccl_note,
                                     "what": "synthetic SE3 graph of 2 rings x 100 000 poses: batches of ~50k blankets sharded over the ranks + one all-gather each"}
         except Exception as e:
             multi["wide_rounds"] = {"error": str(e)[:200]}
 
+    if extras_guard is not None:
+        extras_guard.cancel()
     removed = stats["n_removed"]
-    weak = world > 1 and not shared_graph
-    value = (world if weak else 1) * removed * args.steps / dt
+    weak = False
+    value = removed * args.steps / dt
+    if world > 1:
+        multi["independent_graphs"] = {"value": world * value, "unit": "nodes/s", "scaling": "weak",
+                                       "what": f"in the timed region every rank marginalised a whole replica by itself (nothing was exchanged: exchanged_batches = {stats['n_exchanged']}), "
+                                               f"i.e. {world} graphs of this size were sparsified in the time of one: the job-level parallelism of the reference (src/evaluate.cpp:413-433)"}
     out = {
         "metric": "nodes_marginalized_per_s", "value": value, "unit": "nodes/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
@@ -223,8 +259,9 @@ def main():
                          else f"parking.g2o SE3, {len(g['ids'])} poses, ") +
                         f"{len(g['edge_ij'])} edges, NFR Tree, " + ("Global linearisation point = stored estimates, " if args.lin_point == "global" else "Local linearisation point (10 LM iterations per blanket), ") +
                         f"globalDecimate sparsity {args.sparsity} ({len(which)} removals), marginalizeNoOptimize only",
-            "parallelism": "single GPU" if world == 1 else (f"one graph per GPU ({world} independent graphs, no collective)" if weak else
-                           f"one replicated graph on {world} GPUs; a batch is sharded + all-gathered (RCCL) when the cost model says it pays, otherwise computed by every rank"),
+            "parallelism": "single GPU" if world == 1 else
+                           f"one replicated graph on {world} GPUs; a batch is sharded + all-gathered (RCCL) when the cost model says it pays, otherwise computed by every rank "
+                           "(this workload: never - the figure is flat in N by design, see multi_gpu)",
             "exchanged_batches": stats["n_exchanged"], "exchanged_bytes": stats["exchanged_bytes"], "exchange_seconds": stats["exchange_seconds"],
             "rounds": stats["n_rounds"], "removed": removed, "max_blanket": stats["max_blanket"],
             "kld_sum": stats["kld_sum"], "host_seconds_per_step": stats["host_seconds"], "device_wait_seconds_per_step": stats["device_seconds"],
@@ -238,10 +275,10 @@ def main():
     # its duration (HIP events on its stream) includes the time its workgroups wait for the host's next batch.
     traffic, traffic_note = None, None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
         if world == 1 and args.config == "synthetic" and args.poses == 100000 and args.ring == 400:
             traffic = pm["traffic_bytes_per_launch"]
-            traffic_note = ("NOT measured in this run: from the committed rocprofv3 --pmc passes of this same command (profiles/r02_pmc_summary.json: "
+            traffic_note = ("NOT measured in this run: from the committed rocprofv3 --pmc passes of this same command (profiles/r03_pmc_summary.json: "
                             "FETCH_SIZE + WRITE_SIZE of the worker kernel, separate passes, per launch)")
     except Exception:
         pass
@@ -302,7 +339,7 @@ def main():
         # the arithmetic, the blankets of a round spread over the host cores this process may use
         try:
             import time as _time
-            cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+            cores = max(1, len(os.sched_getaffinity(0)))   # every core this process may use
             ictx = oracle_lib.injected_context(threads=cores)
             from sparsifyposegraph_amd.graph import GraphWrapperHIP as _GW
             hg = _GW.from_dict(gs, ctx=ictx)

@@ -967,7 +967,9 @@ template <int D>
 void launch_glc_jacobians(const GraphBufs &gb, hipStream_t s) {
     if (!gb.has_glc) return;
     size_t sh = (size_t)gb.max_q * (2 * D * D + D) * sizeof(double);
-    if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(glc_weighted_jacobian_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    // (a launch whose dynamic LDS exceeds what the attribute allows is rejected: the error surfaces at the caller's
+    //  hipGetLastError / stream synchronisation as SPG_EHIP, never as a fault)
+    if (sh > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(glc_weighted_jacobian_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return;
     hipLaunchKernelGGL((glc_weighted_jacobian_kernel<D>), dim3(gb.dev.ne), dim3(64), sh, s, gb.dev);
 }
 

@@ -311,6 +311,7 @@ struct spg_graph {
     };
     std::vector<SSlot> sslots;
     std::vector<int32_t> s_free, s_fifo, s_fin, s_woken, s_ready, wl_next, wl_stable, wl_done;
+    bool layout_diverged = false;                     // the graph has streamed on one of several ranks: its arena layout is rank-specific, never shard it again
     int stream_emulation = -1;                        // tests (spg_graph_set_stream_emulation): >= 0 = completion-order seed
     int stream_disabled = 0;                          // SPG_STREAM=0 or spg_graph_set_stream_emulation(g, -2)
 };
@@ -385,7 +386,12 @@ extern "C" int spg_ctx_nranks(const spg_ctx *c) { return c ? c->nranks : 0; }
 
 extern "C" int spg_allgather_region(spg_ctx *c, void *arena, int64_t region_off, int64_t chunk_len) {
     if (!c || !arena || region_off < 0 || chunk_len < 0) return SPG_EINVAL;
-    if (!c->rccl) return 0;
+    if (!c->rccl) {
+        // a multi-rank context without a communicator cannot exchange: committing un-gathered chunks would silently
+        // diverge the replicas (single-rank contexts: nothing to do)
+        if (c->nranks > 1) return set_err(c, SPG_ESTATE, "spg_allgather_region: the context has %s ranks but no RCCL communicator (spg_ctx_create_ranks without a unique id)", std::to_string(c->nranks).c_str());
+        return 0;
+    }
     return spg::rccl_allgather_f64(c->rccl, arena, region_off, chunk_len, spg::hip_backend_stream(&c->be), c->err, sizeof c->err);
 }
 
@@ -743,7 +749,7 @@ extern "C" int spg_graph_load_g2o(spg_ctx *ctx, const char *path, spg_graph **ou
     int d = 0;
     char *lbuf = nullptr;   // getline: a Dense GLC edge is one line of r*n numbers, far beyond any fixed buffer
     size_t lcap = 0;
-    bool bad_glc = false;
+    bool bad_glc = false, has_multi = false;
     while (getline(&lbuf, &lcap, f) >= 0) {
         char *s = lbuf;
         while (*s == ' ' || *s == '\t') s++;
@@ -836,10 +842,16 @@ extern "C" int spg_graph_load_g2o(spg_ctx *ctx, const char *path, spg_graph **ou
                 ge.W.swap(W2);
             }
             ges.push_back(std::move(ge));
+        } else if (!strncmp(tag, "MULTI_EDGE_", 11)) {
+            // MultiEdgeCorrelated::write (src/multi_edge_correlated.hpp:227-267) does not say which vertex pair each
+            // measurement belongs to — the reference's own read() cannot restore the edge either. Dropping the line would
+            // hand back a graph without its correlated constraints (possibly disconnected) and no error: refuse the file.
+            has_multi = true;
         }
     }
     free(lbuf);
     fclose(f);
+    if (has_multi) return set_err(ctx, SPG_EIO, "%s holds MULTI_EDGE_* records: that format omits the vertex pair of each measurement and cannot be read back", path);
     if (bad_glc) return set_err(ctx, SPG_EIO, "malformed GLC_EDGE record in %s", path);
     if (!d) return set_err(ctx, SPG_EIO, "no SE2/SE3 vertices in %s", path);
     std::stable_sort(vs.begin(), vs.end(), [](const V &a, const V &b) { return a.id < b.id; });
@@ -2573,8 +2585,9 @@ struct Streamer {
 // Runs the removal list of the open marginalisation (spg_graph_marginalize_begin) through the streaming driver.
 // Returns 0 = list exhausted, 1 = the rest of the list (g->pending from g->pend_head) is left to the batch driver
 // (a blanket the persistent worker does not take, arena full, or no streaming on this backend), < 0 error.
-static int stream_marginalize(spg_graph *g) {
+static int stream_marginalize(spg_graph *g, bool *started = nullptr) {
     const spg_options &o = g->opts;
+    if (started) *started = false;
     static const bool env_off = [] { const char *e = getenv("SPG_STREAM"); return e && e[0] == '0'; }();
     spg::StreamPort *const sim = g->ctx->is_hip ? nullptr : g->ctx->sim_port;
     const bool emulate = !g->ctx->is_hip && !sim;
@@ -2606,6 +2619,7 @@ static int stream_marginalize(spg_graph *g) {
     if ((int64_t)g->host.size() < g->cap) g->host.resize((size_t)g->cap);
     S.rng = 0x9E3779B97F4A7C15ULL ^ ((uint64_t)(g->stream_emulation > 0 ? g->stream_emulation : 1) * 0xD1B54A32D192ED03ULL);
     const int64_t used0 = g->used;
+    if (started) *started = true;
     if (!emulate) S.cell_slot.assign((size_t)S.port.slots, -1);
     // second host thread that only polls the mailbox (SPG_STREAM_THREADS=1: none); the simulated port of tools/host_sim.cpp
     // gets one only on request (=2): its "device" is a thread as well
@@ -2683,6 +2697,36 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
     // whatever it leaves (rc 1: blankets the worker does not take) goes through the batch driver below
     int stream_rc = 1;
     if (nranks == 1 && !exchange) stream_rc = stream_marginalize(g);
+    else if (nranks > 1) {
+        // Several ranks, one replicated graph. A batch is worth sharding + one all-gather only when it is wide (shard_pays);
+        // lists whose batches are narrow — the 100k-pose lattice: ~200 independent blankets at a time — are computed whole by
+        // every rank with nothing exchanged, and then nothing ties the ranks to the same batches either: each rank may run
+        // its own streaming driver. Results do not depend on the schedule (blanket edges are summed in key order), so the
+        // replicas stay equal in content; their arena LAYOUTS diverge (records are placed in launch order), and regions are
+        // exchanged by offset — so a graph that has streamed on several ranks never shards again (layout_diverged).
+        // The decision is taken on the first pass of the batch scheduler, identically on every rank.
+        bool independent = g->layout_diverged;
+        if (!independent && g->shard_threshold < 0) {
+            const std::vector<int32_t> saved = g->pending;
+            g->B = &g->bt[0];
+            schedule_round(g);
+            independent = !g->bt[0].rb.empty() && !shard_pays(g, g->bt[0]);
+            release_batch_owners(g, g->bt[0]);
+            g->bt[0].rb.clear(); g->bt[0].rb_verts.clear(); g->bt[0].rb_edges.clear();
+            for (int32_t oid : g->transient) owner_release(g, oid);
+            g->transient.clear();
+            g->pending = saved;
+            g->pend_head = 0;
+        }
+        if (independent) {
+            const int rank0 = g->rank, nranks0 = g->nranks;
+            g->rank = 0; g->nranks = 1;
+            bool started = false;
+            stream_rc = stream_marginalize(g, &started);
+            if (started || g->layout_diverged) g->layout_diverged = true;   // (and the batch driver below, if it gets the rest, runs without sharding)
+            else { g->rank = rank0; g->nranks = nranks0; }
+        }
+    }
     if (stream_rc <= 0) {
         const double t_streamed = now_s();
         int rc2 = spg_graph_marginalize_end(g, stats);
@@ -3374,7 +3418,11 @@ static int optimize_with_fixed(spg_graph *g, int iterations, const std::vector<i
 extern "C" int spg_sparse_plan(int n, const int32_t *ptr, const int32_t *adj, int pose_dim, const uint8_t *is_marg, int leaf,
                                spg_sparse_plan_info *info, int32_t *perm, int32_t *sn_first, int32_t *sn_parent, int32_t *sn_level,
                                int32_t *sn_rowptr, int32_t *rows, int32_t *rel, int64_t rows_cap) {
-    if (n < 0 || !ptr || (!adj && n > 0 && ptr[n] > 0) || (pose_dim != 3 && pose_dim != 6) || !info) return SPG_EINVAL;
+    if (n < 0 || !ptr || (pose_dim != 3 && pose_dim != 6) || !info) return SPG_EINVAL;
+    // the row pointers come from the caller: 0-based, non-decreasing, non-negative total — before anything is read through them
+    if (ptr[0] != 0) return SPG_EINVAL;
+    for (int i = 0; i < n; i++) if (ptr[i + 1] < ptr[i]) return SPG_EINVAL;
+    if (!adj && ptr[n] > 0) return SPG_EINVAL;
     spg::sparse::BlockGraph bg;
     bg.n = n;
     bg.ptr.assign(ptr, ptr + n + 1);

@@ -2173,6 +2173,10 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     // ---- interior-point NFR blankets
     if (!ip_list.empty()) {
         if (int rc2 = hb->ensure(S, &S.d_ipws, &S.c_ipws, (size_t)ip_stride * 8 * ip_list.size())) return rc2;
+        // The workspace is reused from launch to launch and from graph to graph: cleared, so that what a blanket finds in its
+        // slice never depends on what ran before it in the process (a run of several graphs through one context died with a
+        // core dump in round 2 where each graph on its own passes; hipMalloc'ed memory is not zeroed either).
+        HIPCHK(hipMemsetAsync(S.d_ipws, 0, (size_t)ip_stride * 8 * ip_list.size(), S.stream));
         spg::IpArgs ia{};
         ia.arena = (double *)arena; ia.blk = ka.blk; ia.vpo = ka.vpo; ia.er = ka.er; ia.ev = ka.ev;
         ia.list = (const int32_t *)(desc_base + o_list) + list_off;

@@ -140,6 +140,17 @@ class GraphWrapperHIP:
         check(rc, self.ctx.h, "spg_graph_marginalize")
         return self.last_stats
 
+    def marginalize_ranks(self, which, options, rank, nranks, flags=0):
+        """spg_graph_marginalize_ranks with the library's built-in exchange (the context's RCCL communicator,
+        Context.ranks): every rank calls this with identical arguments on an identical replica."""
+        which = np.ascontiguousarray(which, np.int32)
+        o = options.to_abi(self.d, self.useGLC, flags) if isinstance(options, SparsityOptions) else options
+        st = abi.MargStats()
+        rc = self.L.spg_graph_marginalize_ranks(self.h, _p(which, C.c_int32), len(which), C.byref(o), int(rank), int(nranks), None, None, C.byref(st))
+        self.last_stats = st.asdict()
+        check(rc, self.ctx.h, "spg_graph_marginalize_ranks")
+        return self.last_stats
+
     def marginalize(self, which, options, flags=0):
         """src/graph_wrapper_g2o.cpp:455-463: marginalizeNoOptimize followed by optimize() (dense LM up to 12 k
         variables, the block-sparse multifrontal solver beyond: `last_optimize_stats["solver"]`)."""

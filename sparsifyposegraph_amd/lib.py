@@ -130,6 +130,15 @@ def check(rc, ctx=None, what=""):
     return rc
 
 
+def get_unique_id():
+    """spg_get_unique_id: the 128 bytes that identify an RCCL communicator (rank 0 calls this, every rank gets the bytes)."""
+    buf = C.create_string_buffer(128)
+    rc = load().spg_get_unique_id(buf)
+    if rc != 0:
+        raise SpgError(f"spg_get_unique_id failed with code {rc}")
+    return bytes(buf.raw)
+
+
 class Context:
     """spg_ctx: one per (host thread, device). Raises if no gfx950 device is available."""
 
@@ -145,6 +154,21 @@ class Context:
             raise SpgError(f"spg_ctx_create(device={device}) failed with code {rc}: no usable gfx950 device "
                            "(the product path has no CPU fallback)")
         self.h = h
+
+    @classmethod
+    def ranks(cls, device, rank, nranks, unique_id):
+        """spg_ctx_create_ranks (include/spg.h): one process per GPU, RCCL communicator inside the library; `unique_id` =
+        the bytes rank 0 got from get_unique_id(), handed to every rank out of band. Collective over the ranks."""
+        L = load()
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+        rc = L.spg_ctx_create_ranks(C.byref(h), int(device), int(rank), int(nranks), buf)
+        if rc != 0:
+            raise SpgError(f"spg_ctx_create_ranks(device={device}, rank={rank}/{nranks}) failed with code {rc}")
+        return cls(_handle=h)
+
+    def nranks(self):
+        return int(self.L.spg_ctx_nranks(self.h))
 
     @classmethod
     def injected(cls, backend, keep=None):

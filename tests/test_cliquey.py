@@ -164,6 +164,12 @@ def test_host_path_with_correlated_edges(case, d, tmp_path):
         q, nm, nrel = bar - 1, int(t[bar + 1]), int(t[bar + 2])
         r = d * nm
         assert nrel == ps and nm == q - 1 and len(t) == bar + 3 + nm * ps + r * (r + 1) // 2
+    # ... and such a file is REFUSED on load (the format omits which vertex pair a measurement belongs to: silently dropping
+    # the lines would hand back a graph without its correlated constraints)
+    path = tmp_path / "cliquey.g2o"
+    path.write_text(hg.writeString())
+    with pytest.raises(SpgError, match="MULTI_EDGE"):
+        GraphWrapperHIP.load(str(path), ctx=oracle_lib.injected_context())
     # clonePortion keeps the correlated edges whose vertices survive the cut
     top = int(max(hg.vertices()[0]))
     clone = hg.clonePortion(top, optimize=False)     # (optimize() is a device path)
@@ -218,3 +224,33 @@ def test_device_reproduces_correlated_fixtures(case, hip_ctx):
     worst = util.compare_edge_sets(g["pose_dim"], gold_edges, hg.edges(), rtol=1e-9)
     assert abs(st["kld_sum"] - float(np.nansum(gold_bl["kld"]))) <= 1e-9 * max(1.0, abs(float(np.nansum(gold_bl["kld"]))))
     print(f"{case}: {int((gold_edges['kind'] == abi.EDGE_MULTI).sum())} correlated edges, worst rel err {worst:.1e}")
+
+
+@pytest.mark.gpu
+def test_device_parking_full_cliquey_dense_then_global_kld(hip_ctx):
+    """The sequence that ended in a core dump once in round 2 (several graphs through one context, then parking.g2o at full
+    size under CliqueyDense, then the global KLD of the result, whose correlated edges hold up to ~170 measurements). Run
+    here in that order on ONE context: a CliqueyDense prefix first (it leaves its data in the context's reused workspaces,
+    which are cleared per launch since), then parking. Every call has to come back with a result or an SPG_E* code.
+    parking.g2o has blankets whose target is rank deficient beyond the gauge (chooseDimensions, src/logdet_function.cpp:40-59):
+    one edge carrying such a target makes the sparsified information matrix singular, which the global KLD reports as
+    SPG_ENOTPD (-9) — the reference's LDLT-based kullbackLeiblerDivergence (src/utils.cpp:70-97) has no value there either.
+    When it does return a number, CliqueyDense must leave the KLD at zero."""
+    from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    from sparsifyposegraph_amd.lib import SpgError
+    g0, which0, opts0, *_ = util.load_golden("manhattan_cliquey_dense")
+    warm = GraphWrapperHIP.from_dict(g0, ctx=hip_ctx)
+    assert warm.marginalizeNoOptimize(which0, opts0)["n_bad_status"] == 0
+    g, which, opts, *_ = util.load_golden("parking_full_nfr_tree")
+    o = _opts(6, abi.TOPO_CLIQUEY_DENSE, 1.0)
+    hg = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+    base = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+    st = hg.marginalizeNoOptimize(which, o)
+    assert st["n_bad_status"] == 0 and st["n_removed"] == len(which)
+    e = hg.edges()
+    assert set(np.unique(e["kind"]).tolist()) <= {abi.EDGE_BINARY, abi.EDGE_MULTI}
+    try:
+        kld = base.kullbackLeibler(hg)
+        assert abs(kld) <= 1e-6 * len(g["ids"])
+    except SpgError as ex:
+        assert "code -9" in str(ex), str(ex)

