@@ -113,10 +113,16 @@ struct EvaluateResult {
 };
 
 // src/evaluate.cpp:32-221. gw holds the FULL graph (ids 0..last). write_files = false keeps everything in memory.
+// RESTRICTION (a deviation from the reference, which takes any GraphWrapper): the source graph must be a GraphWrapperHIP.
+// Everything else in the loop goes through the abstract interface; computeSubstituteEdge (src/compute_substitute_edge.cpp:
+// 13-96) does not — it is one C-ABI call (spg_graph_substitute_edge: breadth-first search to the nearest surviving vertex,
+// composition of the measurements along the path, sum of the covariances) on the library's own graph object instead of a
+// walk over vertex(id)->edges() with Eigen inverses, which this Eigen-free header does not carry. A caller with another
+// backend gets a std::runtime_error here, before anything is computed.
 inline EvaluateResult evaluate(GraphWrapper *gw, const EvaluateInfo &info, bool write_files = true) {
     EvaluateResult res;
     GraphWrapperHIP *source = dynamic_cast<GraphWrapperHIP *>(gw);
-    if (!source) throw std::runtime_error("evaluate: computeSubstituteEdge needs a GraphWrapperHIP source graph");
+    if (!source) throw std::runtime_error("evaluate: computeSubstituteEdge needs a GraphWrapperHIP source graph (see the note above evaluate() in spg_evaluate.hpp)");
     std::unique_ptr<GraphWrapper> incremental(gw->clonePortion(3)), baseline(gw->clonePortion(3));
     const bool is2d = gw->vertex(1)->is2d();
     const bool sparsify = info.algorithm != EvaluateInfo::None;

@@ -30,6 +30,7 @@
 #include <pthread.h>
 #include <sched.h>
 #endif
+#include <unistd.h>
 #include <unordered_map>
 #include <vector>
 #include "../../include/spg.h"
@@ -311,6 +312,7 @@ struct spg_graph {
     };
     std::vector<SSlot> sslots;
     std::vector<int32_t> s_free, s_fifo, s_fin, s_woken, s_ready, wl_next, wl_stable, wl_done;
+    int64_t unsorted_from = -1;                       // edges[unsorted_from ..) were appended in commit order by the streaming driver: see canonicalize_edge_order
     bool layout_diverged = false;                     // the graph has streamed on one of several ranks: its arena layout is rank-specific, never shard it again
     int stream_emulation = -1;                        // tests (spg_graph_set_stream_emulation): >= 0 = completion-order seed
     int stream_disabled = 0;                          // SPG_STREAM=0 or spg_graph_set_stream_emulation(g, -2)
@@ -326,7 +328,44 @@ static int set_err(spg_ctx *c, int code, const char *fmt, const char *a = "") {
 }
 
 // ================================================================================= context
+// SPG_SEGV_BACKTRACE=1 (diagnostic): a SIGSEGV inside the process prints the native frames (addresses relative to the
+// load address of this library, for addr2line on a -g build) before the default action runs.
+#if defined(__linux__)
+#include <execinfo.h>
+#include <signal.h>
+#include <dlfcn.h>
+static void spg_segv_handler(int sig) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    Dl_info di;
+    const char *base = nullptr;
+    if (dladdr((void *)&spg_segv_handler, &di)) base = (const char *)di.dli_fbase;
+    char line[160];
+    int len = snprintf(line, sizeof line, "spg: signal %d; frames relative to libspg_hip.so (base %p):\n", sig, (const void *)base);
+    if (write(2, line, (size_t)len) < 0) {}
+    for (int i = 0; i < n; i++) {
+        Dl_info fi;
+        const bool ours = dladdr(frames[i], &fi) && fi.dli_fbase == (void *)base;
+        len = snprintf(line, sizeof line, "  #%d %s0x%llx\n", i, ours ? "+" : "abs ", (unsigned long long)(ours ? (const char *)frames[i] - base : (const char *)frames[i] - (const char *)0));
+        if (write(2, line, (size_t)len) < 0) {}
+    }
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static void spg_install_segv_trace() {
+    static bool done = false;
+    const char *e = getenv("SPG_SEGV_BACKTRACE");
+    if (done || !(e && e[0] == '1')) return;
+    done = true;
+    signal(SIGSEGV, spg_segv_handler);
+    signal(SIGABRT, spg_segv_handler);
+}
+#else
+static void spg_install_segv_trace() {}
+#endif
+
 extern "C" int spg_ctx_create(spg_ctx **out, int device) {
+    spg_install_segv_trace();
     if (!out) return SPG_EINVAL;
     spg_ctx *c = new spg_ctx;
     int rc = spg::hip_backend_create(device, &c->be, c->err, sizeof c->err);
@@ -643,6 +682,43 @@ extern "C" int spg_graph_add_edges(spg_graph *g, int n, const int32_t *ij, const
 extern "C" int spg_graph_pose_dim(const spg_graph *g) { return g ? g->d : 0; }
 extern "C" int spg_graph_num_vertices(const spg_graph *g) { return g ? g->n_live_v : 0; }
 extern "C" int spg_graph_num_edges(const spg_graph *g) { return g ? g->n_live_e : 0; }
+// The streaming driver appends new edges in the order their blankets happen to complete, which varies from run to run.
+// Results never depend on it (blanket edges are summed in key order), but everything that EXPOSES the edge array's order
+// does: spg_graph_get_edges / the .g2o writer / clones, and the dense assembly, which sums a vertex's incident edges in
+// array order. Before any of those the tail the stream appended is put into key order — the order the sequential loop
+// would have inserted the edges in — so that two runs on the same input hand out byte-identical graphs. Lazy: it costs
+// ~3 ms on the 100k-pose graph and a marginalisation that is only followed by another one never pays it.
+static void next_stamp(spg_graph *g);
+static void canonicalize_edge_order(spg_graph *g) {
+    if (g->unsorted_from < 0 || g->active) return;
+    const size_t from = (size_t)g->unsorted_from, n = g->edges.size() - from;
+    g->unsorted_from = -1;
+    if (n < 2) return;
+    std::vector<uint32_t> perm(n);
+    for (size_t i = 0; i < n; i++) perm[i] = (uint32_t)i;
+    bool sorted = true;
+    for (size_t i = 1; i < n && sorted; i++) sorted = g->edges[from + i - 1].key <= g->edges[from + i].key;
+    if (sorted) return;
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return g->edges[from + a].key < g->edges[from + b].key; });
+    std::vector<int32_t> newid(n);
+    std::vector<GEdge> tmp(n);
+    for (size_t i = 0; i < n; i++) { tmp[i] = g->edges[from + perm[i]]; newid[perm[i]] = (int32_t)(from + i); }
+    std::copy(tmp.begin(), tmp.end(), g->edges.begin() + (long)from);
+    next_stamp(g);
+    const int32_t st = g->stamp;
+    for (size_t i = 0; i < n; i++) {
+        const GEdge &e = g->edges[from + i];
+        if (!e.alive) continue;
+        for (int t = 0; t < e.nv; t++) {
+            const int32_t v = edge_verts(g, e)[t];
+            if (g->vstamp[v] == st) continue;
+            g->vstamp[v] = st;
+            for (auto &a : g->vr[v].adj) if ((size_t)a.eid >= from) a.eid = newid[(size_t)a.eid - from];
+        }
+    }
+    g->n_mutations++;
+}
+
 extern "C" int64_t spg_graph_edge_data_size(const spg_graph *g) {
     int64_t s = 0;
     for (auto &e : g->edges) if (e.alive) s += e.len;
@@ -669,6 +745,7 @@ extern "C" int spg_graph_get_vertices(spg_graph *g, int32_t *ids, double *poses)
 
 extern "C" int spg_graph_get_edges(spg_graph *g, int32_t *kind, int32_t *vert_off, int32_t *vert_ids, int64_t *data_off, double *data) {
     if (!g) return SPG_EINVAL;
+    canonicalize_edge_order(g);
     if (int rc = sync_host(g)) return rc;
     int ne = 0, nv = 0;
     int64_t nd = 0;
@@ -888,6 +965,7 @@ extern "C" int spg_graph_write_g2o_mem(spg_graph *g, char **text, size_t *len) {
     return 0;
 }
 static void write_g2o_stream(spg_graph *g, FILE *f) {
+    canonicalize_edge_order(g);
     std::vector<std::pair<int32_t, int32_t>> order;
     for (size_t i = 0; i < g->vid.size(); i++) if (g->valive[i]) order.push_back({g->vid[i], (int32_t)i});
     std::sort(order.begin(), order.end());
@@ -933,6 +1011,7 @@ static void write_g2o_stream(spg_graph *g, FILE *f) {
 // GraphWrapperG2O::clonePortion (src/graph_wrapper_g2o.cpp:334-356)
 extern "C" int spg_graph_clone_portion(spg_graph *g, int maxid, spg_graph **out) {
     if (!g || !out || g->active) return SPG_EINVAL;
+    canonicalize_edge_order(g);
     if (int rc = sync_host(g)) return rc;
     spg_graph *c;
     if (int rc = spg_graph_create(g->ctx, g->d, &c)) return rc;
@@ -1723,6 +1802,9 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
         const int64_t base = bt.rinfo.region_off + bt.rinfo.chunk_len * bt.eff_rank;
         const double want = SPG_READY_WORD(bt.tag), want_final = SPG_FINAL_WORD(bt.tag);
         const double t_spin = now_s();
+        // (SPG_POLL_SPIN_S: tests set 0 to force the synchronisation path on ordinary batches)
+        const char *sl_env = getenv("SPG_POLL_SPIN_S");
+        const double spin_limit = sl_env ? atof(sl_env) : 5.0;
         polled = true;
         bool first_seen = false;
         for (const RoundBlanket &r : bt.rb) {
@@ -1730,7 +1812,7 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
             if (first_seen == false && &r != &bt.rb[0]) { g->tr_first += now_s() - bt.t_launch; first_seen = true; }
             uint32_t spins = 0;
             for (double fv = *flag; fv != want && fv != want_final; fv = *flag) {
-                if ((++spins & 0x3fff) == 0 && now_s() - t_spin > 5.0) { polled = false; break; }
+                if ((++spins & 0x3fff) == 0 && now_s() - t_spin > spin_limit) { polled = false; break; }
 #if defined(__x86_64__)
                 __builtin_ia32_pause();
 #endif
@@ -1742,6 +1824,17 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
     if (!polled) {
         rc = slotted ? g->ctx->be.synchronize_slot(g->ctx->be.user, bt.slot) : g->ctx->be.synchronize(g->ctx->be.user);
         if (rc) return rc;
+        if (mail && nr == 1) {
+            // the launch has completed: every record must carry this launch's tag now. One that does not was never written
+            // (a blanket no kernel took, a kernel that died): an error, never a graph update from whatever the cell held.
+            const int64_t base = bt.rinfo.region_off + bt.rinfo.chunk_len * bt.eff_rank;
+            const double want = SPG_READY_WORD(bt.tag), want_final = SPG_FINAL_WORD(bt.tag);
+            for (const RoundBlanket &r : bt.rb) {
+                const double fv = mail[(r.desc.out_off - base) + 5];
+                if (fv != want && fv != want_final)
+                    return set_err(g->ctx, SPG_EHIP, "the blanket of vertex %s did not deliver its out record although its launch has completed", std::to_string(g->vid[r.root]).c_str());
+            }
+        }
     }
     g->tr_n++; g->tr_wait += now_s() - t0; g->tr_age += t0 - bt.t_launch;
     // read back the out-record part of every rank chunk (mailbox: already in host memory)
@@ -1798,6 +1891,25 @@ extern "C" int spg_graph_round_commit(spg_graph *g) {
         }
         PT(9);
         int vpos = 0;
+        // (the record comes from the device: nothing in it is used as an index before it has been checked)
+        {
+            bool sane = n_new >= 0 && n_new <= bd.n_new_max;
+            int vsum = 0, why = sane ? 0 : 1;
+            double badv = 0;
+            for (int e = 0; sane && e < n_new; e++) {
+                const double nvd = rec[SPG_OUT_HDR + 4 * e + 3], reld = rec[SPG_OUT_HDR + 4 * e + 1], lend = rec[SPG_OUT_HDR + 4 * e + 2];
+                sane = nvd >= 1 && nvd <= r.nv && reld >= 0 && lend >= 1 && reld + lend <= (double)bd.new_len;
+                if (!sane) { why = 2; badv = (double)bd.new_len; }
+                if (sane) { for (int i = 0; i < (int)nvd && sane; i++) { const double li = rec[SPG_OUT_HDR + 4 * bd.n_new_max + vsum + i]; sane = li >= 0 && li < r.nv; if (!sane) { why = 3; badv = li + 1e-3 * i; } } vsum += (int)nvd; }
+                if (sane && vsum > bd.n_new_vert_max) { sane = false; why = 4; badv = bd.n_new_vert_max; }
+            }
+            if (!sane) {
+                char msg[256];
+                snprintf(msg, sizeof msg, "out record of the blanket of vertex %d is not well formed (status %d, %d new edges of at most %d, k + m = %d, m = %d; words %g %g %g %g %g %g | %g %g %g %g)", g->vid[r.root], status, n_new, bd.n_new_max, r.nv, r.n_remove,
+                         rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], rec[7], rec[8], rec[9]);
+                return set_err(g->ctx, SPG_EHIP, "%s", msg);
+            }
+        }
         for (int e = 0; e < n_new; e++) {
             int kind = (int)rec[SPG_OUT_HDR + 4 * e + 0];
             int64_t rel = (int64_t)rec[SPG_OUT_HDR + 4 * e + 1];
@@ -2040,12 +2152,16 @@ struct Streamer {
             const int k0 = nX - 1;
             if (k0 < 1 || D * k0 > spg::kWorkerMaxN) { fallback = true; return 0; }
             // (A)
+            int32_t blocker = -1;   // of several blockers the LAST list entry: it is the one that finishes last, as a rule, and a wake-up by any other only parks v again
             for (int i = 1; i < nX; i++) {
                 const int32_t c = cst[X[i]];
                 // (a DONE entry that is still in the graph kept a status that forbids the graph update: it is inert)
-                if (c >= 0 && (c & 3) != SV_DONE && ((c >> 2) < p || (c & 3) == SV_INFLIGHT)) {
+                if (c >= 0 && (c & 3) != SV_DONE && ((c >> 2) < p || (c & 3) == SV_INFLIGHT)) blocker = std::max(blocker, c >> 2);
+            }
+            {
+                if (blocker >= 0) {
                     n_park[0]++;
-                    park(g->wl_done, c >> 2, p);
+                    park(g->wl_done, blocker, p);
                     // first look at v (the list cursor runs well ahead of the results): pull what its launch will read — its
                     // neighbours' records and its edges' records, cold in DRAM until now — towards the shared cache
                     if (p >= prefetched_to) {
@@ -2083,15 +2199,19 @@ struct Streamer {
                 hs[nh++] = s;
             }
         }
-        for (int h = 0; h < nh; h++) {
-            const spg_graph::SSlot &o = slots[hs[h]];
-            if (o.pos > p) continue;
-            const int32_t *mem = o.npend >= 0 ? o.pend : o.verts + 1;
-            const int nmem = o.npend >= 0 ? o.npend : o.nv - 1;
-            for (int i = 0; i < nmem; i++) {
-                const int32_t c = cst[mem[i]];
-                if (c >= 0 && (c & 3) == SV_WAITING && (c >> 2) < p) { n_park[3]++; reserve(p, X, nX); park(g->wl_done, o.pos, p); return 0; }
+        {
+            int32_t blocker = -1;
+            for (int h = 0; h < nh; h++) {
+                const spg_graph::SSlot &o = slots[hs[h]];
+                if (o.pos > p) continue;
+                const int32_t *mem = o.npend >= 0 ? o.pend : o.verts + 1;
+                const int nmem = o.npend >= 0 ? o.npend : o.nv - 1;
+                for (int i = 0; i < nmem; i++) {
+                    const int32_t c = cst[mem[i]];
+                    if (c >= 0 && (c & 3) == SV_WAITING && (c >> 2) < p) { blocker = std::max(blocker, o.pos); break; }
+                }
             }
+            if (blocker >= 0) { n_park[3]++; reserve(p, X, nX); park(g->wl_done, blocker, p); return 0; }
         }
         // (B), entries without a final blanket, fused with markovBlanketEdges (src/vertex_remover.cpp:225-251): one pass over
         // the adjacency of X \ {v}; no edge record is read (the far endpoints are in the adjacency entries) and no
@@ -2620,6 +2740,7 @@ static int stream_marginalize(spg_graph *g, bool *started = nullptr) {
     S.rng = 0x9E3779B97F4A7C15ULL ^ ((uint64_t)(g->stream_emulation > 0 ? g->stream_emulation : 1) * 0xD1B54A32D192ED03ULL);
     const int64_t used0 = g->used;
     if (started) *started = true;
+    if (g->unsorted_from < 0) g->unsorted_from = (int64_t)g->edges.size();
     if (!emulate) S.cell_slot.assign((size_t)S.port.slots, -1);
     // second host thread that only polls the mailbox (SPG_STREAM_THREADS=1: none); the simulated port of tools/host_sim.cpp
     // gets one only on request (=2): its "device" is a thread as well
@@ -3197,6 +3318,7 @@ std::vector<int32_t> live_vertices_by_id(const spg_graph *g) {
 
 // st.pos must be filled (size = number of vertex slots, -1 = not a variable).
 void build_dense_stage(spg_graph *g, DenseStage &st) {
+    canonicalize_edge_order(g);
     const int nv = (int)g->vid.size();
     std::vector<int32_t> remap(g->edges.size(), -1);
     for (size_t e = 0; e < g->edges.size(); e++) {

@@ -2183,6 +2183,11 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         ia.ws = (double *)S.d_ipws; ia.ws_stride = ip_stride; ia.mail = mail_dev; ia.mail_base = rd->mail_base;
         ia.topology = o.topology; ia.lin_point = o.lin_point; ia.tag = rd->tag; ia.chord_ratio = o.chord_ratio;
         if (int rc2 = spg::hip_nfr_ip_launch((void *)S.stream, D, ia, (int)ip_list.size(), ip_hot)) { snprintf(err, sizeof hb->err, "launch of the interior-point kernel failed"); return rc2; }
+        // (this kernel comes AFTER the event a bin launch left in wait_ev: waiting for the slot must mean the whole stream.
+        //  Until round 3 wait_slot returned when the bin kernel was done — with a cluster of 150 vertices still running in
+        //  this one, the commit read whatever the mailbox held at its record's place: silently wrong graphs on parking.g2o
+        //  under CliqueyDense, and a segmentation fault when the stale words were not zeros.)
+        S.wait_ev = nullptr;
         S.stream_dirty = true;
         S.busy = true;
     }
@@ -2213,6 +2218,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         if (brc) return brc;
         hb->prof_big_ms += 1e3 * secs; hb->prof_big_flops += flops; hb->prof_big_count++;
         hb->prof_big_nmax = std::max(hb->prof_big_nmax, D * (k + m));
+        S.wait_ev = nullptr;   // (as above: the slot is done when the stream is)
         S.stream_dirty = true;
     }
     LP(3);

@@ -64,23 +64,30 @@ def test_evaluate_loop_on_the_oracle_alone():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("profile,alg", [("online", "nfr"), ("cluster", "nfr"), ("online", "glc"), ("cluster", "nfr-chi2"),
-                                         ("cluster", "nfr-local")])
-def test_replay_matches_oracle(profile, alg, hip_ctx):
+@pytest.mark.parametrize("profile,alg,nprefix", [("online", "nfr", 70), ("cluster", "nfr", 70), ("online", "glc", 70), ("cluster", "nfr-chi2", 70),
+                                                 ("cluster", "nfr-local", 70), ("online", "nfr", 300), ("cluster", "glc", 300)])
+def test_replay_matches_oracle(profile, alg, nprefix, hip_ctx):
+    """The reference's evaluate() loop (src/evaluate.cpp:32-221) on the product and on the oracle: the same .kld series.
+    Every point of the series is the output of two LM runs of up to 50 iterations (incremental and baseline graph) that end
+    on g2o's stall rule, so it is defined to the optimiser's tolerance: 1e-7 relative at the stored estimates, 1e-5 under the
+    Local linearisation point (10 more LM iterations per blanket: tests/test_local_conditioning.py). Two 300-vertex prefixes
+    (150 incremental optimisations each) beside the 70-vertex ones."""
     use_chi2 = alg.endswith("-chi2")
     local = alg.endswith("-local")    # the reference's default linearisation point (LM on the blankets)
     alg = alg.split("-")[0]
     g, which, opts, *_ = util.load_golden("manhattan_nfr_tree" if alg == "nfr" else "manhattan_glc_tree")
-    sub, _ = util.prefix_graph(g, which, 70)
+    sub, _ = util.prefix_graph(g, which, nprefix)
     dec = {"online": (onlineDecimate, DecimateOptions(2)), "cluster": (clusterDecimate, DecimateOptions(2, 10))}[profile]
     so = SparsityOptions(SparsityOptions.Tree, linPoint=SparsityOptions.Local if local else SparsityOptions.Global)
-    info = EvaluateInfo(dec[0], dec[1], so, alg, kldPeriod=10, useChi2=use_chi2)
+    info = EvaluateInfo(dec[0], dec[1], so, alg, kldPeriod=10 if nprefix <= 100 else 50, useChi2=use_chi2)
     full = GraphWrapperHIP.from_dict(sub, ctx=hip_ctx)     # computeSubstituteEdge walks the full graph (host side)
     got, inc_h, base_h = evaluate(sub, info, lambda glc: GraphWrapperHIP(ctx=hip_ctx, pose_dim=3, useGLC=glc), full)
     ref, inc_o, base_o = evaluate(sub, info, lambda glc: OracleWrapper(3, glc), full)
     assert [i for i, _ in got] == [i for i, _ in ref]
+    tol = 1e-5 if local else 1e-7
+    worst = max(abs(a - b) / max(abs(b), 1.0) for (_, a), (_, b) in zip(got, ref))
     for (i, a), (_, b) in zip(got, ref):
-        assert a == pytest.approx(b, rel=1e-5, abs=1e-6), (i, a, b)
+        assert a == pytest.approx(b, rel=tol, abs=tol), (i, a, b, worst)
     assert got[-1][1] > -1e-9    # (online removal of a just-added chain vertex is exact: KLD 0 is legitimate)
     assert np.array_equal(inc_h.vertices()[0], inc_o.g.vertices()[0])
-    print(profile, alg, [(i, round(k, 6)) for i, k in got])
+    print(profile, alg, nprefix, f"worst rel err of the series {worst:.1e}", [(i, round(k, 6)) for i, k in got][-4:])

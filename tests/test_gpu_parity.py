@@ -306,12 +306,21 @@ KLD_CASES = ["intel_nfr_tree_sp3", "sphere_nfr_tree", "parking_nfr_tree", "manha
              "manhattan_glc_dense"]
 
 
+@pytest.fixture(params=["dense", "sparse"])
+def kld_solver(request, hip_ctx):
+    want = abi.SOLVER_DENSE if request.param == "dense" else abi.SOLVER_SPARSE
+    hip_ctx.set_linear_solver(want)
+    yield want
+    hip_ctx.set_linear_solver(abi.SOLVER_AUTO)
+
+
 @pytest.mark.parametrize("case", KLD_CASES)
-def test_global_kld_matches_oracle(case, hip_ctx):
-    """baseline.kullbackLeibler(sparsified) on the device (dense assembly, blocked fp64-MFMA Cholesky,
-    triangular solve) vs the oracle's restatement of src/graph_wrapper_g2o.cpp:531-548 on a vertex
-    prefix: information matrices within 1e-9 relative, every term of the formula within 1e-9 of its
-    scale (the terms are O(n); the KLD is their small difference, so it is compared relative to n)."""
+def test_global_kld_matches_oracle(case, hip_ctx, kld_solver):
+    """baseline.kullbackLeibler(sparsified) on the device — dense (assembly, blocked fp64-MFMA Cholesky, triangular
+    solve) and block-sparse multifrontal (marginalised-first factorisation, selected inverse) — vs the oracle's
+    restatement of src/graph_wrapper_g2o.cpp:531-548 on a vertex prefix: information matrices within 1e-9 relative,
+    every term of the formula within 1e-9 of its scale (the terms are O(n); the KLD is their small difference, so it is
+    compared relative to n)."""
     g, which, opts, *_ = util.load_golden(case)
     sub, w = util.prefix_graph(g, which, 200)
     glc = opts.algorithm == abi.ALG_GLC
@@ -329,7 +338,7 @@ def test_global_kld_matches_oracle(case, hip_ctx):
     kld = hb.kullbackLeibler(ho)
     t, r = hb.last_kld_terms, ob.kullback_leibler(oo, fid)
     n = r["n"]
-    assert t["n"] == n and t["n_marginalized"] == Hb.shape[0] - n
+    assert t["n"] == n and t["n_marginalized"] == Hb.shape[0] - n and t["solver"] == kld_solver
     assert abs(t["mahalanobis"]) <= 1e-20 and abs(r["mahalanobis"]) <= 1e-20   # same estimates in both graphs
     assert abs(t["innerprod"] - r["innerprod"]) <= util.RTOL * n
     assert abs(t["logdetx"] - r["logdetx"]) <= util.RTOL * max(abs(r["logdetx"]), n)

@@ -74,13 +74,24 @@ def test_oracle_lm_recovers_noise_free_poses():
     assert np.abs(poses[:, 3:] * sign - g["poses"][:, 3:]).max() < 1e-9
 
 
+@pytest.fixture(params=["dense", "sparse"])
+def solver_ctx(request, hip_ctx):
+    """The context with its linear solver forced to the dense path or to the block-sparse multifrontal one (spg_ctx_set_linear_solver):
+    both meet the ORACLE directly, not only each other."""
+    hip_ctx.set_linear_solver(abi.SOLVER_DENSE if request.param == "dense" else abi.SOLVER_SPARSE)
+    yield hip_ctx, (abi.SOLVER_DENSE if request.param == "dense" else abi.SOLVER_SPARSE)
+    hip_ctx.set_linear_solver(abi.SOLVER_AUTO)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,n,glc", [("intel_nfr_tree_sp3", 200, False), ("sphere_nfr_tree", 150, False),
                                         ("manhattan_glc_tree", 200, True), ("sphere_glc_tree", 120, True)])
-def test_device_lm_matches_oracle(case, n, glc, hip_ctx):
+def test_device_lm_matches_oracle(case, n, glc, solver_ctx):
     """Same algorithm, same inputs: chi2 before/after within 1e-9 relative, final estimates within 1e-8,
-    on the perturbed baseline and on its sparsified graph (binary NFR edges or n-ary GLC edges)."""
+    on the perturbed baseline and on its sparsified graph (binary NFR edges or n-ary GLC edges) — with the dense
+    factorisation and with the block-sparse multifrontal one."""
     from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    hip_ctx, solver = solver_ctx
     sub, w, opts = _perturbed(case, n)
     fid = int(sub["ids"][0])
     d = sub["pose_dim"]
@@ -101,6 +112,7 @@ def test_device_lm_matches_oracle(case, n, glc, hip_ctx):
                     og.set_estimate(int(vid), sub["poses"][i])
         ref = og.optimize(50, fid)
         got = hg.optimize(50, fid)
+        assert got["solver"] == solver
         assert got["chi2_initial"] == pytest.approx(ref["chi2_initial"], rel=1e-9)
         assert got["chi2_final"] == pytest.approx(ref["chi2_final"], rel=1e-7, abs=1e-12)
         assert got["chi2_final"] < got["chi2_initial"]

@@ -90,6 +90,30 @@ def test_stream_then_more_calls_keep_edge_order(ictx):
     assert util.compare_edge_sets(6, og.edges(), hg.edges(), rtol=0.0) == 0.0
 
 
+def test_exposed_edge_order_does_not_depend_on_completion_order(ictx):
+    """The stream appends new edges in the order their blankets complete; whatever exposes the edge array (get_edges, the
+    .g2o writer, clones, the dense assembly) sees it in key order = the sequential loop's insertion order instead: two runs
+    with different completion orders hand out byte-identical arrays and files."""
+    g = g2o_io.synth_sphere(n_poses=2000, ring=50)
+    which = np.array([i for i in range(4, 2000) if i % 2], np.int32)
+    opts = abi.make_options(6)
+    outs = []
+    for seed in (1, 9):
+        hg = GraphWrapperHIP.from_dict(g, ctx=ictx)
+        hg.set_stream_emulation(seed)
+        hg.marginalizeNoOptimize(which, opts)
+        e = hg.edges()
+        outs.append((e["kind"].copy(), e["vert_ids"].copy(), e["data"].copy(), hg.writeString()))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert np.array_equal(a, b)
+    assert outs[0][3] == outs[1][3]
+    # ... and it is the sequential oracle's order
+    og = oracle_lib.OracleGraph.from_dict(g)
+    assert og.marginalize(which, opts) == 0
+    oe = og.edges()
+    assert np.array_equal(oe["vert_ids"], outs[0][1]) and np.array_equal(oe["data"], outs[0][2])
+
+
 # ------------------------------------------------------------------------------------------------- on the GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("threads", ["1", "0"])

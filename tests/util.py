@@ -139,9 +139,10 @@ def compare_digests(da, db, rtol=RTOL):
     return worst
 
 
-def first_round_batch(g, which, opts, limit=None):
+def first_round_batch(g, which, opts, limit=None, k_range=None):
     """Gather, in pure Python, the blankets of the removal-list vertices that touch no other list
-    vertex's blanket (a trivially independent set), as an spg_batch dict. Tree-type blankets only."""
+    vertex's blanket (a trivially independent set), as an spg_batch dict. Tree-type blankets only.
+    k_range = (lo, hi): only blankets with lo <= kept vertices <= hi."""
     d = g["pose_dim"]
     ids = g["ids"]
     idx = {int(v): i for i, v in enumerate(ids)}
@@ -160,6 +161,8 @@ def first_round_batch(g, which, opts, limit=None):
         for e in adj[v]:
             nb.update(int(x) for x in g["edge_ij"][e])
         if nb & used:
+            continue
+        if k_range is not None and not (k_range[0] <= len(nb) - 1 <= k_range[1]):
             continue
         used |= nb
         order = [v] + sorted(nb - {v})
