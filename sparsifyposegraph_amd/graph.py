@@ -77,6 +77,7 @@ class GraphWrapperHIP:
         self.h = _handle
         self.d = self.L.spg_graph_pose_dim(self.h)
         self.last_stats = None
+        self.ctx._track(self)
 
     # ---- construction -------------------------------------------------------------------
     @classmethod
@@ -339,7 +340,11 @@ class GraphWrapperHIP:
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.spg_graph_destroy(self.h)
+            # a graph's arena belongs to its context's backend: once the context is gone (Context.close() destroys the graphs
+            # it still knows first, so this only happens when finalisers run in an arbitrary order inside a reference cycle)
+            # the handle must not be touched any more
+            if getattr(self.ctx, "h", None):
+                self.L.spg_graph_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -214,8 +214,20 @@ class Context:
     def marginalize_batch(self, opts, batch, want_target=True):
         return abi.marginalize_batch(self.L, self.h, opts, batch, want_target)
 
+    def _track(self, graph):
+        """Graphs created on this context (weak references): destroyed before the context is."""
+        import weakref
+        if not hasattr(self, "_graphs"):
+            self._graphs = weakref.WeakSet()
+        self._graphs.add(graph)
+
     def close(self):
         if getattr(self, "h", None):
+            for g in list(getattr(self, "_graphs", ())):
+                try:
+                    g.close()
+                except Exception:
+                    pass
             self.L.spg_ctx_destroy(self.h)
             self.h = None
 

@@ -22,4 +22,7 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 # block-sparse path at the headline size (optimize after marginalisation, global KLD) and the interior-point kernel
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sparse -o run -- python3 tools/sparse_bench.py 100000 400 all > $OUT/prof_sparse.log 2>&1 || true
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_ip -o run -- python3 tools/ip_bench.py > $OUT/prof_ip.log 2>&1 || true
+# GLC Tree on the bench graph and BASELINE config 4 (parking.g2o, NFR Tree): kernel stats behind the figures quoted in DESIGN.md
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_glc -o run -- python3 tools/glc_check.py > $OUT/prof_glc.log 2>&1 || true
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_parking -o run -- python3 bench.py --config parking --steps 5 --warmup 1 --no-cpu-baseline > $OUT/prof_parking.log 2>&1 || true
 find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -name '*.csv' | head -20
