@@ -53,10 +53,10 @@ enum {
     SPG_ST_MARGINAL_NOT_PD = 8, /* LLT inside PseudoChowLiu::marginal failed (src/pseudo_chow_liu.cpp:134) */
     SPG_ST_EMPTY_BLANKET = 9,   /* removed vertex without edges (assert at src/vertex_remover.cpp:291) */
     SPG_ST_UNSUPPORTED = 10,    /* option combination the reference asserts against or that is out of scope */
-    SPG_ST_NEEDS_LOCAL_OPTIMIZATION = 11 /* Local linearisation point, no closed-form estimate, and the blanket is a
-                                   cluster (m > 1) or holds a GLC edge: the 10 LM iterations of
-                                   src/vertex_remover.cpp:382-391 run in the kernel for single-vertex blankets of
-                                   pose-pose edges only */
+    SPG_ST_NEEDS_LOCAL_OPTIMIZATION = 11 /* Local linearisation point without a closed-form estimate where the 10 LM iterations of
+                                   src/vertex_remover.cpp:382-391 cannot run: a blanket that holds a GLC edge (the GLC provider
+                                   asserts the Global point, src/topology_provider_glc.cpp:110-111). Pose-pose and correlated
+                                   blankets of every NFR pattern, clusters included, are re-linearised on the device. */
 };
 /* informational bits OR-ed into status << 8 are not used; see spg_result.info */
 enum {

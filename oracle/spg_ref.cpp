@@ -627,13 +627,14 @@ int spgref_graph_set_estimate(void *h, int id, const double *pose) {
 // buildSubgraph, Local linearisation point without a closed form (src/vertex_remover.cpp:382-391): the
 // blanket becomes a small graph (local vertex index = id), the first removed vertex is fixed, 10 LM iterations.
 static bool blanket_local_lm(const BlanketIn &in, std::vector<double> &pose) {
-    if (in.m != 1) return false;   // clusters (Dense) with a Local linearisation point: not restated
+    // clusters (m > 1, Dense / CliqueyDense): as in the reference, only the FIRST removed vertex (*toRemove.begin(), local
+    // index 0) is held fixed; the other removed vertices are optimised with the kept ones (src/vertex_remover.cpp:382-391)
     int ps = pose_stride(in.d);
     RGraph g;
     g.d = in.d;
     for (int v = 0; v < in.nv; v++) { g.pose[v] = std::vector<double>(in.pose + (size_t)v * ps, in.pose + (size_t)(v + 1) * ps); g.adj[v]; }
     for (const EdgeIn &e : in.edges) {
-        if (e.kind != SPG_EDGE_BINARY) return false;
+        if (e.kind == SPG_EDGE_GLC) return false;   // (NFR blankets hold pose-pose and correlated MULTI edges; GLC has no Local point: src/topology_provider_glc.cpp:110-111)
         REdge re;
         re.kind = e.kind; re.ids.assign(e.v.begin(), e.v.end()); re.data.assign(e.data, e.data + e.len); re.alive = true;
         g.edges.push_back(re);

@@ -342,7 +342,9 @@ __device__ __forceinline__ void blanket_body(const KArgs &a_in, const spg_blanke
 
     // Local linearisation point without a closed form: lm_left LM iterations on the blanket (below)
     int lm_left = 0;
-    if (a.lin_point != SPG_LIN_GLOBAL) {
+    // (a cluster with fewer than two kept vertices emits no edge whatever the linearisation point: it is not re-linearised;
+    //  clusters with k >= 2 under Local go to the generic kernel behind the pre-pass of hip_run_round)
+    if (a.lin_point != SPG_LIN_GLOBAL && !(m > 1 && k < 2)) {
         // Local linearisation point, closed-form branch of buildSubgraph (src/vertex_remover.cpp:304-381):
         // possible iff every vertex but the first removed one sits in exactly one (pose-pose) blanket edge;
         // then the removed vertex goes to the origin and each neighbour to z (or z^-1) of its edge.
@@ -1442,6 +1444,92 @@ __global__ void __launch_bounds__(NT) blanket_kernel(KArgs a) {
     blanket_body<D, NT, GWS, ALG>(a, bd, a.vpo + bd.vert_begin, a.er + bd.edge_begin, a.ev, (int)blockIdx.x, smem);
 }
 
+// ---------------------------------------------------------------------------------- Local linearisation point, pre-pass
+// buildSubgraph with SparsityOptions::Local (src/vertex_remover.cpp:304-391) for the blankets the generic NFR kernel takes
+// (interior point, correlated patterns, clusters): the blanket's estimates are copied into a scratch block; if every vertex
+// but the first removed one sits in exactly one pose-pose edge they are re-initialised in closed form (the first removed
+// vertex at the origin, each neighbour at z or z^-1 of its edge, edges in blanket order: :304-381) and flag = 1; otherwise
+// flag = 0 and the host runs the 10 LM iterations with that vertex fixed (:382-391) on the scratch block. The kernels that
+// follow read the blanket's poses from the scratch block (their pose offsets are redirected) and take them as they are.
+__device__ __forceinline__ void tq_rotate(const double *q, const double *v, double *o) {
+    const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+    const double cx = uy * v[2] - uz * v[1], cy = uz * v[0] - ux * v[2], cz = ux * v[1] - uy * v[0];
+    o[0] = v[0] + 2.0 * (w * cx + (uy * cz - uz * cy));
+    o[1] = v[1] + 2.0 * (w * cy + (uz * cx - ux * cz));
+    o[2] = v[2] + 2.0 * (w * cz + (ux * cy - uy * cx));
+}
+__device__ __forceinline__ void tq_compose(const double *a, const double *b, double *o) {   // o = a * b (may alias neither)
+    double r[3];
+    tq_rotate(a + 3, b, r);
+    o[0] = a[0] + r[0]; o[1] = a[1] + r[1]; o[2] = a[2] + r[2];
+    const double ax = a[3], ay = a[4], az = a[5], aw = a[6], bx = b[3], by = b[4], bz = b[5], bw = b[6];
+    double x = aw * bx + ax * bw + ay * bz - az * by, y = aw * by - ax * bz + ay * bw + az * bx,
+           z = aw * bz + ax * by - ay * bx + az * bw, w = aw * bw - ax * bx - ay * by - az * bz;
+    const double nn = 1.0 / sqrt(x * x + y * y + z * z + w * w), sg = (w < 0) ? -nn : nn;
+    o[3] = x * sg; o[4] = y * sg; o[5] = z * sg; o[6] = w * sg;
+}
+__device__ __forceinline__ void tq_inverse(const double *a, double *o) {
+    double q[4] = {-a[3], -a[4], -a[5], a[6]}, r[3];
+    tq_rotate(q, a, r);
+    o[0] = -r[0]; o[1] = -r[1]; o[2] = -r[2]; o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3];
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void local_point_kernel(const double *arena, double *lpose, const spg_blanket_desc *blk, const int64_t *vpo,
+                                                         const spg_edge_ref *er, const int32_t *ev, const int32_t *list, const int64_t *lp_off, int32_t *flag) {
+    constexpr int PS = (D == 6) ? 7 : 3;
+    __shared__ int cnt[1024];
+    const int tid = threadIdx.x;
+    const spg_blanket_desc bd = blk[list[blockIdx.x]];
+    const int nv = bd.n_vert;
+    double *P = lpose + lp_off[blockIdx.x];
+    for (int it = tid; it < nv * PS; it += 64) P[it] = arena[vpo[bd.vert_begin + it / PS] + it % PS];
+    for (int v = tid; v < nv && v < 1024; v += 64) cnt[v] = 0;
+    __syncthreads();
+    if (tid != 0) return;
+    bool ok = nv <= 1024;
+    for (int e = 0; ok && e < bd.n_edge; e++) {
+        const spg_edge_ref r = er[bd.edge_begin + e];
+        if (r.kind != SPG_EDGE_BINARY) { ok = false; break; }
+        const int vi = ev[r.vbegin], vj = ev[r.vbegin + 1];
+        if (vi != 0) cnt[vi]++;
+        if (vj != 0) cnt[vj]++;
+    }
+    for (int v = 1; ok && v < nv; v++) if (cnt[v] > 1) ok = false;
+    if (ok) {
+        if (D == 3) { P[0] = 0; P[1] = 0; P[2] = 0; }
+        else { P[0] = 0; P[1] = 0; P[2] = 0; P[3] = 0; P[4] = 0; P[5] = 0; P[6] = 1; }
+        for (int e = 0; e < bd.n_edge; e++) {
+            const spg_edge_ref r = er[bd.edge_begin + e];
+            const int vi = ev[r.vbegin], vj = ev[r.vbegin + 1];
+            if (vi == 0 && vj == 0) continue;
+            const double *z = arena + r.off;
+            if (D == 3) {
+                if (vi == 0) {
+                    const double c = cos(P[2]), sn = sin(P[2]);
+                    double *o = P + vj * 3;
+                    o[0] = P[0] + c * z[0] - sn * z[1]; o[1] = P[1] + sn * z[0] + c * z[1]; o[2] = normalize_theta(P[2] + z[2]);
+                } else {
+                    const double cz = cos(z[2]), sz = sin(z[2]);
+                    const double zi[3] = {-(cz * z[0] + sz * z[1]), -(-sz * z[0] + cz * z[1]), normalize_theta(-z[2])};
+                    const double *a = P + vj * 3;
+                    const double c = cos(a[2]), sn = sin(a[2]);
+                    const double ox = a[0] + c * zi[0] - sn * zi[1], oy = a[1] + sn * zi[0] + c * zi[1], ot = normalize_theta(a[2] + zi[2]);
+                    double *o = P + vi * 3;
+                    o[0] = ox; o[1] = oy; o[2] = ot;
+                }
+            } else {
+                double zq[7], out[7];
+                for (int i = 0; i < 7; i++) zq[i] = z[i];
+                { const double nn = 1.0 / sqrt(zq[3] * zq[3] + zq[4] * zq[4] + zq[5] * zq[5] + zq[6] * zq[6]); for (int i = 3; i < 7; i++) zq[i] *= nn; }
+                if (vi == 0) { tq_compose(P, zq, out); for (int i = 0; i < 7; i++) P[vj * 7 + i] = out[i]; }
+                else { double zi[7]; tq_inverse(zq, zi); tq_compose(P + vj * 7, zi, out); for (int i = 0; i < 7; i++) P[vi * 7 + i] = out[i]; }
+            }
+        }
+    }
+    flag[blockIdx.x] = ok ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------- persistent worker
 // Narrow rounds (a few dozen blankets that depend on the previous few dozen) are bound by the launch-to-result latency
 // of a batch, not by arithmetic. For them the device runs ONE long-lived kernel per marginalisation: kWorkerWGs
@@ -1565,8 +1653,8 @@ struct HipBackend {
     // previous one is still running.
     struct Slot {
         hipStream_t stream = nullptr;
-        void *d_desc = nullptr, *d_gws = nullptr, *d_ipws = nullptr;
-        size_t c_desc = 0, c_gws = 0, c_ipws = 0;
+        void *d_desc = nullptr, *d_gws = nullptr, *d_ipws = nullptr, *d_lpose = nullptr, *d_lmeta = nullptr;
+        size_t c_desc = 0, c_gws = 0, c_ipws = 0, c_lpose = 0, c_lmeta = 0;
         void *h_mail = nullptr, *d_mail = nullptr;   // pinned host mailbox the kernel writes out records into
         size_t c_mail = 0;
         void *h_stage = nullptr;                      // pinned host staging for the descriptor upload
@@ -1973,7 +2061,9 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
                 for (int e = bd.edge_begin; e < bd.edge_begin + bd.n_edge; e++) has_multi |= rd->edges[e].kind == SPG_EDGE_MULTI;
                 const bool ip = k >= 3 && !cliquey && E > k - 1;           // uncorrelated pattern without a closed form
                 // correlated patterns (and any blanket that holds a correlated edge) take the same generic kernel's closed form
-                if (ip || (cliquey && k >= 3) || (has_multi && k >= 2)) {
+                // (clusters under the Local linearisation point too: the blanket kernel's own Local branch is for one removed vertex)
+                const bool local_cluster = o.lin_point != SPG_LIN_GLOBAL && m > 1 && k >= 2;
+                if (ip || (cliquey && k >= 3) || (has_multi && k >= 2) || local_cluster) {
                     const int msub = (int)((1 + o.chord_ratio) * (k - 1));
                     const bool masks = o.topology == SPG_TOPO_CLIQUEY_SUBGRAPH && msub < k * (k - 1) / 2;   // fillCliques on 64-bit vertex masks
                     if ((ip && (int64_t)D * D * E > 2048) || (masks && k > 64) || k > 256) {
@@ -2182,6 +2272,61 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
         ia.list = (const int32_t *)(desc_base + o_list) + list_off;
         ia.ws = (double *)S.d_ipws; ia.ws_stride = ip_stride; ia.mail = mail_dev; ia.mail_base = rd->mail_base;
         ia.topology = o.topology; ia.lin_point = o.lin_point; ia.tag = rd->tag; ia.chord_ratio = o.chord_ratio;
+        if (o.lin_point != SPG_LIN_GLOBAL) {
+            // ---- Local linearisation point for these blankets (pre-pass, see local_point_kernel): scratch poses, closed-form
+            // re-initialisation on the device, else the reference's 10 LM iterations with the first removed vertex fixed —
+            // the dense LM of optimize() on the blanket as a small graph, host-driven, one blanket after the other — and a
+            // second table of pose offsets that points the generic kernel at the scratch blocks.
+            const int PSl = (D == 6) ? 7 : 3;
+            const size_t nl = ip_list.size();
+            std::vector<int64_t> lp_off(nl);
+            int64_t lp_tot = 0;
+            for (size_t i = 0; i < nl; i++) { lp_off[i] = lp_tot; lp_tot += (int64_t)rd->blankets[ip_list[i]].n_vert * PSl; }
+            const size_t meta_bytes = nl * 8 + nl * 4 + (size_t)rd->n_vert_total * 8 + 64;
+            if (int rc2 = hb->ensure(S, &S.d_lpose, &S.c_lpose, (size_t)lp_tot * 8 + 64)) return rc2;
+            if (int rc2 = hb->ensure(S, &S.d_lmeta, &S.c_lmeta, meta_bytes)) return rc2;
+            int64_t *d_lp_off = (int64_t *)S.d_lmeta, *d_vpo2 = d_lp_off + nl;
+            int32_t *d_flag = (int32_t *)(d_vpo2 + rd->n_vert_total);
+            const int64_t scratch0 = ((intptr_t)S.d_lpose - (intptr_t)arena) / 8;   // the scratch block as an "arena offset"
+            std::vector<int64_t> vpo2(rd->vert_pose_off, rd->vert_pose_off + rd->n_vert_total);
+            for (size_t i = 0; i < nl; i++) {
+                const spg_blanket_desc &bd = rd->blankets[ip_list[i]];
+                for (int v = 0; v < bd.n_vert; v++) vpo2[(size_t)bd.vert_begin + v] = scratch0 + lp_off[i] + (int64_t)v * PSl;
+            }
+            HIPCHK(hipMemcpyAsync(d_lp_off, lp_off.data(), nl * 8, hipMemcpyHostToDevice, S.stream));
+            HIPCHK(hipMemcpyAsync(d_vpo2, vpo2.data(), (size_t)rd->n_vert_total * 8, hipMemcpyHostToDevice, S.stream));
+            if (D == 6) hipLaunchKernelGGL((local_point_kernel<6>), dim3((unsigned)nl), dim3(64), 0, S.stream, (const double *)arena, (double *)S.d_lpose, ka.blk, ka.vpo, ka.er, ka.ev, ia.list, (const int64_t *)d_lp_off, d_flag);
+            else hipLaunchKernelGGL((local_point_kernel<3>), dim3((unsigned)nl), dim3(64), 0, S.stream, (const double *)arena, (double *)S.d_lpose, ka.blk, ka.vpo, ka.er, ka.ev, ia.list, (const int64_t *)d_lp_off, d_flag);
+            HIPCHK(hipGetLastError());
+            std::vector<int32_t> h_flag(nl);
+            HIPCHK(hipMemcpyAsync(h_flag.data(), d_flag, nl * 4, hipMemcpyDeviceToHost, S.stream));
+            HIPCHK(hipStreamSynchronize(S.stream));
+            for (size_t i = 0; i < nl; i++) {
+                if (h_flag[i]) continue;
+                const spg_blanket_desc &bd = rd->blankets[ip_list[i]];
+                // the blanket as a small graph (local vertex = blanket-local index), vertex 0 fixed
+                std::vector<int32_t> pos(bd.n_vert), rowptr(bd.n_vert + 1, 0), inc;
+                std::vector<int64_t> lvpo(bd.n_vert);
+                for (int l = 0; l < bd.n_vert; l++) { pos[l] = l == 0 ? -1 : (l - 1) * D; lvpo[l] = scratch0 + lp_off[i] + (int64_t)l * PSl; }
+                std::vector<std::vector<int32_t>> per(bd.n_vert);
+                for (int e = 0; e < bd.n_edge; e++) {
+                    const spg_edge_ref &r = rd->edges[bd.edge_begin + e];
+                    for (int t = 0; t < r.nv; t++) {
+                        const int32_t l = rd->edge_vert[r.vbegin + t];
+                        if (per[l].empty() || per[l].back() != e) per[l].push_back(e);
+                    }
+                }
+                for (int l = 0; l < bd.n_vert; l++) { inc.insert(inc.end(), per[l].begin(), per[l].end()); rowptr[l + 1] = (int32_t)inc.size(); }
+                spg::DenseGraphIn in;
+                in.D = D; in.nv = bd.n_vert; in.ne = bd.n_edge;
+                in.pos = pos.data(); in.vpo = lvpo.data(); in.rowptr = rowptr.data(); in.inc = inc.data();
+                in.er = rd->edges + bd.edge_begin; in.ev = rd->edge_vert; in.n_ev = rd->n_edge_vert_total; in.dev_arena = arena;
+                double lm_stats[8] = {0}, lm_secs = 0;
+                if (int lrc = spg::hip_dense_optimize((void *)S.stream, in, D * (bd.n_vert - 1), 10, lm_stats, &lm_secs, hb->err, sizeof hb->err)) return lrc;
+            }
+            ia.vpo = (const int64_t *)d_vpo2;
+            ia.lin_point = SPG_LIN_GLOBAL;   // the scratch poses ARE the local linearisation point: taken as they are
+        }
         if (int rc2 = spg::hip_nfr_ip_launch((void *)S.stream, D, ia, (int)ip_list.size(), ip_hot)) { snprintf(err, sizeof hb->err, "launch of the interior-point kernel failed"); return rc2; }
         // (this kernel comes AFTER the event a bin launch left in wait_ev: waiting for the slot must mean the whole stream.
         //  Until round 3 wait_slot returned when the bin kernel was done — with a cluster of 150 vertices still running in
@@ -2342,6 +2487,8 @@ void hip_backend_destroy(spg_backend *b) {
         (void)hipStreamSynchronize(S.stream);
         if (S.d_desc) (void)hipFree(S.d_desc);
         if (S.d_gws) (void)hipFree(S.d_gws);
+        if (S.d_lpose) (void)hipFree(S.d_lpose);
+        if (S.d_lmeta) (void)hipFree(S.d_lmeta);
         if (S.h_mail) (void)hipHostFree(S.h_mail);
         if (S.h_stage) (void)hipHostFree(S.h_stage);
         if (S.d_bar) (void)hipFree(S.d_bar);
