@@ -2063,7 +2063,15 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
                 // correlated patterns (and any blanket that holds a correlated edge) take the same generic kernel's closed form
                 // (clusters under the Local linearisation point too: the blanket kernel's own Local branch is for one removed vertex)
                 const bool local_cluster = o.lin_point != SPG_LIN_GLOBAL && m > 1 && k >= 2;
-                if (ip || (cliquey && k >= 3) || (has_multi && k >= 2) || local_cluster) {
+                // (and blankets whose Chow-Liu pair tables and side buffers outgrow LDS even with the tiles in the L2 workspace —
+                //  k beyond ~130: until round 3 SPG_ECAPACITY — the generic kernel keeps everything in its workspace, k <= 256)
+                bool too_big = false;
+                if (i == NB - 1 && k >= 2) {
+                    const bool lm_ = o.lin_point != SPG_LIN_GLOBAL;
+                    Layout Lw = make_layout(D, lm_ ? 256 : 1024, k, m, o.algorithm, o.topology, bd.pad_);
+                    too_big = (size_t)Lw.small_doubles * 8 > (size_t)hb->lds_limit;
+                }
+                if (ip || (cliquey && k >= 3) || (has_multi && k >= 2) || local_cluster || too_big) {
                     const int msub = (int)((1 + o.chord_ratio) * (k - 1));
                     const bool masks = o.topology == SPG_TOPO_CLIQUEY_SUBGRAPH && msub < k * (k - 1) / 2;   // fillCliques on 64-bit vertex masks
                     if ((ip && (int64_t)D * D * E > 2048) || (masks && k > 64) || k > 256) {
