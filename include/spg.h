@@ -61,7 +61,10 @@ enum {
 /* informational bits OR-ed into status << 8 are not used; see spg_result.info */
 enum {
     SPG_INFO_RANK_DEFICIENT = 1, /* smalleigs > dim: chooseDimensions path taken (src/logdet_function.cpp:42-59) */
-    SPG_INFO_GLC_ROOT_EDGE = 2   /* a unary GLC root edge survived the 1e-8 cut (src/topology_provider_glc.cpp:134-140) */
+    SPG_INFO_GLC_ROOT_EDGE = 2,  /* a unary GLC root edge survived the 1e-8 cut (src/topology_provider_glc.cpp:134-140) */
+    SPG_INFO_IP_HESSIAN_NOT_PD = 4 /* interior point: a Newton system was not positive definite and that barrier step was given up
+                                    (src/pqn/pqn_optimizer.cpp:48-53 solves with the failed LLT unchecked; the loop over rho,
+                                    src/optimizer.cpp:60-75, goes on from the same x either way) */
 };
 
 enum {

@@ -620,7 +620,7 @@ struct IpFunction {
 
 // PQNOptimizer::optimize (useHessian, maxIters = 0) + LineSearchSimpleBacktracking. Returns the function value,
 // infinity when the line search (or the Hessian factorisation) fails; iters counts Newton steps (diagnostic).
-inline double pqn_newton(IpFunction &fun, std::vector<double> &x, double tol, long &iters) {
+inline double pqn_newton(IpFunction &fun, std::vector<double> &x, double tol, long &iters, bool &hessian_failed) {
     const int nx = fun.nx;
     std::vector<double> g, gn, xn((size_t)nx), dvec((size_t)nx);
     double f = fun.value(x);
@@ -628,7 +628,7 @@ inline double pqn_newton(IpFunction &fun, std::vector<double> &x, double tol, lo
     for (;;) {
         Mat H;
         fun.hessian(H);
-        if (!chol_lower(H)) return std::numeric_limits<double>::infinity();
+        if (!chol_lower(H)) { hessian_failed = true; return std::numeric_limits<double>::infinity(); }
         Mat rhs(nx, 1);
         for (int i = 0; i < nx; i++) rhs(i, 0) = -g[i];
         chol_solve(H, rhs);
@@ -656,7 +656,7 @@ inline double pqn_newton(IpFunction &fun, std::vector<double> &x, double tol, lo
 }
 
 // the interior-point branch of optimizeInformation (src/optimizer.cpp:38-79)
-inline bool interior_point(const JacMapping &mapping, const Spectrum &sp, int n, std::vector<Mat> &X, double &final_value, long &iters) {
+inline bool interior_point(const JacMapping &mapping, const Spectrum &sp, int n, std::vector<Mat> &X, double &final_value, long &iters, bool &hessian_failed) {
     IpFunction fun(mapping, sp, n);
     std::vector<double> x((size_t)fun.nx, 0.0);
     for (int e = 0; e < fun.E; e++) for (int i = 0; i < fun.d; i++) x[(size_t)e * fun.d * fun.d + (size_t)i * fun.d + i] = 1.0;   // educatedGuess
@@ -666,7 +666,7 @@ inline bool interior_point(const JacMapping &mapping, const Spectrum &sp, int n,
     for (double rho = startRho; rho >= endRho; rho /= stepRho) {
         fun.rho = rho;
         if (rho / stepRho < endRho) tol = 1e-12;
-        pqn_newton(fun, x, tol, iters);
+        pqn_newton(fun, x, tol, iters, hessian_failed);     // the reference ignores the return value too: the next rho goes on from x
     }
     final_value = fun.base_value(x);
     if (!std::isfinite(final_value)) return false;
@@ -807,7 +807,9 @@ inline void run_nfr(const spg_options &o, const BlanketIn &in, BlanketOut &out) 
         for (auto &tree : pattern) if (tree.size() != 1) { out.status = SPG_ST_UNSUPPORTED; return; }
         double fin = 0;
         long iters = 0;
-        if (!interior_point(mapping, sp, n, X, fin, iters)) { out.status = SPG_ST_KLD_NOT_PD; return; }   // the reference exit(0)s here
+        bool hfail = false;
+        if (!interior_point(mapping, sp, n, X, fin, iters, hfail)) { out.status = SPG_ST_KLD_NOT_PD; return; }   // the reference exit(0)s here
+        if (hfail) out.info |= SPG_INFO_IP_HESSIAN_NOT_PD;
         out.info |= (int)std::min<long>(iters, 32767) << 8;   // Newton steps taken (diagnostic, bits 8..)
     }
     for (size_t e = 0; e < edges.size(); e++) {

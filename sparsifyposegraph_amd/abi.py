@@ -16,7 +16,7 @@ EDGE_BINARY, EDGE_GLC, EDGE_MULTI = 0, 1, 2
 ST_OK, ST_HMM_NOT_PD, ST_EIG_FAIL, ST_NONFINITE, ST_TIKHONOV_NOT_PD, ST_CLOSED_FORM_NOT_PD, \
     ST_KLD_NOT_PD, ST_NEEDS_INTERIOR_POINT, ST_MARGINAL_NOT_PD, ST_EMPTY_BLANKET, ST_UNSUPPORTED, \
     ST_NEEDS_LOCAL_OPTIMIZATION = range(12)
-INFO_RANK_DEFICIENT, INFO_GLC_ROOT_EDGE = 1, 2
+INFO_RANK_DEFICIENT, INFO_GLC_ROOT_EDGE, INFO_IP_HESSIAN_NOT_PD = 1, 2, 4
 FLAG_FORCE_EIG = 2
 EINVAL, ENODEV, ENOMEM, ECAPACITY, EHIP, EIO, ESTATE, EBLANKET, ENOTPD = -1, -2, -3, -4, -5, -6, -7, -8, -9
 OUT_HDR = 6

@@ -2333,8 +2333,14 @@ struct Streamer {
                 memcpy(w, recd + 6, 16);
                 for (int e = 0; e < n_new; e++) {
                     const unsigned pr = (unsigned)(w[e >> 3] >> (8 * (e & 7))) & 0xffu;
-                    int32_t vix[2] = {sl.verts[pr & 15u], sl.verts[pr >> 4]};
-                    add_edge_idx(g, SPG_EDGE_BINARY, 2, vix, sl.new_off + (int64_t)e * rec, rec, key0 + e);
+                    const int32_t va = sl.verts[pr & 15u], vb = sl.verts[pr >> 4];
+                    // (add_edge_idx for a pose-pose edge between two different vertices, without its general-case checks)
+                    GEdge ge;
+                    ge.off = sl.new_off + (int64_t)e * rec; ge.key = key0 + e; ge.len = rec; ge.vtx[0] = va; ge.vtx[1] = vb; ge.nv = 2; ge.kind = SPG_EDGE_BINARY; ge.alive = 1;
+                    const int32_t eid = (int32_t)g->edges.size();
+                    g->edges.push_back(ge);
+                    g->vr[va].adj.push_back({eid, vb});
+                    if (vb != va) g->vr[vb].adj.push_back({eid, va});
                 }
             } else {
                 int vpos = 0;
@@ -2349,6 +2355,7 @@ struct Streamer {
                 }
             }
             g->stats.n_new_edges += n_new;
+            if (!emulate) { g->n_mutations += n_new; g->n_live_e += n_new; }
         }
         for (int i = 0; i < sl.nv; i++) {
             spg_graph::SVtx &sx = sv[sl.verts[i]];
@@ -2612,7 +2619,9 @@ struct Streamer {
                 P1(1);
             }
             if (!fallback) {
-                // (woken entries are examined in the order of their wake-up: a launch may be what the next one waits for)
+                // woken entries are examined in list order: an earlier one that launches (or gets its final blanket) is often
+                // what a later one of the same wake-up waits for — the wait lists hand them out newest first
+                if (woken.size() > 1) std::sort(woken.begin(), woken.end());
                 for (size_t wi = 0; wi < woken.size(); wi++) {
                     examine(woken[wi]);
                     if (pending_bell >= 8) ring();

@@ -1629,6 +1629,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     };
     // PQNOptimizer::optimize with useHessian (src/pqn/pqn_optimizer.cpp:29-126)
     int newton_steps = 0;
+    bool hessian_failed = false;     // a Newton system that was not positive definite: that barrier step was given up
     auto optimize = [&](double tol) {
         double f = value(x);
         gradient(x, g);
@@ -1643,13 +1644,13 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                                  : hx_tiled2 ? chol_solve_tiled(std::integral_constant<int, 2>{}, nx, xn, dv)
                                              : chol_solve_packed(nx, xn, dv);      // d = -(L L^T)^-1 g
                 IPT(2);
-                if (!hok) return;
+                if (!hok) { hessian_failed = true; return; }
             } else {
                 for (int it = tid; it < nx; it += NT) Hx[(long long)nx * ldh + it] = -g[it];     // the right-hand side rides along as row nx
                 __syncthreads();
                 const bool hok = hx_streamed ? chol_streamed(Hx, nx) : chol_rows(Hx, nx);
                 IPT(2);
-                if (!hok) return;
+                if (!hok) { hessian_failed = true; return; }
                 if (hx_streamed && nx <= 511) solve_reg(std::integral_constant<int, 8>{}, std::false_type{}, nx, dv);
                 else solve_rows(Hx, nx, dv);     // d = -(L L^T)^-1 g
                 IPT(3);
@@ -1708,6 +1709,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     if (!okf || !isfinite(fin)) { status = SPG_ST_KLD_NOT_PD; finish(); return; }    // the reference exit(0)s here
     kld = fin;
     info |= min(newton_steps, 32767) << 8;
+    if (hessian_failed) info |= SPG_INFO_IP_HESSIAN_NOT_PD;
     // information of the new edges: upper triangle of the symmetric view of x
     for (int it = tid; it < E * (D * (D + 1) / 2); it += NT) {
         const int e = it / (D * (D + 1) / 2);

@@ -156,6 +156,7 @@ def test_device_interior_point_matches_oracle(case, topo, chord, hip_ctx, oracle
           f"Newton steps oracle {steps_r.mean():.1f} device {steps_g.mean():.1f}")
     assert worst <= 1e-9 and kerr <= 1e-9      # (the north star's bar; measured ~5e-12)
     assert np.array_equal(steps_r, steps_g)    # where a tolerance-terminated Newton run stops is part of the result
+    assert np.array_equal(ref["info"][ip] & abi.INFO_IP_HESSIAN_NOT_PD, got["info"][ip] & abi.INFO_IP_HESSIAN_NOT_PD)   # a given-up barrier step is reported alike
     fin = ~ip & np.isfinite(ref["kld"])
     assert util.rel_err(ref["kld"][fin], got["kld"][fin]) <= 1e-9 or np.abs(ref["kld"][fin] - got["kld"][fin]).max() <= 1e-9
 
@@ -188,6 +189,7 @@ def test_device_interior_point_streamed_sizes_match_oracle(case, k_range, hip_ct
           f"Newton steps {(ref['info'] >> 8).tolist()}")
     assert worst <= util.RTOL and kerr <= 1e-9
     assert np.array_equal(ref["info"] >> 8, got["info"] >> 8)
+    assert np.array_equal(ref["info"] & abi.INFO_IP_HESSIAN_NOT_PD, got["info"] & abi.INFO_IP_HESSIAN_NOT_PD)
 
 
 @pytest.mark.gpu

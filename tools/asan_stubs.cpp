@@ -12,6 +12,8 @@ void hip_backend_profile_read(spg_backend *, double *, double *, long long *, lo
 void hip_backend_profile_read_worker(spg_backend *, double *, double *, long long *, long long *) {}
 void hip_backend_profile_read_big(spg_backend *, double *, double *, long long *, int *) {}
 int hip_backend_end_of_call(spg_backend *) { return 0; }
+int hip_stream_open(spg_backend *, int, int, int, StreamPort *) { return 1; }
+void hip_stream_close(spg_backend *, const StreamPort *, double, long long) {}
 int hip_big_glc_dense(void *, const DenseGraphIn &, int, int, int, int64_t, double *, int, int, double *, double *, char *, size_t) { return SPG_ENODEV; }
 int hip_dense_information(void *, const DenseGraphIn &, int, double *, char *, size_t) { return SPG_ENODEV; }
 int hip_dense_covariance(void *, const DenseGraphIn &, int, double *, char *, size_t) { return SPG_ENODEV; }
@@ -21,4 +23,6 @@ int rccl_allgather_f64(void *, void *, int64_t, int64_t, void *, char *, size_t)
 void rccl_comm_destroy(void *) {}
 int hip_dense_kld(void *, const DenseGraphIn &, const DenseGraphIn &, int, int, const int64_t *, const int64_t *, double *, double *, char *, size_t) { return SPG_ENODEV; }
 int hip_dense_optimize(void *, const DenseGraphIn &, int, int, double *, double *, char *, size_t) { return SPG_ENODEV; }
+int hip_sparse_optimize(void *, const DenseGraphIn &, int, int, double *, double *, double *, char *, size_t) { return SPG_ENODEV; }
+int hip_sparse_kld(void *, const DenseGraphIn &, const DenseGraphIn &, const uint8_t *, const int32_t *, const int32_t *, int, const int64_t *, const int64_t *, double *, double *, double *, char *, size_t) { return SPG_ENODEV; }
 }

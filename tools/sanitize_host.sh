@@ -11,4 +11,4 @@ g++ -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer
 cd $ROOT
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 \
 UBSAN_OPTIONS=print_stacktrace=1 SPG_LIB_PATH=$OUT/libspg_host_asan.so \
-python -m pytest tests/test_host_scheduler.py tests/test_decimation_and_io.py tests/test_substitute_edge.py tests/test_distributed.py -x -q -m "not gpu"
+python -m pytest tests/test_host_scheduler.py tests/test_stream_scheduler.py tests/test_decimation_and_io.py tests/test_substitute_edge.py tests/test_distributed.py tests/test_cliquey.py -x -q -m "not gpu"
