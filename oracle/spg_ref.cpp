@@ -742,6 +742,20 @@ int spgref_lu_inverse(int n, const double *A, double *X) {
     std::memcpy(X, I.a.data(), sizeof(double) * n * n);
     return ok ? 0 : 1;
 }
+// fillCliques on a given tree (pairs: k - 1 edges as 2 ints each): clique_of[i] = the clique that holds tree edge i,
+// count[i] = the number of cliques that hold it. Returns the number of cliques. (Tests: every tree edge lies in exactly one.)
+int spgref_fill_cliques(int k, int m, const int32_t *pairs, int32_t *clique_of, int32_t *count) {
+    std::vector<std::pair<int, int>> bin;
+    for (int i = 0; i < k - 1; i++) bin.push_back({pairs[2 * i], pairs[2 * i + 1]});
+    Pattern pattern;
+    fill_cliques(bin, k, m, pattern);
+    for (int i = 0; i < k - 1; i++) { clique_of[i] = -1; count[i] = 0; }
+    for (size_t j = 0; j < pattern.size(); j++)
+        for (auto &pr : pattern[j])
+            for (int i = 0; i < k - 1; i++)
+                if (bin[i] == pr) { clique_of[i] = (int)j; count[i]++; }
+    return (int)pattern.size();
+}
 double spgref_spd_logdet(int n, const double *A) {
     Mat M(n, n);
     std::memcpy(M.a.data(), A, sizeof(double) * n * n);

@@ -871,8 +871,55 @@ __global__ __launch_bounds__(256) void big_write_record_kernel(const double *L, 
         rec[it] = v;
     }
 }
-// out record of the blanket (layout in include/spg.h). flags[0] = H_mm not PD, flags[1] = a reparametrisation block is
-// singular, flags[2] = M_rel not PD; stats as above; partial[0..np) = sum of squares of L^-T (trace of M_rel^-1).
+// Whether the Cholesky shortcut stands: flags[0] = H_mm not PD, flags[1] = a reparametrisation block is singular,
+// flags[2] = M_rel not PD; stats[0] / stats[1] = largest entry of the absolute rows / of M; tr_inv = trace(M_rel^-1).
+__device__ inline int big_shortcut_status(const int *flags, const double *stats, double tr_inv) {
+    if (flags[0]) return SPG_ST_HMM_NOT_PD;
+    if (flags[1] || !isfinite(stats[1])) return SPG_ST_NONFINITE;
+    if (flags[2] || !(tr_inv < 1e8) || !(stats[0] <= 1e-9 * fmax(stats[1], 1e-300))) return SPG_ST_EIG_FAIL;   // needs the truncating eig route
+    return SPG_OK;
+}
+// The truncating eigen route of glc_chol (src/topology_provider_glc.cpp:59-71) for a large blanket whose target fails the
+// shortcut's guard (rank-deficient beyond the gauge, or lambda_min < 1e-8): eigen-decomposition of the whole n x n
+// M = sym(Mt) by one workgroup (parallel-order Jacobi on matrices in HBM — the rare path: seconds at n ~ 600), rows
+// sqrt(lambda) v^T for lambda >= 1e-8 in ascending order, as the LDS kernels emit them. A, V: n x n scratch with leading
+// dimension lda; cs: n + 2 doubles, perm: n ints. flags[4] = 1 done / 2 no convergence, flags[5] = rows kept.
+__global__ __launch_bounds__(1024) void big_glc_eig_kernel(int *flags, const double *stats, const double *partial, int np, const double *Mt, int ldm, int n,
+                                                           int rmax, double *A, double *V, int lda, double *cs, int *perm, const double *meas, double *rec) {
+    constexpr int NT = 1024;
+    __shared__ double red[NT / 64];
+    __shared__ int flag_s;
+    const int tid = threadIdx.x;
+    const Team<NT> T{tid, red, &flag_s};
+    double sp = 0;
+    for (int i = tid; i < np; i += NT) sp += partial[i];
+    const double tr_inv = T.sum(sp);
+    if (big_shortcut_status(flags, stats, tr_inv) != SPG_ST_EIG_FAIL) return;
+    for (long long it = tid; it < (long long)n * n; it += NT) {
+        const int i = (int)(it / n), j = (int)(it - (long long)i * n);
+        A[(long long)i * lda + j] = 0.5 * (Mt[(long long)i * ldm + j] + Mt[(long long)j * ldm + i]);
+    }
+    T.sync();
+    if (!jacobi_eigh<NT>(T, A, V, n, lda, cs)) { if (tid == 0) flags[4] = 2; return; }
+    double *ev = cs;
+    for (int i = tid; i < n; i += NT) ev[i] = A[(long long)i * lda + i];
+    T.sync();
+    sort_ascending<NT>(T, ev, 1, n, perm);
+    double below = 0;
+    for (int i = tid; i < n; i += NT) below += (ev[i] < 1e-8) ? 1.0 : 0.0;      // glc_eps, src/topology_provider_glc.cpp:18,67
+    int i0 = (int)T.sum(below);
+    if (n - i0 > rmax) i0 = n - rmax;     // (the record has room for n - D rows: the gauge directions never pass the cut)
+    const int r = n - i0;
+    for (long long it = tid; it < (long long)n + (long long)r * n; it += NT) {
+        if (it < n) { rec[it] = meas[it]; continue; }
+        const long long w = it - n;
+        const int e = (int)(w / n), c = (int)(w - (long long)e * n), col = perm[i0 + e];
+        rec[it] = V[(long long)c * lda + col] * sqrt(ev[col]);
+    }
+    if (tid == 0) { flags[4] = 1; flags[5] = r; }
+}
+// out record of the blanket (layout in include/spg.h). flags / stats as above; partial[0..np) = sum of squares of L^-T
+// (trace of M_rel^-1); flags[4], flags[5] = outcome of the eigen route when the shortcut's guard failed.
 __global__ void big_out_record_kernel(double *orec, const int *flags, const double *stats, const double *partial, int np, int n, int D_, int m, int k,
                                       int n_new_max, int tag, long long rec_len) {
     __shared__ double red[256];
@@ -883,11 +930,13 @@ __global__ void big_out_record_kernel(double *orec, const int *flags, const doub
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x != 0) return;
     const double tr_inv = red[0] - 0.0;
-    int status = SPG_OK;
-    if (flags[0]) status = SPG_ST_HMM_NOT_PD;
-    else if (flags[1] || !isfinite(stats[1])) status = SPG_ST_NONFINITE;
-    else if (flags[2] || !(tr_inv < 1e8) || !(stats[0] <= 1e-9 * fmax(stats[1], 1e-300))) status = SPG_ST_EIG_FAIL;   // needs the truncating eig route
-    const int n_new = (status == SPG_OK) ? 1 : 0;
+    int status = big_shortcut_status(flags, stats, tr_inv);
+    int n_new = (status == SPG_OK) ? 1 : 0;
+    if (status == SPG_ST_EIG_FAIL && flags[4] == 1) {
+        status = SPG_OK;
+        n_new = flags[5] > 0 ? 1 : 0;
+        rec_len = (long long)n + (long long)flags[5] * n;
+    }
     orec[0] = (double)status; orec[1] = 0.0; orec[2] = __builtin_nan(""); orec[3] = __builtin_inf(); orec[4] = (double)n_new;
     if (n_new) {
         orec[SPG_OUT_HDR + 0] = (double)SPG_EDGE_GLC;
@@ -1089,7 +1138,7 @@ static int big_glc_dense_impl(hipStream_t s, const spg::DenseGraphIn &in, int m,
     }
     HIPCHK(hipMalloc(&linv.p, TB * TB * 8));
     HIPCHK(hipMalloc(&linv_all.p, (size_t)ntr * TB * TB * 8));
-    HIPCHK(hipMalloc(&flags.p, 4 * sizeof(int)));
+    HIPCHK(hipMalloc(&flags.p, 8 * sizeof(int)));
     HIPCHK(hipMalloc(&stats.p, 2 * 8));
     HIPCHK(hipMalloc(&partial.p, np * 8));
     HIPCHK(hipMalloc(&jinv.p, (size_t)std::max(k, 1) * 2 * DD * 8));
@@ -1101,7 +1150,7 @@ static int big_glc_dense_impl(hipStream_t s, const spg::DenseGraphIn &in, int m,
     HIPCHK(hipMemsetAsync(H.p, 0, (size_t)N * N * 8, s));
     HIPCHK(hipMemsetAsync(Mrel.p, 0, (size_t)Nr * Nr * 8, s));
     HIPCHK(hipMemsetAsync(Yi.p, 0, (size_t)Nr * Nr * 8, s));
-    HIPCHK(hipMemsetAsync(flags.p, 0, 4 * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(flags.p, 0, 8 * sizeof(int), s));
     HIPCHK(hipMemsetAsync(stats.p, 0, 2 * 8, s));
     launch_assemble<D>(gb, (double *)H.p, N, s);
     if (Nm > nm) hipLaunchKernelGGL(pad_identity_kernel, dim3((Nm - nm + 255) / 256), dim3(256), 0, s, (double *)H.p, N, nm, Nm);
@@ -1124,6 +1173,15 @@ static int big_glc_dense_impl(hipStream_t s, const spg::DenseGraphIn &in, int m,
         hipLaunchKernelGGL(sumsq_kernel, dim3(np), dim3(256), 0, s, (const double *)Yi.p, Nr, n - D, (double *)partial.p);
         const long long rec_len = (long long)n + (long long)(n - D) * n;
         hipLaunchKernelGGL((big_write_record_kernel<D>), dim3(512), dim3(256), 0, s, (const double *)Mrel.p, Nr, n, (const double *)meas.p, arena + new_off);
+        {
+            // the eigen route, taken inside the kernel only when the shortcut's guard failed: A in Y (free since the left
+            // multiplication), V and the small scratch in H (free since the Schur complement was read)
+            double *Vs = (double *)H.p, *cs = Vs + (size_t)Ng * Ng;
+            int *perm = reinterpret_cast<int *>(cs + n + 2);
+            static_assert(TB >= 16, "the scratch behind V assumes N^2 - Ng^2 >= 2 n + 2");
+            hipLaunchKernelGGL(big_glc_eig_kernel, dim3(1), dim3(1024), 0, s, (int *)flags.p, (const double *)stats.p, (const double *)partial.p, np,
+                               (const double *)Mt.p, Ng, n, n - D, (double *)Y.p, Vs, Ng, cs, perm, (const double *)meas.p, arena + new_off);
+        }
         hipLaunchKernelGGL(big_out_record_kernel, dim3(1), dim3(256), 0, s, orec, (const int *)flags.p, (const double *)stats.p, (const double *)partial.p, np,
                            n, D, m, k, n_new_max, tag, rec_len);
     }

@@ -532,8 +532,11 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
         __syncthreads();
         min_gap = sc[0];
-        // a tree edge inside two cliques: more measurements than rank, no closed form — the reference then runs the
-        // interior point over correlated blocks, which is not built
+        // a tree edge inside two cliques would mean more measurements than rank and no closed form (the reference would then
+        // run the interior point over correlated blocks, src/logdet_function.cpp:135-214). fillCliques cannot produce it: the
+        // cliques start as the k - 1 edges of the Chow-Liu TREE and only ever merge where they intersect, so they stay
+        // edge-disjoint connected subtrees, two of which share at most one vertex — every tree edge lies in exactly one
+        // clique and the measurements always add up to the rank. Kept as a check of that invariant.
         if (cliquey && si[1] != k - 1) { status = SPG_ST_UNSUPPORTED; finish(); return; }
     }
     __syncthreads();

@@ -81,6 +81,76 @@ def test_dense_pipeline_forced_on_every_blanket_matches_fixtures(tmp_path):
     print(out.stdout)
 
 
+DEFICIENT = r"""
+import os, sys
+os.environ["SPG_FORCE_BIG"] = "1"
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from sparsifyposegraph_amd import abi
+from sparsifyposegraph_amd.graph import GraphWrapperHIP
+from sparsifyposegraph_amd.lib import Context
+from tests import oracle_lib, util
+rng = np.random.default_rng(11)
+# SE2: a loop of 12 poses with full-rank odometry, and three pendant poses whose only edge measures the translation
+# alone (information of rank 2): the marginal of a blanket that holds one of them lacks that pose's heading
+n = 15
+poses = np.zeros((n, 3))
+for i in range(12):
+    a = 2 * np.pi * i / 12
+    poses[i] = [5 * np.cos(a), 5 * np.sin(a), a + np.pi / 2]
+poses[12:] = poses[[2, 6, 9]] + rng.normal(scale=1.0, size=(3, 3))
+def rel(a, b):
+    c, s = np.cos(poses[a, 2]), np.sin(poses[a, 2])
+    dx, dy = poses[b, :2] - poses[a, :2]
+    return np.array([c * dx + s * dy, -s * dx + c * dy, poses[b, 2] - poses[a, 2]]) + rng.normal(scale=0.01, size=3)
+full = np.diag([50.0, 50.0, 200.0])[np.triu_indices(3)]
+trans = np.diag([50.0, 50.0, 0.0])[np.triu_indices(3)]
+ij, data = [], []
+for i in range(12):
+    ij.append((i, (i + 1) % 12)); data.append(np.concatenate([rel(i, (i + 1) % 12), full]))
+for p, a in zip((12, 13, 14), (2, 6, 9)):
+    ij.append((a, p)); data.append(np.concatenate([rel(a, p), trans]))
+g = {"pose_dim": 3, "ids": np.arange(n, dtype=np.int32), "poses": poses, "edge_ij": np.array(ij, np.int32), "edge_data": np.array(data)}
+which = np.array([2, 6, 9], np.int32)
+opts = abi.make_options(3, abi.ALG_GLC, abi.TOPO_DENSE)
+og = oracle_lib.OracleGraph.from_dict(g)
+assert og.marginalize(which, opts) == 0
+ob = og.blankets()
+assert (ob["status"] == 0).all(), ob
+ctx = Context(0)
+hg = GraphWrapperHIP.from_dict(g, ctx=ctx, useGLC=True)
+ctx.profile(True)
+st = hg.marginalizeNoOptimize(which, opts)
+big = ctx.profile_read_big()
+assert st["n_bad_status"] == 0, st
+assert big["blankets"] == 3, big
+he, oe = hg.edges(), og.edges()
+rows = []
+for e in range(len(he["kind"])):
+    if he["kind"][e] != abi.EDGE_GLC: continue
+    q = he["vert_off"][e + 1] - he["vert_off"][e]
+    ln = he["data_off"][e + 1] - he["data_off"][e]
+    rows.append((3 * q, (ln - 3 * q) // (3 * q)))
+assert rows and all(r == nn - 3 - 1 for nn, r in rows), rows      # one direction beyond the gauge is cut at 1e-8
+worst = util.compare_edge_sets(3, oe, he)
+print(f"deficient ok: {len(rows)} GLC edges with (n, rows) = {rows}, worst rel err {worst:.2e}")
+"""
+
+
+@pytest.mark.gpu
+def test_dense_pipeline_truncating_eigen_route(tmp_path):
+    """A blanket whose target is rank-deficient beyond the gauge (a pendant pose measured in translation only) fails the
+    Cholesky shortcut's guard of the dense HBM pipeline; the truncating eigen route of glc_chol
+    (src/topology_provider_glc.cpp:59-71) then cuts the spectrum at 1e-8 as the oracle does: same edges, n - d - 1 rows,
+    W^T W to 1e-9 (SPG_FORCE_BIG=1 in its own process, so that 9-variable blankets take that pipeline)."""
+    script = tmp_path / "deficient.py"
+    script.write_text(DEFICIENT)
+    out = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "deficient ok" in out.stdout
+    print(out.stdout)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("graph", ["lattice6000", "parking"])
 def test_glc_dense_is_exact_on_large_clusters(graph, hip_ctx):

@@ -72,6 +72,32 @@ def test_oracle_whole_graph_with_correlated_edges(case, n, topo, chord):
         assert -1e-9 <= r["kld"] <= rt["kld"]
 
 
+def test_fill_cliques_keeps_every_tree_edge_in_one_clique():
+    """fillCliques (src/pseudo_chow_liu.cpp:198-251) merges cliques that start as the edges of a TREE, so they stay
+    edge-disjoint connected subtrees: every tree edge ends in exactly one clique, the measurements of the pattern add up to
+    the rank (hasClosedFormSolution, src/logdet_function.cpp:83-86) and the interior point over correlated blocks
+    (src/logdet_function.cpp:135-214) is never reached from CliqueySubgraph. Random trees of 3-40 vertices, every budget m."""
+    import ctypes as C
+    L = oracle_lib.lib()
+    L.spgref_fill_cliques.restype = C.c_int
+    rng = np.random.default_rng(5)
+    merged = 0
+    for trial in range(300):
+        k = int(rng.integers(3, 41))
+        perm = rng.permutation(k)
+        pairs = np.array([(perm[i], perm[rng.integers(0, i)]) for i in range(1, k)], np.int32)
+        pairs = np.ascontiguousarray(pairs[rng.permutation(k - 1)])
+        for chord in (0.0, 0.25, 0.5, 1.0, 3.0):
+            m = int((1 + chord) * (k - 1))
+            clique_of, count = np.zeros(k - 1, np.int32), np.zeros(k - 1, np.int32)
+            nc = L.spgref_fill_cliques(k, m, pairs.ctypes.data_as(C.POINTER(C.c_int32)), clique_of.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       count.ctypes.data_as(C.POINTER(C.c_int32)))
+            assert (count == 1).all(), (k, m, pairs.tolist(), count.tolist())
+            assert 1 <= nc <= k - 1
+            merged += nc < k - 1
+    assert merged > 300
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,topo,chord", CASES)
 def test_device_correlated_patterns_match_oracle(case, topo, chord, hip_ctx, oracle):
