@@ -21,6 +21,7 @@
 #include <cstring>
 #include <limits>
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "spg_dev_geom.hpp"
@@ -73,16 +74,9 @@ struct TileOp {
 
 constexpr int KC = 32, LDK = 34;
 
-__global__ __launch_bounds__(256, 2) void tile_abt_kernel(TileOp op) {
-    __shared__ __attribute__((aligned(16))) double As[128 * LDK], Bs[128 * LDK];
-    int p = blockIdx.x, q = blockIdx.y;
-    if (op.tri) {
-        int t = blockIdx.x;   // t = p(p+1)/2 + q
-        p = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-        while ((p + 1) * (p + 2) / 2 <= t) p++;
-        while (p * (p + 1) / 2 > t) p--;
-        q = t - p * (p + 1) / 2;
-    }
+// p, q: the 128-tile this workgroup computes; As / Bs: 128 * LDK doubles of LDS each. Every thread of the workgroup
+// takes part (barriers inside); the caller separates two tiles that reuse the LDS by a barrier of its own.
+__device__ __forceinline__ void tile_abt_body(const TileOp &op, int p, int q, double *As, double *Bs) {
     const int rows = min(2, op.P64 - 2 * p) * TB, cols = min(2, op.Q64 - 2 * q) * TB;   // valid extent: 64 or 128
     const double *A = op.A + 2 * p * op.a_p;
     const double *B = op.B + 2 * q * op.b_q;
@@ -153,73 +147,226 @@ __global__ __launch_bounds__(256, 2) void tile_abt_kernel(TileOp op) {
             }
 }
 
+// the 128-tile (p, q) behind a linear index: row-major over the rectangle, or t = p(p+1)/2 + q over the triangle q <= p
+__device__ __forceinline__ void tile_of(const TileOp &op, int t, int &p, int &q) {
+    if (op.tri) {
+        p = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((p + 1) * (p + 2) / 2 <= t) p++;
+        while (p * (p + 1) / 2 > t) p--;
+        q = t - p * (p + 1) / 2;
+    } else {
+        const int gq = (op.Q64 + 1) / 2;
+        p = t / gq;
+        q = t - p * gq;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void tile_abt_kernel(TileOp op) {
+    __shared__ __attribute__((aligned(16))) double As[128 * LDK], Bs[128 * LDK];
+    int p = blockIdx.x, q = blockIdx.y;
+    if (op.tri) tile_of(op, blockIdx.x, p, q);
+    tile_abt_body(op, p, q, As, Bs);
+}
+
+// The same step for the steps of a factorisation chain, which have a handful of tiles and are waited for: what counts
+// is the time to the LAST tile, not the throughput. One workgroup per 64 x 64 tile (four times as many workgroups), its
+// four wavefronts split K: each reads its quarter of the two operands straight from memory in the fragment layout (no
+// LDS staging, no barrier in the loop — all loads of a wavefront are in flight together), the partial sums meet in LDS
+// and wavefront w finishes rows 16 w .. 16 w + 15 of the tile. (128 x 128 x 512 on one CU is 27 us of matrix-core time
+// alone; a 64 x 64 tile with K split four ways holds each wavefront for a sixteenth of that.)
+__global__ __launch_bounds__(256) void tile_abt_small_kernel(TileOp op) {
+    __shared__ double part[4][3][16][64];       // [owner block row x][source slot][4 block columns x 4 registers][lane]
+    int p = blockIdx.x, q = blockIdx.y;
+    if (op.tri) {
+        const int t = blockIdx.x;   // t = p(p+1)/2 + q over 64-tiles
+        p = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((p + 1) * (p + 2) / 2 <= t) p++;
+        while (p * (p + 1) / 2 > t) p--;
+        q = t - p * (p + 1) / 2;
+    }
+    const double *A = op.A + p * op.a_p;
+    const double *B = op.B + q * op.b_q;
+    double *C = op.C + p * op.c_p + q * op.c_q;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int kw = 8 * op.kchunks, kbeg = w * kw;      // K = 32 * kchunks, a quarter per wavefront
+    d4 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+        for (int y = 0; y < 4; y++) acc[x][y] = d4{0, 0, 0, 0};
+    const double *ga = A + (long long)li * op.lda + kbeg + lk, *gb = B + (long long)li * op.ldb + kbeg + lk;
+#pragma unroll 2
+    for (int k0 = 0; k0 < kw; k0 += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            a[x] = ga[(long long)(16 * x) * op.lda + k0];
+            b[x] = gb[(long long)(16 * x) * op.ldb + k0];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+#pragma unroll
+            for (int y = 0; y < 4; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+    }
+    // block row x of the tile belongs to wavefront x: the other three park their partial sums for it
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        if (x == w) continue;
+        const int slot = (w - x - 1) & 3;       // 0..2
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[x][slot][4 * y + r][lane] = acc[x][y][r];
+    }
+    __syncthreads();
+    // (the operands were read before the barrier: C may alias A as in the 128-tile kernel)
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        if (x != w) continue;
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double v = acc[x][y][r] + part[x][0][4 * y + r][lane] + part[x][1][4 * y + r][lane] + part[x][2][4 * y + r][lane];
+                const int row = 16 * x + lk + 4 * r, col = 16 * y + li;      // C/D layout of the f64 MFMA
+                double *dst = C + (long long)row * op.ldc + col;
+                *dst = op.subtract ? (*dst - v) : v;
+            }
+    }
+}
+
 // Factor the 64x64 diagonal block at Ajj (lower Cholesky, in place, strict upper zeroed) and write
 // its inverse (dense 64x64, row-major, strict upper zero) to Linv; factor = 0: the block already holds
-// a Cholesky factor, only invert it. *bad is set if a pivot is not positive. One wavefront per block,
-// register-resident: lane i owns row i of the block (64 fp64 registers); the factorisation broadcasts
-// pivot-row entries with v_readlane (as csrc/spg_dev_wave.hpp does for n <= 24), the inverse then runs
-// one independent forward substitution per lane (lane c = column c of L^-1) with L[i][k] broadcast from
-// lane i's registers. No barrier and no LDS round trip in either chain — the
-// LDS-cooperative version (chol_lower<256> + tri_inverse_lower) took 119 us per block, the serial
-// critical path of the blocked factorisation.
-__device__ __forceinline__ void diag_potrf_body(double *Ls /* LDS, 64 * 65 */, double *Ajj, int ld, double *Linv, int *bad, int factor) {
-    const int lane = threadIdx.x;
-    // coalesced load of the lower triangle into LDS (row stride 65: row-per-lane reads hit 64 banks)
-    // (16 independent loads in flight per step: a rolled loop waits one full memory latency per row)
-    for (int r0 = 0; r0 < TB; r0 += 16) {
-        double t[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) t[i] = (lane <= r0 + i) ? Ajj[(long long)(r0 + i) * ld + lane] : 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) Ls[(r0 + i) * 65 + lane] = t[i];
-    }
+// a Cholesky factor, only invert it. *bad is set if a pivot is not positive. One wavefront per block — this is the serial
+// link of every blocked factorisation here, so its latency counts, not its throughput. The block lives in LDS (Ls, the
+// inverse grows in Li; 64 x 65 doubles each) and is processed in 16-wide block columns: the 16 x 16 diagonal block is
+// factorised and inverted in registers (lane i owns row i, pivot rows broadcast with v_readlane: 2 x 120 dependent
+// steps instead of the 2 x 2016 of a register-resident 64 x 64), the panel below it (product with the inverse), the
+// trailing update and the block forward substitution for L^-1 are 16 x 16 x 16 products on v_mfma_f64_16x16x4_f64 with
+// operands read from LDS. (Round 2: whole block in 128 registers per lane, 44 us; the LDS-cooperative version before
+// that, 119 us.)
+__device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    double a[TB];   // row `lane` of the block (of L once factorised)
+}
+// acc += A B^T (bt) or A B: A, B 16 x 16 blocks in LDS with row stride 65
+__device__ __forceinline__ d4 mm16(d4 acc, const double *A, const double *B, bool bt, int li, int lk) {
 #pragma unroll
-    for (int c = 0; c < TB; c++) a[c] = Ls[lane * 65 + c];
-    if (factor) {
-        bool ok = true;
+    for (int s4 = 0; s4 < 16; s4 += 4) {
+        const double a = A[li * 65 + s4 + lk];
+        const double b = bt ? B[li * 65 + s4 + lk] : B[(s4 + lk) * 65 + li];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ void diag_potrf_body(double *Ls /* LDS, 64 * 65 */, double *Li /* LDS, 64 * 65 */, double *Ajj, int ld, double *Linv, int *bad, int factor) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    // coalesced load of the lower triangle into LDS (row stride 65): all 64 rows in flight at once — one memory latency,
+    // not one per group of rows, on the critical path of the factorisation
+    {
+        double t[TB];
 #pragma unroll
-        for (int j = 0; j < TB; j++) {
-            double d = readlane64(a[j], j);
-            if (!(d > 0.0) || !isfinite(d)) { ok = false; d = 1.0; }
-            double rs = fast_rsqrt(d);
-            a[j] = (lane == j) ? d * rs : a[j] * rs;     // L_jj = sqrt(d); column j scaled
+        for (int i = 0; i < TB; i++) t[i] = (lane <= i) ? Ajj[(long long)i * ld + lane] : 0.0;
 #pragma unroll
-            for (int c = j + 1; c < TB; c++) {
-                double lc = readlane64(a[j], c);          // L[c][j]
-                a[c] -= a[j] * lc;                        // rows above the diagonal carry zeros: harmless
+        for (int i = 0; i < TB; i++) { Ls[i * 65 + lane] = t[i]; Li[i * 65 + lane] = 0.0; }
+    }
+    wave_sync();
+    auto blk = [&](double *M, int i, int j) { return M + (16 * i) * 65 + 16 * j; };
+    bool ok = true;
+#pragma unroll 1
+    for (int jb = 0; jb < 4; jb++) {
+        double *Dg = blk(Ls, jb, jb);
+        double a[16];   // row li of the diagonal block (each group of 16 lanes holds a copy; lanes 0-15 are the ones read)
+#pragma unroll
+        for (int c = 0; c < 16; c++) a[c] = Dg[li * 65 + c];
+        if (factor) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                double d = readlane64(a[j], j);
+                if (!(d > 0.0) || !isfinite(d)) { ok = false; d = 1.0; }
+                const double rs = fast_rsqrt(d);
+                a[j] = (li == j) ? d * rs : a[j] * rs;      // L_jj = sqrt(d); column j scaled
+#pragma unroll
+                for (int c = j + 1; c < 16; c++) a[c] -= a[j] * readlane64(a[j], c);     // (entries above the diagonal are never read)
             }
         }
-        if (!ok && lane == 0) *bad = 1;
+        // x[i] = (L16^-1)[i][li]: one forward substitution per lane, L16[i][k] broadcast from lane i
+        double x[16];
 #pragma unroll
-        for (int c = 0; c < TB; c++) Ls[lane * 65 + c] = (c <= lane) ? a[c] : 0.0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < 16; i++) {
+            double sacc = (li == i) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k2 = 0; k2 < i; k2++) sacc -= readlane64(a[k2], i) * x[k2];
+            x[i] = (li <= i) ? sacc * fast_rcp(readlane64(a[i], i)) : 0.0;
+        }
+        if (lk == 0) {
+            if (factor) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) Dg[li * 65 + c] = (c <= li) ? a[c] : 0.0;
+            }
+            double *Dv = blk(Li, jb, jb);
+#pragma unroll
+            for (int i = 0; i < 16; i++) Dv[i * 65 + li] = x[i];
+        }
+        wave_sync();
+        if (factor && jb < 3) {
+            // panel: L[ib][jb] = A[ib][jb] L16^-T for the block rows below
+            const double *Dv = blk(Li, jb, jb);
+            d4 pc[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) { pc[t] = d4{0, 0, 0, 0}; if (jb + 1 + t < 4) pc[t] = mm16(pc[t], blk(Ls, jb + 1 + t, jb), Dv, true, li, lk); }
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+                if (jb + 1 + t < 4) {
+                    double *P = blk(Ls, jb + 1 + t, jb);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) P[(lk + 4 * r) * 65 + li] = pc[t][r];
+                }
+            wave_sync();
+            // trailing blocks (ib >= kb > jb): A[ib][kb] -= L[ib][jb] L[kb][jb]^T
+#pragma unroll 1
+            for (int kb = jb + 1; kb < 4; kb++)
+#pragma unroll 1
+                for (int ib = kb; ib < 4; ib++) {
+                    d4 acc = mm16(d4{0, 0, 0, 0}, blk(Ls, ib, jb), blk(Ls, kb, jb), true, li, lk);
+                    double *Cb = blk(Ls, ib, kb);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Cb[(lk + 4 * r) * 65 + li] -= acc[r];
+                }
+            wave_sync();
+        }
+    }
+    if (factor) {
+        if (!ok && lane == 0) *bad = 1;
         for (int r = 0; r < TB; r++) Ajj[(long long)r * ld + lane] = Ls[r * 65 + lane];
     }
-    // x[i] = (L^-1)[i][lane]: one forward substitution per lane; L[i][k] is broadcast from lane i's registers
-    double x[TB];
+    // L^-1 below its diagonal blocks, block column by block column: Linv[ib][jb] = -L16_ib^-1 sum_{jb <= kb < ib} L[ib][kb] Linv[kb][jb]
+    // (the product passes through the unused block (0, 3) of Ls to change from the result layout to the operand layout)
+    wave_sync();
+    double *Tmp = blk(Ls, 0, 3);
+#pragma unroll 1
+    for (int jb = 0; jb < 3; jb++)
+#pragma unroll 1
+        for (int ib = jb + 1; ib < 4; ib++) {
+            d4 acc = d4{0, 0, 0, 0};
+#pragma unroll 1
+            for (int kb = jb; kb < ib; kb++) acc = mm16(acc, blk(Ls, ib, kb), blk(Li, kb, jb), false, li, lk);
 #pragma unroll
-    for (int i = 0; i < TB; i++) {
-        double s = (lane == i) ? 1.0 : 0.0;
+            for (int r = 0; r < 4; r++) Tmp[(lk + 4 * r) * 65 + li] = acc[r];
+            wave_sync();
+            d4 res = mm16(d4{0, 0, 0, 0}, blk(Li, ib, ib), Tmp, false, li, lk);
+            double *Ob = blk(Li, ib, jb);
 #pragma unroll
-        for (int k = 0; k < i; k++) s -= readlane64(a[k], i) * x[k];
-        x[i] = (lane <= i) ? s * fast_rcp(readlane64(a[i], i)) : 0.0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < TB; i++) Ls[i * 65 + lane] = x[i];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int r = 0; r < TB; r++) Linv[r * TB + lane] = Ls[r * 65 + lane];
+            for (int r = 0; r < 4; r++) Ob[(lk + 4 * r) * 65 + li] = -res[r];
+            wave_sync();
+        }
+    for (int r = 0; r < TB; r++) Linv[r * TB + lane] = Li[r * 65 + lane];
 }
 
 __global__ __launch_bounds__(64) void diag_potrf_kernel(double *Ajj, int ld, double *Linv, int *bad, int factor) {
-    __shared__ double Ls[TB * 65];
-    diag_potrf_body(Ls, Ajj + (long long)blockIdx.x * TB * ((long long)ld + 1), ld, Linv + (long long)blockIdx.x * TB * TB, bad, factor);
+    __shared__ double Ls[TB * 65], Li[TB * 65];
+    diag_potrf_body(Ls, Li, Ajj + (long long)blockIdx.x * TB * ((long long)ld + 1), ld, Linv + (long long)blockIdx.x * TB * TB, bad, factor);
 }
 
 // pad rows [n, N) of an N x N matrix get a unit diagonal
@@ -785,49 +932,77 @@ __global__ __launch_bounds__(64) void big_right_mul_kernel(const double *Lam, in
     constexpr int DD = D * D;
     const int i = blockIdx.x, n = D * k, lane = threadIdx.x;
     auto S = [&](int r, int c) { return (c <= r) ? Lam[(long long)r * ldl + c] : Lam[(long long)c * ldl + r]; };
-    for (int j = lane; j < n; j += 64) {
+    for (int j = D + lane; j < n; j += 64) {
         const int b = j / D, c = j - b * D;
+        const double *Tbb = Jinv + (size_t)b * 2 * DD + DD;
         double sacc = 0;
-        if (b > 0) {
-            const double *Tbb = Jinv + (size_t)b * 2 * DD + DD;
 #pragma unroll
-            for (int p = 0; p < D; p++) sacc += S(i, b * D + p) * Tbb[p * D + c];
-        } else {
-            const double *T00 = Jinv + DD;
-#pragma unroll
-            for (int p = 0; p < D; p++) sacc += S(i, p) * T00[p * D + c];
-            for (int cb = 1; cb < k; cb++) {
-                const double *Tc0 = Jinv + (size_t)cb * 2 * DD;
-#pragma unroll
-                for (int p = 0; p < D; p++) sacc += S(i, cb * D + p) * Tc0[p * D + c];
-            }
-        }
+        for (int p = 0; p < D; p++) sacc += S(i, b * D + p) * Tbb[p * D + c];
         Y[(long long)i * ldy + j] = sacc;
+    }
+    // the d columns of block 0 are sums over the whole row: the lanes share the row (entry t of it per lane and step),
+    // each with d partial sums, and a butterfly adds them up (one lane per column used to walk the n terms alone)
+    double part[D];
+#pragma unroll
+    for (int c = 0; c < D; c++) part[c] = 0.0;
+    for (int t = lane; t < n; t += 64) {
+        const int cb = t / D, p = t - cb * D;
+        const double *Tc = (cb == 0) ? Jinv + DD : Jinv + (size_t)cb * 2 * DD;
+        const double sv = S(i, t);
+#pragma unroll
+        for (int c = 0; c < D; c++) part[c] += sv * Tc[p * D + c];
+    }
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part[c] += __shfl_xor(part[c], o, 64);
+        if (lane == c) Y[(long long)i * ldy + c] = part[c];
     }
 }
 // Mt = T^T Y (n x n): row block a > 0: T_aa^T Y[a, :]; row block 0: T_00^T Y[0, :] + sum_{c > 0} T_c0^T Y[c, :].
+// blockIdx.x < n - d: row d + blockIdx.x, lanes over the columns. The remaining workgroups take the d rows of block 0 —
+// sums over ALL rows of Y — for 64 columns each: lane = column, the four wavefronts split the row blocks of Y (one read of
+// Y serves the d rows), partial sums meet in LDS. (One wavefront per such row walked the n terms of each of its columns
+// alone: 243 us, four times the rest of the kernel.)
 template <int D>
-__global__ __launch_bounds__(64) void big_left_mul_kernel(const double *Y, int ldy, int k, const double *Jinv, double *Mt, int ldm) {
+__global__ __launch_bounds__(256) void big_left_mul_kernel(const double *Y, int ldy, int k, const double *Jinv, double *Mt, int ldm) {
     constexpr int DD = D * D;
-    const int i = blockIdx.x, n = D * k, lane = threadIdx.x;
-    const int a = i / D, r = i - a * D;
-    for (int j = lane; j < n; j += 64) {
-        double sacc = 0;
-        if (a > 0) {
-            const double *Taa = Jinv + (size_t)a * 2 * DD + DD;
+    __shared__ double red[3][D][64];
+    const int n = D * k, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if ((int)blockIdx.x < n - D) {
+        const int i = D + blockIdx.x, a = i / D, r = i - a * D;
+        const double *Taa = Jinv + (size_t)a * 2 * DD + DD;
+        for (int j = tid; j < n; j += 256) {
+            double sacc = 0;
 #pragma unroll
             for (int p = 0; p < D; p++) sacc += Taa[p * D + r] * Y[(long long)(a * D + p) * ldy + j];
-        } else {
-            const double *T00 = Jinv + DD;
-#pragma unroll
-            for (int p = 0; p < D; p++) sacc += T00[p * D + r] * Y[(long long)p * ldy + j];
-            for (int cb = 1; cb < k; cb++) {
-                const double *Tc0 = Jinv + (size_t)cb * 2 * DD;
-#pragma unroll
-                for (int p = 0; p < D; p++) sacc += Tc0[p * D + r] * Y[(long long)(cb * D + p) * ldy + j];
-            }
+            Mt[(long long)i * ldm + j] = sacc;
         }
-        Mt[(long long)i * ldm + j] = sacc;
+        return;
+    }
+    const int j = ((int)blockIdx.x - (n - D)) * 64 + lane;
+    double acc[D];
+#pragma unroll
+    for (int r = 0; r < D; r++) acc[r] = 0.0;
+    if (j < n)
+        for (int cb = w; cb < k; cb += 4) {
+            const double *Tc = (cb == 0) ? Jinv + DD : Jinv + (size_t)cb * 2 * DD;
+            double yv[D];
+#pragma unroll
+            for (int p = 0; p < D; p++) yv[p] = Y[(long long)(cb * D + p) * ldy + j];
+#pragma unroll
+            for (int p = 0; p < D; p++)
+#pragma unroll
+                for (int r = 0; r < D; r++) acc[r] += Tc[p * D + r] * yv[p];
+        }
+    if (w > 0) {
+#pragma unroll
+        for (int r = 0; r < D; r++) red[w - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (w == 0 && j < n) {
+#pragma unroll
+        for (int r = 0; r < D; r++) Mt[(long long)r * ldm + j] = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
     }
 }
 // Mrel (Nr x Nr, zeroed, padded with a unit diagonal) <- sym(Mt)[D.., D..] ; stats[0] = max |sym(Mt)| over the first D
@@ -971,19 +1146,18 @@ struct GraphBufs {
     bool has_glc = false;
 };
 
-int stage_graph(const spg::DenseGraphIn &in, GraphBufs &gb, hipStream_t s) {
-    std::vector<int64_t> awoff((size_t)in.ne, -1);
-    int64_t aw_total = 0;
+// per-edge offsets of the weighted Jacobians of n-ary edges (A_e and the weighted error) and what their staging needs
+int plan_graph(const spg::DenseGraphIn &in, GraphBufs &gb, std::vector<int64_t> &awoff, int64_t &aw_total) {
+    awoff.assign((size_t)in.ne, -1);
+    aw_total = 0;
     for (int e = 0; e < in.ne; e++) {
         if (in.er[e].kind == SPG_EDGE_BINARY) continue;
         int q = in.er[e].nv, dq = in.D * q;
         if (in.er[e].kind == SPG_EDGE_MULTI) {
             // r = d nm rows; nm = q - 1 for the patterns that emit such edges, never more than len allows
-            const int ps = in.D == 6 ? 7 : 3;
             int nm = 1;
             while (SPG_MULTI_LEN(in.D, nm) < in.er[e].len) nm++;
             if (q < 2 || SPG_MULTI_LEN(in.D, nm) != in.er[e].len) return SPG_EINVAL;
-            (void)ps;
             awoff[e] = aw_total;
             aw_total += (int64_t)in.D * nm * dq + in.D * nm;
             gb.max_q = std::max(gb.max_q, std::max(q, nm + 1));
@@ -997,7 +1171,14 @@ int stage_graph(const spg::DenseGraphIn &in, GraphBufs &gb, hipStream_t s) {
         gb.has_glc = true;
     }
     if ((size_t)gb.max_q * (2 * in.D * in.D + in.D) * sizeof(double) > 160 * 1024) return SPG_ECAPACITY;   // LDS staging of one GLC edge's Jacobians
+    return 0;
+}
+
+int stage_graph(const spg::DenseGraphIn &in, GraphBufs &gb, hipStream_t s) {
+    std::vector<int64_t> awoff;
+    int64_t aw_total = 0;
     int rc;
+    if ((rc = plan_graph(in, gb, awoff, aw_total))) return rc;
     if ((rc = upload(gb.pos, in.pos, (size_t)in.nv, s))) return rc;
     if ((rc = upload(gb.vpo, in.vpo, (size_t)in.nv, s))) return rc;
     if ((rc = upload(gb.rowptr, in.rowptr, (size_t)in.nv + 1, s))) return rc;
@@ -1033,9 +1214,17 @@ void launch_assemble(const GraphBufs &gb, double *M, int ld, hipStream_t s, doub
     launch_assemble_into<D>(gb, DenseSink{M, ld}, s, bvec);
 }
 
+constexpr int kSmallTileSteps = 128;   // steps of at most this many 128-tiles take tile_abt_small_kernel
+
 void launch_tiles(const TileOp &op, hipStream_t s) {
     if (op.P64 <= 0 || op.Q64 <= 0) return;
     const int gp = (op.P64 + 1) / 2, gq = (op.Q64 + 1) / 2;
+    const int big_tiles = op.tri ? gp * (gp + 1) / 2 : gp * gq;
+    if (big_tiles <= kSmallTileSteps) {      // a step that cannot fill the chip: latency form
+        if (op.tri) hipLaunchKernelGGL(tile_abt_small_kernel, dim3(op.P64 * (op.P64 + 1) / 2), dim3(256), 0, s, op);
+        else hipLaunchKernelGGL(tile_abt_small_kernel, dim3(op.P64, op.Q64), dim3(256), 0, s, op);
+        return;
+    }
     if (op.tri) hipLaunchKernelGGL(tile_abt_kernel, dim3(gp * (gp + 1) / 2), dim3(256), 0, s, op);
     else hipLaunchKernelGGL(tile_abt_kernel, dim3(gp, gq), dim3(256), 0, s, op);
 }
@@ -1114,7 +1303,31 @@ void rsolve_lower_transposed(double *Y, int ldy, const double *Ls, int ld, int N
 
 inline int round_up(int n) { return (n + TB - 1) / TB * TB; }
 
-// One large GLC Dense blanket, asynchronously on `stream` up to the final synchronisation that releases the scratch.
+// Scratch of the large-blanket pipeline: one device block and one pinned staging block per process, grown on demand and
+// kept (a blanket used to pay 20 hipMalloc / hipFree pairs and 7 synchronous copies). Calls are serialised by `mu`; each
+// ends with a stream synchronisation, so the blocks are idle when the next call lays them out.
+struct BigPool {
+    std::mutex mu;
+    int device = -1;
+    char *dev = nullptr, *pin = nullptr;
+    size_t dcap = 0, pcap = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    void drop() {
+        if (dev) (void)hipFree(dev);
+        if (pin) (void)hipHostFree(pin);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        dev = pin = nullptr; dcap = pcap = 0; e0 = e1 = nullptr; device = -1;
+    }
+};
+BigPool &big_pool() { static BigPool *p = new BigPool; return *p; }
+
+struct Carver {      // offsets into a block, 256-byte aligned
+    size_t used = 0;
+    size_t take(size_t bytes) { size_t at = used; used += (bytes + 255) & ~(size_t)255; return at; }
+};
+
+// One large GLC Dense blanket, asynchronously on `stream` up to the final synchronisation.
 // in: the blanket as a local graph (vertices = blanket-local indices, removed first; pos[l] = l*D for removed vertices,
 // Nm + (l - m)*D for kept ones, Nm = nm rounded up to 64). The new edge record goes to arena[new_off ...), the out
 // record (include/spg.h) to orec (device address: arena or pinned mailbox).
@@ -1125,74 +1338,110 @@ static int big_glc_dense_impl(hipStream_t s, const spg::DenseGraphIn &in, int m,
     constexpr int DD = D * D;
     const int n = D * k, nm = D * m, Ng = round_up(std::max(n, 1)), N = Nm + Ng, Nr = round_up(std::max(n - D, 1)), ntr = Nr / TB;
     double *arena = (double *)const_cast<void *>(in.dev_arena);
-    GraphBufs gb;
-    DevBuf H, Y, Mt, Mrel, Yi, linv, linv_all, flags, stats, partial, jinv, meas, vpo_d;
     const int np = 256;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0;
-    if (hipMalloc(&H.p, (size_t)N * N * 8) != hipSuccess || hipMalloc(&Y.p, (size_t)Ng * Ng * 8) != hipSuccess ||
-        hipMalloc(&Mt.p, (size_t)Ng * Ng * 8) != hipSuccess || hipMalloc(&Mrel.p, (size_t)Nr * Nr * 8) != hipSuccess ||
-        hipMalloc(&Yi.p, (size_t)Nr * Nr * 8) != hipSuccess) {
-        snprintf(err, errlen, "hipMalloc of the dense matrices of a large blanket failed (N = %d)", N);
-        return SPG_ENOMEM;
+    BigPool &P = big_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    int dev_now = 0;
+    GraphBufs gb;                      // (its DevBufs stay empty: everything lives in the pool)
+    std::vector<int64_t> awoff;
+    int64_t aw_total = 0;
+    if ((rc = plan_graph(in, gb, awoff, aw_total))) { snprintf(err, errlen, "staging a large blanket failed (%d)", rc); return rc; }
+    // ---- layout: matrices, small state, then the staged block (the graph arrays), mirrored in pinned memory
+    Carver dc, pc;
+    const size_t oH = dc.take((size_t)N * N * 8), oY = dc.take((size_t)Ng * Ng * 8), oMt = dc.take((size_t)Ng * Ng * 8);
+    const size_t oMrel = dc.take((size_t)Nr * Nr * 8), oYi = dc.take((size_t)Nr * Nr * 8);      // adjacent: cleared together
+    const size_t oLinv = dc.take(TB * TB * 8), oLinvAll = dc.take((size_t)ntr * TB * TB * 8);
+    const size_t oState = dc.take(256);       // flags (8 ints) | stats (2 doubles) — cleared together
+    const size_t oPartial = dc.take(np * 8), oJinv = dc.take((size_t)std::max(k, 1) * 2 * DD * 8), oMeas = dc.take((size_t)std::max(n, 1) * 8);
+    const size_t oAw = dc.take((size_t)std::max<int64_t>(aw_total, 1) * 8);
+    const size_t n_inc = (size_t)in.rowptr[in.nv];
+    const size_t sPos = pc.take((size_t)in.nv * 4), sVpo = pc.take((size_t)in.nv * 8), sRow = pc.take(((size_t)in.nv + 1) * 4), sInc = pc.take(std::max<size_t>(n_inc, 1) * 4);
+    const size_t sEr = pc.take(std::max<size_t>(in.ne, 1) * sizeof(spg_edge_ref)), sEv = pc.take(std::max<size_t>((size_t)in.n_ev, 1) * 4), sAwoff = pc.take(std::max<size_t>(in.ne, 1) * 8);
+    const size_t oStaged = dc.take(pc.used);
+    HIPCHK(hipGetDevice(&dev_now));
+    if (P.device != dev_now || P.dcap < dc.used || P.pcap < pc.used) {
+        if (P.device != dev_now) P.drop();
+        if (P.dcap < dc.used) {
+            if (P.dev) { (void)hipFree(P.dev); P.dev = nullptr; P.dcap = 0; }
+            const size_t want = dc.used + dc.used / 4;
+            if (hipMalloc((void **)&P.dev, want) != hipSuccess) {
+                (void)hipGetLastError();
+                snprintf(err, errlen, "hipMalloc of the dense matrices of a large blanket failed (N = %d, %.1f MB)", N, 1e-6 * (double)want);
+                return SPG_ENOMEM;
+            }
+            P.dcap = want;
+        }
+        if (P.pcap < pc.used) {
+            if (P.pin) { (void)hipHostFree(P.pin); P.pin = nullptr; P.pcap = 0; }
+            const size_t want = pc.used + pc.used / 4;
+            HIPCHK(hipHostMalloc((void **)&P.pin, want, hipHostMallocDefault));
+            P.pcap = want;
+        }
+        if (!P.e0) { HIPCHK(hipEventCreate(&P.e0)); HIPCHK(hipEventCreate(&P.e1)); }
+        P.device = dev_now;
     }
-    HIPCHK(hipMalloc(&linv.p, TB * TB * 8));
-    HIPCHK(hipMalloc(&linv_all.p, (size_t)ntr * TB * TB * 8));
-    HIPCHK(hipMalloc(&flags.p, 8 * sizeof(int)));
-    HIPCHK(hipMalloc(&stats.p, 2 * 8));
-    HIPCHK(hipMalloc(&partial.p, np * 8));
-    HIPCHK(hipMalloc(&jinv.p, (size_t)std::max(k, 1) * 2 * DD * 8));
-    HIPCHK(hipMalloc(&meas.p, (size_t)std::max(n, 1) * 8));
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    if ((rc = stage_graph(in, gb, s))) { snprintf(err, errlen, "staging a large blanket failed (%d)", rc); goto done; }
-    HIPCHK(hipEventRecord(e0, s));
-    HIPCHK(hipMemsetAsync(H.p, 0, (size_t)N * N * 8, s));
-    HIPCHK(hipMemsetAsync(Mrel.p, 0, (size_t)Nr * Nr * 8, s));
-    HIPCHK(hipMemsetAsync(Yi.p, 0, (size_t)Nr * Nr * 8, s));
-    HIPCHK(hipMemsetAsync(flags.p, 0, 8 * sizeof(int), s));
-    HIPCHK(hipMemsetAsync(stats.p, 0, 2 * 8, s));
-    launch_assemble<D>(gb, (double *)H.p, N, s);
-    if (Nm > nm) hipLaunchKernelGGL(pad_identity_kernel, dim3((Nm - nm + 255) / 256), dim3(256), 0, s, (double *)H.p, N, nm, Nm);
-    if (Ng > n) hipLaunchKernelGGL(pad_identity_kernel, dim3((Ng - n + 255) / 256), dim3(256), 0, s, (double *)H.p, N, Nm + n, N);
-    // Schur complement onto the kept block: the factorisation stops where that block begins
-    potrf_lower((double *)H.p, N, (double *)linv.p, (int *)flags.p, s, Nm / TB);
     {
-        const double *Lam = (const double *)H.p + ((long long)Nm * N + Nm);
-        BigArrow ar{(double *)jinv.p, (double *)meas.p};
-        hipLaunchKernelGGL((big_reparam_kernel<D>), dim3((k + 63) / 64), dim3(64), 0, s, (const double *)arena, gb.dev.vpo, m, k, ar, (int *)flags.p + 1);
+        double *H = (double *)(P.dev + oH), *Y = (double *)(P.dev + oY), *Mt = (double *)(P.dev + oMt), *Mrel = (double *)(P.dev + oMrel), *Yi = (double *)(P.dev + oYi);
+        double *linv = (double *)(P.dev + oLinv), *linv_all = (double *)(P.dev + oLinvAll), *partial = (double *)(P.dev + oPartial);
+        double *jinv = (double *)(P.dev + oJinv), *meas = (double *)(P.dev + oMeas);
+        int *flags = (int *)(P.dev + oState);
+        double *stats = (double *)(P.dev + oState + 64);
+        char *staged = P.dev + oStaged;
+        // ---- the staged block
+        memcpy(P.pin + sPos, in.pos, (size_t)in.nv * 4);
+        memcpy(P.pin + sVpo, in.vpo, (size_t)in.nv * 8);
+        memcpy(P.pin + sRow, in.rowptr, ((size_t)in.nv + 1) * 4);
+        if (n_inc) memcpy(P.pin + sInc, in.inc, n_inc * 4);
+        if (in.ne) memcpy(P.pin + sEr, in.er, (size_t)in.ne * sizeof(spg_edge_ref));
+        if (in.n_ev) memcpy(P.pin + sEv, in.ev, (size_t)in.n_ev * 4);
+        if (in.ne) memcpy(P.pin + sAwoff, awoff.data(), (size_t)in.ne * 8);
+        HIPCHK(hipMemcpyAsync(staged, P.pin, pc.used, hipMemcpyHostToDevice, s));
+        gb.dev = GraphDev{(const double *)in.dev_arena, (const int32_t *)(staged + sPos), (const int64_t *)(staged + sVpo),
+                          (const int32_t *)(staged + sRow), (const int32_t *)(staged + sInc), (const spg_edge_ref *)(staged + sEr),
+                          (const int32_t *)(staged + sEv), (const int64_t *)(staged + sAwoff), (double *)(P.dev + oAw), in.nv, in.ne};
+        HIPCHK(hipEventRecord(P.e0, s));
+        HIPCHK(hipMemsetAsync(H, 0, (size_t)N * N * 8, s));
+        HIPCHK(hipMemsetAsync(Mrel, 0, (oYi - oMrel) + (size_t)Nr * Nr * 8, s));      // M_rel and Yi
+        HIPCHK(hipMemsetAsync(flags, 0, 256, s));
+        launch_assemble<D>(gb, H, N, s);
+        if (Nm > nm) hipLaunchKernelGGL(pad_identity_kernel, dim3((Nm - nm + 255) / 256), dim3(256), 0, s, H, N, nm, Nm);
+        if (Ng > n) hipLaunchKernelGGL(pad_identity_kernel, dim3((Ng - n + 255) / 256), dim3(256), 0, s, H, N, Nm + n, N);
+        // Schur complement onto the kept block: the factorisation stops where that block begins
+        potrf_lower(H, N, linv, flags, s, Nm / TB);
+        const double *Lam = H + ((long long)Nm * N + Nm);
+        BigArrow ar{jinv, meas};
+        hipLaunchKernelGGL((big_reparam_kernel<D>), dim3((k + 63) / 64), dim3(64), 0, s, (const double *)arena, gb.dev.vpo, m, k, ar, flags + 1);
         if (k > 1) hipLaunchKernelGGL((big_arrow_finish_kernel<D>), dim3((k + 62) / 64), dim3(64), 0, s, k, ar);
-        hipLaunchKernelGGL((big_right_mul_kernel<D>), dim3(n), dim3(64), 0, s, Lam, N, k, (const double *)jinv.p, (double *)Y.p, Ng);
-        hipLaunchKernelGGL((big_left_mul_kernel<D>), dim3(n), dim3(64), 0, s, (const double *)Y.p, Ng, k, (const double *)jinv.p, (double *)Mt.p, Ng);
-        hipLaunchKernelGGL((big_extract_kernel<D>), dim3(256), dim3(256), 0, s, (const double *)Mt.p, Ng, n, (double *)Mrel.p, Nr, (double *)stats.p);
-        if (Nr > n - D) hipLaunchKernelGGL(pad_identity_kernel, dim3((Nr - (n - D) + 255) / 256), dim3(256), 0, s, (double *)Mrel.p, Nr, n - D, Nr);
-        potrf_lower((double *)Mrel.p, Nr, (double *)linv.p, (int *)flags.p + 2, s);
+        hipLaunchKernelGGL((big_right_mul_kernel<D>), dim3(n), dim3(64), 0, s, Lam, N, k, (const double *)jinv, Y, Ng);
+        hipLaunchKernelGGL((big_left_mul_kernel<D>), dim3(n - D + (n + 63) / 64), dim3(256), 0, s, (const double *)Y, Ng, k, (const double *)jinv, Mt, Ng);
+        hipLaunchKernelGGL((big_extract_kernel<D>), dim3(256), dim3(256), 0, s, (const double *)Mt, Ng, n, Mrel, Nr, stats);
+        if (Nr > n - D) hipLaunchKernelGGL(pad_identity_kernel, dim3((Nr - (n - D) + 255) / 256), dim3(256), 0, s, Mrel, Nr, n - D, Nr);
+        hipLaunchKernelGGL(pad_identity_kernel, dim3((Nr + 255) / 256), dim3(256), 0, s, Yi, Nr, 0, Nr);
         // lambda_min(M_rel) > 1e-8 is proven by trace(M_rel^-1) = ||L^-T||_F^2 < 1e8
-        hipLaunchKernelGGL(pad_identity_kernel, dim3((Nr + 255) / 256), dim3(256), 0, s, (double *)Yi.p, Nr, 0, Nr);
-        rsolve_lower_transposed((double *)Yi.p, Nr, (const double *)Mrel.p, Nr, Nr, (double *)linv_all.p, (int *)flags.p + 3, s);
-        hipLaunchKernelGGL(sumsq_kernel, dim3(np), dim3(256), 0, s, (const double *)Yi.p, Nr, n - D, (double *)partial.p);
+        potrf_lower(Mrel, Nr, linv, flags + 2, s);
+        rsolve_lower_transposed(Yi, Nr, Mrel, Nr, Nr, linv_all, flags + 3, s);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(np), dim3(256), 0, s, (const double *)Yi, Nr, n - D, partial);
         const long long rec_len = (long long)n + (long long)(n - D) * n;
-        hipLaunchKernelGGL((big_write_record_kernel<D>), dim3(512), dim3(256), 0, s, (const double *)Mrel.p, Nr, n, (const double *)meas.p, arena + new_off);
+        hipLaunchKernelGGL((big_write_record_kernel<D>), dim3(512), dim3(256), 0, s, (const double *)Mrel, Nr, n, (const double *)meas, arena + new_off);
         {
             // the eigen route, taken inside the kernel only when the shortcut's guard failed: A in Y (free since the left
             // multiplication), V and the small scratch in H (free since the Schur complement was read)
-            double *Vs = (double *)H.p, *cs = Vs + (size_t)Ng * Ng;
+            double *Vs = H, *cs = Vs + (size_t)Ng * Ng;
             int *perm = reinterpret_cast<int *>(cs + n + 2);
             static_assert(TB >= 16, "the scratch behind V assumes N^2 - Ng^2 >= 2 n + 2");
-            hipLaunchKernelGGL(big_glc_eig_kernel, dim3(1), dim3(1024), 0, s, (int *)flags.p, (const double *)stats.p, (const double *)partial.p, np,
-                               (const double *)Mt.p, Ng, n, n - D, (double *)Y.p, Vs, Ng, cs, perm, (const double *)meas.p, arena + new_off);
+            hipLaunchKernelGGL(big_glc_eig_kernel, dim3(1), dim3(1024), 0, s, flags, (const double *)stats, (const double *)partial, np,
+                               (const double *)Mt, Ng, n, n - D, Y, Vs, Ng, cs, perm, (const double *)meas, arena + new_off);
         }
-        hipLaunchKernelGGL(big_out_record_kernel, dim3(1), dim3(256), 0, s, orec, (const int *)flags.p, (const double *)stats.p, (const double *)partial.p, np,
+        hipLaunchKernelGGL(big_out_record_kernel, dim3(1), dim3(256), 0, s, orec, (const int *)flags, (const double *)stats, (const double *)partial, np,
                            n, D, m, k, n_new_max, tag, rec_len);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(P.e1, s));
+        HIPCHK(hipStreamSynchronize(s));   // the pool is laid out anew by the next call
+        HIPCHK(hipEventElapsedTime(&ms, P.e0, P.e1));
+        if (seconds) *seconds = 1e-3 * ms;
     }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e1, s));
-    HIPCHK(hipStreamSynchronize(s));   // the scratch is released below
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    if (seconds) *seconds = 1e-3 * ms;
 done:
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
     return rc;
 }
 
@@ -1269,6 +1518,12 @@ int hip_dense_covariance(void *stream, const DenseGraphIn &in, int n, double *ou
         for (int j = 0; j < n; j++) out[(size_t)i * n + j] = (j <= i) ? h[(size_t)i * N + j] : h[(size_t)j * N + i];
 done:
     return rc;
+}
+
+void hip_big_release_scratch() {
+    BigPool &P = big_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    P.drop();
 }
 
 int hip_big_glc_dense(void *stream, const DenseGraphIn &in, int m, int k, int Nm, int64_t new_off, double *orec, int n_new_max, int tag,

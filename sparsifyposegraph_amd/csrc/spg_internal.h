@@ -73,6 +73,8 @@ int hip_dense_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &ot
 // One GLC Dense blanket too large for the LDS kernel, dense in HBM on the fp64 matrix cores (spg_dense.hip)
 int hip_big_glc_dense(void *stream, const DenseGraphIn &local_graph, int m, int k, int Nm, int64_t new_off, double *orec, int n_new_max, int tag,
                       double *seconds, double *flops, char *err, size_t errlen);
+// frees the scratch the large-blanket pipeline keeps between calls (device block + pinned staging); called when a backend goes
+void hip_big_release_scratch();
 int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iterations, double *stats, double *seconds,
                        char *err, size_t errlen);
 

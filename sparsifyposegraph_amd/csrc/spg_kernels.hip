@@ -2505,6 +2505,7 @@ void hip_backend_destroy(spg_backend *b) {
         for (auto &pr : S.pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         (void)hipStreamDestroy(S.stream);
     }
+    spg::hip_big_release_scratch();
     delete hb;
     b->user = nullptr;
 }

@@ -39,6 +39,12 @@ constexpr int RIF = 4;    // rows in flight per wavefront in the trailing update
 #else
 #define IPT(k) do { } while (0)
 #endif
+// phases of the closed-form path of a cluster (development builds with -DSPG_CF_PROF print them per blanket)
+#ifdef SPG_CF_PROF
+#define CFP(k) do { __syncthreads(); long long t_ = wall_clock64(); cfp[k] += t_ - cfp_last; cfp_last = t_; } while (0)
+#else
+#define CFP(k) do { } while (0)
+#endif
 constexpr int kPanelDoubles = 8192;   // 64 KB: 16 columns of a panel up to 480 rows tall, fewer columns for taller ones
 
 struct IpLayout {   // offsets (doubles) of one blanket's buffers: a cold part in the global workspace, a hot part (everything the
@@ -202,6 +208,211 @@ __device__ __forceinline__ void chol_lower_reg(int tid, double *A, int n, int ld
     __syncthreads();
 }
 
+// C (M x N, row-major, ldc) = / += / -= op(A) op(B) by one workgroup on the fp64 matrix cores, operands in the L2 workspace
+// (or LDS). op(A) is M x K: A[i * lda + k], or A[k * lda + i] when ta; op(B) is K x N: B[k * ldb + j], or B[j * ldb + k]
+// when tb. The scalar loops this replaces (one lane per output entry, two reads per FMA) ran a 600 x 600 x 600 product of a
+// cluster in 100-190 ms, 2 GFMA/s. 64 x 64 output tiles; wavefront w owns rows 16 w .. 16 w + 15 of the tile as four
+// v_mfma_f64_16x16x4_f64 accumulators; K in chunks of 32 staged through LDS as As[i][k], Bs[j][k] (row stride 34: the
+// fragment reads of a half wave fall on distinct bank pairs), the next chunk already in registers while the matrix
+// cores work on the current one. lower_only skips the tiles strictly above the block diagonal (M = N products whose
+// upper part is mirrored or not needed). lds: 2 * 64 * 34 doubles. mode 0: C = AB, 1: C += AB, 2: C -= AB.
+constexpr int kGemmLds = 2 * 64 * 34;
+template <int NT_>
+__device__ void team_gemm(const Team<NT_> T, double *C, int ldc, const double *A, int lda, bool ta, const double *B, int ldb, bool tb,
+                          int M, int N, int K, int mode, bool lower_only, double *lds) {
+    static_assert(NT_ == 256, "four wavefronts per tile");
+    using d4 = __attribute__((ext_vector_type(4))) double;
+    constexpr int KC = 32, LDK = 34;
+    double *As = lds, *Bs = lds + 64 * LDK;
+    const int tid = T.tid, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+    // staging maps. k-contiguous operand: thread -> (row tid / 4, 8 consecutive k at (tid & 3) * 8);
+    // row-contiguous (transposed) operand: thread -> (k = tid / 8, 8 consecutive rows at (tid & 7) * 8)
+    const int rA = ta ? (tid & 7) * 8 : tid >> 2, kA = ta ? tid >> 3 : (tid & 3) * 8;
+    const int rB = tb ? tid >> 2 : (tid & 7) * 8, kB = tb ? (tid & 3) * 8 : tid >> 3;
+    for (int i0 = 0; i0 < M; i0 += 64)
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            if (lower_only && j0 > i0) continue;
+            d4 acc[4];
+#pragma unroll
+            for (int y = 0; y < 4; y++) acc[y] = d4{0, 0, 0, 0};
+            double ra[8], rb[8];
+            auto fetch = [&](int k0) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (ta) { const int i = i0 + rA + u, kk = k0 + kA; ra[u] = (i < M && kk < K) ? A[(long long)kk * lda + i] : 0.0; }
+                    else    { const int i = i0 + rA, kk = k0 + kA + u; ra[u] = (i < M && kk < K) ? A[(long long)i * lda + kk] : 0.0; }
+                    if (tb) { const int j = j0 + rB, kk = k0 + kB + u; rb[u] = (j < N && kk < K) ? B[(long long)j * ldb + kk] : 0.0; }
+                    else    { const int j = j0 + rB + u, kk = k0 + kB; rb[u] = (j < N && kk < K) ? B[(long long)kk * ldb + j] : 0.0; }
+                }
+            };
+            fetch(0);
+            for (int k0 = 0; k0 < K; k0 += KC) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (ta) As[(rA + u) * LDK + kA] = ra[u]; else As[rA * LDK + kA + u] = ra[u];
+                    if (tb) Bs[rB * LDK + kB + u] = rb[u]; else Bs[(rB + u) * LDK + kB] = rb[u];
+                }
+                T.sync();
+                if (k0 + KC < K) fetch(k0 + KC);
+#pragma unroll
+                for (int kk = 0; kk < KC; kk += 4) {
+                    const double av = As[(16 * w + li) * LDK + kk + lk];
+#pragma unroll
+                    for (int y = 0; y < 4; y++) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bs[(16 * y + li) * LDK + kk + lk], acc[y], 0, 0, 0);
+                }
+                T.sync();
+            }
+            // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const int row = i0 + 16 * w + lk + 4 * r4, col = j0 + 16 * y + li;
+                    if (row < M && col < N) {
+                        double *dst = C + (long long)row * ldc + col;
+                        const double v = acc[y][r4];
+                        *dst = mode == 0 ? v : (mode == 1 ? *dst + v : *dst - v);
+                    }
+                }
+        }
+    T.sync();
+}
+
+// Li = L^-1 (lower; strict upper zeroed) for a matrix of a cluster, in block columns of 64: the diagonal block is inverted by
+// one lane per column as tri_inverse_lower does, the block below it is  -Li[below, below] (L[below, jb] Li[jb, jb])  — two
+// products on the matrix cores, right to left so that the inverse of the trailing block is already in place. Li may not
+// alias L; tmp: (n - 64) x 64 doubles of workspace. (tri_inverse_lower: 39 ms at n = 600, three calls per cluster.)
+template <int NT_>
+__device__ void tri_inverse_lower_blocked(const Team<NT_> T, const double *L, int ldl, double *Li, int ldi, int n, double *tmp, double *lds) {
+    const int tid = T.tid;
+    for (long long it = tid; it < (long long)n * n; it += NT_) { const int i = (int)(it / n), j = (int)(it - (long long)i * n); if (j > i) Li[(long long)i * ldi + j] = 0.0; }
+    const int nb = (n + 63) / 64;
+    for (int jb = nb - 1; jb >= 0; jb--) {
+        const int j0 = jb * 64, w = min(64, n - j0), below = n - j0 - w;
+        // diagonal block: one lane per column
+        if (tid < w) {
+            const int c = j0 + tid;
+            Li[(long long)c * ldi + c] = fast_rcp(L[(long long)c * ldl + c]);
+            for (int i = c + 1; i < j0 + w; i++) {
+                double sacc = 0;
+                for (int k2 = c; k2 < i; k2++) sacc += L[(long long)i * ldl + k2] * Li[(long long)k2 * ldi + c];
+                Li[(long long)i * ldi + c] = -sacc * fast_rcp(L[(long long)i * ldl + i]);
+            }
+        }
+        T.sync();
+        if (below > 0) {
+            // tmp = L[below, jb] * Li[jb, jb]   (below x w, K = w)
+            team_gemm<NT_>(T, tmp, 64, L + (long long)(j0 + w) * ldl + j0, ldl, false, Li + (long long)j0 * ldi + j0, ldi, false, below, w, w, 0, false, lds);
+            // Li[below, jb] = -Li[below, below] * tmp   (K = below; the factor is lower triangular with zeros above)
+            team_gemm<NT_>(T, Li + (long long)(j0 + w) * ldi + j0, ldi, Li + (long long)(j0 + w) * ldi + j0 + w, ldi, false, tmp, 64, false, below, w, below, 0, false, lds);
+            for (long long it = tid; it < (long long)below * w; it += NT_) {
+                const int i = (int)(it / w), c = (int)(it - (long long)i * w);
+                double *e = Li + (long long)(j0 + w + i) * ldi + j0 + c;
+                *e = -*e;
+            }
+            T.sync();
+        }
+    }
+}
+
+// In-place lower Cholesky of a cluster's matrix (n x n in the L2 workspace, leading dimension ld; lower triangle read and
+// written) in block columns of 64 with the trailing update on the matrix cores: the diagonal block is factorised in LDS
+// (chol_lower, the LDS routine) and inverted there, the panel below it is its product with that inverse, the trailing
+// matrix takes P P^T through team_gemm (lower block triangle, K = 64). lds: 64 * 65 doubles (the same region team_gemm
+// stages through — the two never run together); tmp: (n + 64) * 65 doubles of workspace. Failure as chol_lower: *T.flag = 1.
+template <int NT_>
+__device__ void chol_lower_blocked(const Team<NT_> T, double *A, int n, int ld, double *tmp, double *lds) {
+    static_assert(kGemmLds >= 64 * 65, "the diagonal block borrows the staging area of team_gemm");
+    const int tid = T.tid;
+    double *Db = lds, *Dinv = tmp, *P = tmp + 64 * 65;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int w = min(64, n - j0), below = n - j0 - w;
+        for (int it = tid; it < w * w; it += NT_) { const int i = it / w, c = it - i * w; Db[i * 65 + c] = (c <= i) ? A[(long long)(j0 + i) * ld + j0 + c] : 0.0; }
+        T.sync();
+        chol_lower<NT_>(T, Db, w, 65);
+        for (int it = tid; it < w * w; it += NT_) { const int i = it / w, c = it - i * w; if (c <= i) A[(long long)(j0 + i) * ld + j0 + c] = Db[i * 65 + c]; }
+        if (below == 0) { T.sync(); break; }
+        tri_inverse_lower<NT_>(T, Db, Dinv, w, 65);       // (reads the factor from LDS with stride 65, writes with the same stride)
+        // (tri_inverse_lower uses one leading dimension for both matrices: Dinv has row stride 65 too)
+        team_gemm<NT_>(T, P, 64, A + (long long)(j0 + w) * ld + j0, ld, false, Dinv, 65, true, below, w, w, 0, false, lds);     // P = A21 L11^-T
+        for (long long it = tid; it < (long long)below * w; it += NT_) {
+            const int i = (int)(it / w), c = (int)(it - (long long)i * w);
+            A[(long long)(j0 + w + i) * ld + j0 + c] = P[(long long)i * 64 + c];
+        }
+        T.sync();
+        team_gemm<NT_>(T, A + (long long)(j0 + w) * (ld + 1), ld, P, 64, false, P, 64, true, below, below, w, 2, true, lds);     // A22 -= P P^T
+    }
+}
+
+// In-place lower Cholesky of a matrix in the L2 workspace (n x n, leading dimension ld; lower triangle read and written),
+// for the matrices of a cluster (n = 600 .. 1200): chol_lower of spg_dev_la.hpp is written for LDS — one column per step,
+// every entry of the trailing update three reads and a write, the pivot-column reads strided — and took 50-100 ms per call
+// out of L2, five calls per cluster. Here a panel of up to 16 columns (all rows below the diagonal block) is factorised in
+// LDS and applied to the trailing matrix in one sweep: lane = column (coalesced row segments), the panel rows of the
+// lane's column in registers, kRif rows in flight. Same structure as chol_rows of the interior point below, without the
+// right-hand-side row. On a non-positive pivot *T.flag = 1 (and the pivot is replaced by 1), as chol_lower does.
+template <int NT_>
+__device__ void chol_lower_panel(const Team<NT_> T, double *A, int n, int ld, double *panel /* LDS, kPanelDoubles */) {
+    const int tid = T.tid;
+    const int PB = max(1, min(16, kPanelDoubles / max(n, 1) - 1));
+    const int PBS = PB + 1;
+    bool bad = false;
+    for (int j0 = 0; j0 < n; j0 += PB) {
+        const int pb = min(PB, n - j0), nrows = n - j0;
+        for (int rr = tid >> 4; rr < nrows; rr += NT_ / 16) {
+            const int pc = tid & 15;
+            if (pc < pb) panel[rr * PBS + pc] = (pc <= rr) ? A[(long long)(j0 + rr) * ld + j0 + pc] : 0.0;
+        }
+        T.sync();
+        for (int pc = 0; pc < pb; pc++) {
+            double dpiv = panel[pc * PBS + pc];
+            if (!(dpiv > 0.0) || !isfinite(dpiv)) { bad = true; dpiv = 1.0; }
+            const double l = sqrt(dpiv);
+            T.sync();                                     // everybody has read the pivot
+            for (int rr = pc + 1 + tid; rr < nrows; rr += NT_) panel[rr * PBS + pc] /= l;
+            if (tid == 0) panel[pc * PBS + pc] = l;
+            T.sync();
+            const int p2 = pc + 1 + (tid & 15);
+            if (p2 < pb)
+                for (int rr = pc + 1 + (tid >> 4); rr < nrows; rr += NT_ / 16)
+                    if (rr >= p2) panel[rr * PBS + p2] -= panel[rr * PBS + pc] * panel[p2 * PBS + pc];
+            T.sync();
+        }
+        for (int rr = tid >> 4; rr < nrows; rr += NT_ / 16) {
+            const int pc = tid & 15;
+            if (pc < pb && pc <= rr) A[(long long)(j0 + rr) * ld + j0 + pc] = panel[rr * PBS + pc];
+        }
+        // trailing update: rows i >= j0 + pb, columns j0 + pb <= c <= i
+        const int t0 = j0 + pb, wv = tid >> 6, lane = tid & 63;
+        constexpr int kRif = 4, kWaves = NT_ / 64;
+        for (int cb = t0 + lane; cb < n; cb += 64) {
+            double pcv[16];
+            const double *pcp = panel + (cb - j0) * PBS;
+#pragma unroll
+            for (int pc = 0; pc < 16; pc++) pcv[pc] = (pc < pb) ? pcp[pc] : 0.0;
+            for (int ib = (cb - lane) + kRif * wv; ib < n; ib += kWaves * kRif) {
+                double v[kRif];
+#pragma unroll
+                for (int u = 0; u < kRif; u++) { const int i = ib + u; v[u] = (i < n && cb <= i) ? A[(long long)i * ld + cb] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < kRif; u++) {
+                    const int i = ib + u;
+                    if (i < n && cb <= i) {
+                        const double *piv = panel + (i - j0) * PBS;
+                        double acc = v[u];
+#pragma unroll
+                        for (int pc = 0; pc < 16; pc++) if (pc < pb) acc -= piv[pc] * pcv[pc];
+                        A[(long long)i * ld + cb] = acc;
+                    }
+                }
+            }
+        }
+        T.sync();
+    }
+    if (bad && tid == 0) *T.flag = 1;
+    T.sync();
+}
+
 template <int D>
 __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     constexpr int DD = D * D, PS = (D == 6) ? 7 : 3, PSZ = (D == 6) ? 12 : 3, REC = PS + D * (D + 1) / 2;
@@ -243,8 +454,33 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     if (tid == 0) flag_s = 0;
     __syncthreads();
     Team<NT> T{tid, red, &flag_s};
+    // Cholesky of a matrix of the closed-form path: out of L2 in panels once it is large (never while the interior point's
+    // packed Hessian owns the dynamic LDS), the LDS-style routine otherwise
+    const bool big = n >= 96 && !hx_lds;
+    // Cholesky of a matrix of the closed-form path: blocked on the matrix cores once it is large (tmp: cap doubles of free
+    // workspace, (nn + 64) * 65 needed — else in LDS panels), the LDS routine for the small ones and whenever the interior
+    // point's packed Hessian owns the dynamic LDS
+    auto chol_big = [&](double *A, int nn, int ld, double *tmp, long long cap) {
+        if (nn >= 96 && !hx_lds) {
+            if ((long long)(nn + 64) * 65 <= cap) chol_lower_blocked<NT>(T, A, nn, ld, tmp, panel);
+            else chol_lower_panel<NT>(T, A, nn, ld, panel);
+        } else chol_lower<NT>(T, A, nn, ld);
+    };
+    // (L L^T)^-1 into Out (full symmetric) with L^-1 left in Linv_; Out doubles as scratch of the blocked inverse
+    auto spd_inverse_from_chol = [&](const double *Lc, double *Linv_, double *Out, int nn) {
+        if (big && nn >= 96) {
+            tri_inverse_lower_blocked<NT>(T, Lc, nn, Linv_, nn, nn, Out, panel);
+            team_gemm<NT>(T, Out, nn, Linv_, nn, true, Linv_, nn, false, nn, nn, nn, 0, false, panel);
+        } else {
+            tri_inverse_lower<NT>(T, Lc, Linv_, nn, nn);
+            gram_lower_inverse<NT>(T, Linv_, Out, nn, nn);
+        }
+    };
 #ifdef SPG_IP_PROF
     long long ipt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ipt_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
+#ifdef SPG_CF_PROF
+    long long cfp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, cfp_last = wall_clock64();
 #endif
     int status = SPG_OK, info = 0, n_new = 0;
     double kld = __builtin_nan(""), min_gap = __builtin_inf();
@@ -375,27 +611,44 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             __syncthreads();
         }
     }
+    CFP(0);
     // ---- Schur complement onto the kept block (src/vertex_remover.cpp:409-449)
     double *Lam = ws + L.Lam;
     if (nm > 0) {
-        chol_lower<NT>(T, H, nm, N);                            // H_mm = L L^T (lower, in place)
+        chol_big(H, nm, N, ws + L.A1, (long long)n * n);        // H_mm = L L^T (lower, in place)
         if (flag_s) { status = SPG_ST_HMM_NOT_PD; finish(); return; }
         // W = L^-1 H_mk (nm x n), stored over the upper right block
-        for (int c = tid; c < n; c += NT)
-            for (int i = 0; i < nm; i++) {
-                double s = H[i * N + nm + c];
-                for (int t = 0; t < i; t++) s -= H[i * N + t] * H[t * N + nm + c];
-                H[i * N + nm + c] = s / H[i * N + i];
-            }
+        if (big && nm >= 96 && nm <= n) {
+            // through L^-1 (blocked inverse into A1, scratch in V) and one product on the matrix cores into Lam, copied back
+            double *Linv_m = ws + L.A1, *Wt = Lam;
+            tri_inverse_lower_blocked<NT>(T, H, N, Linv_m, nm, nm, ws + L.V, panel);
+            team_gemm<NT>(T, Wt, n, Linv_m, nm, false, H + nm, N, false, nm, n, nm, 0, false, panel);
+            for (int it = tid; it < nm * n; it += NT) { const int i = it / n, c = it - i * n; H[i * N + nm + c] = Wt[it]; }
+            __syncthreads();
+        } else {
+            for (int c = tid; c < n; c += NT)
+                for (int i = 0; i < nm; i++) {
+                    double s = H[i * N + nm + c];
+                    for (int t = 0; t < i; t++) s -= H[i * N + t] * H[t * N + nm + c];
+                    H[i * N + nm + c] = s / H[i * N + i];
+                }
+            __syncthreads();
+        }
+    }
+    CFP(1);
+    if (big && nm > 0) {
+        for (int it = tid; it < n * n; it += NT) { const int i = it / n, j = it - i * n; Lam[it] = H[(nm + i) * N + nm + j]; }
+        __syncthreads();
+        team_gemm<NT>(T, Lam, n, H + nm, N, true, H + nm, N, false, n, n, nm, 2, false, panel);      // Lambda_t = H_kk - W^T W
+    } else {
+        for (int it = tid; it < n * n; it += NT) {
+            const int i = it / n, j = it - i * n;
+            double s = H[(nm + i) * N + nm + j];
+            for (int t = 0; t < nm; t++) s -= H[t * N + nm + i] * H[t * N + nm + j];
+            Lam[it] = s;
+        }
         __syncthreads();
     }
-    for (int it = tid; it < n * n; it += NT) {
-        const int i = it / n, j = it - i * n;
-        double s = H[(nm + i) * N + nm + j];
-        for (int t = 0; t < nm; t++) s -= H[t * N + nm + i] * H[t * N + nm + j];
-        Lam[it] = s;
-    }
-    __syncthreads();
     for (int it = tid; it < n * n; it += NT) { const int i = it / n, j = it - i * n; if (j > i) Lam[it] = 0.5 * (Lam[it] + Lam[j * n + i]); }
     __syncthreads();
     for (int it = tid; it < n * n; it += NT) { const int i = it / n, j = it - i * n; if (j < i) Lam[it] = Lam[j * n + i]; }
@@ -406,6 +659,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         if (T.sum(bad) > 0) { status = SPG_ST_NONFINITE; finish(); return; }
     }
 
+    CFP(2);
     // ---- sparsity pattern (src/pseudo_chow_liu.cpp:33-87)
     if (k == 2) {
         if (tid == 0) { pairs[0] = 0; pairs[1] = 1; }
@@ -417,10 +671,9 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         double *A1 = ws + L.A1, *Vv = ws + L.V, *Sg = hot + L.Y;
         for (int it = tid; it < n * n; it += NT) { const int i = it / n, j = it - i * n; A1[it] = Lam[it] + (i == j ? 1.0 : 0.0); }
         __syncthreads();
-        chol_lower<NT>(T, A1, n, n);
+        chol_big(A1, n, n, Vv, (long long)n * n);
         if (flag_s) { status = SPG_ST_TIKHONOV_NOT_PD; finish(); return; }
-        tri_inverse_lower<NT>(T, A1, Vv, n, n);
-        gram_lower_inverse<NT>(T, Vv, Sg, n, n);
+        spd_inverse_from_chol(A1, Vv, Sg, n);
         const int P2 = k * (k - 1) / 2;
         double *w = ws + L.w;               // w[p], then (after P2) scratch
         int *pij = reinterpret_cast<int *>(ws + L.w + P2);    // 2 P2 ints
@@ -547,6 +800,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     }
     __syncthreads();
 
+    CFP(3);
     // ---- new edge skeleton: measurement from the state, Jacobians (src/topology_provider_binary.hpp:38-47)
     double *Jb = hot + L.J;
     for (int e = tid; e < E; e += NT) {
@@ -645,7 +899,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
         if (tid == 0) flag_s = 0;
         __syncthreads();
-        chol_lower<NT>(T, A1, n, n);
+        chol_big(A1, n, n, Vv, (long long)n * n);
         gfail |= flag_s != 0;
         __syncthreads();
         if (tid == 0) flag_s = 0;
@@ -655,14 +909,14 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             for (int i = tid; i < n; i += NT) l += log(A1[i * n + i]);
             logdetC = 2.0 * T.sum(l);
             double *Cinv = hot + L.Y;
-            tri_inverse_lower<NT>(T, A1, Vv, n, n);
-            gram_lower_inverse<NT>(T, Vv, Cinv, n, n);
+            spd_inverse_from_chol(A1, Vv, Cinv, n);
             double trc = 0;
             for (int i = tid; i < n; i += NT) trc += Cinv[i * n + i];
             trc = T.sum(trc);
             gauge_ok = isfinite(trc) && trc < 5e4 && isfinite(logdetC);
         }
     }
+    CFP(4);
     // ---- spectrum of the target (src/logdet_function.cpp:14-64): the interior point needs U and S; the closed form only
     // when the gauge route did not apply
     if (!gauge_ok) {
@@ -725,6 +979,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         }
     }
     }
+    CFP(5);
     double logdetS = 0;
     if (!gauge_ok) {
         double l = 0;
@@ -809,41 +1064,58 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                 }
             }
             __syncthreads();
-            for (int it = tid; it < re * n; it += NT) {
-                const int pr = it / n, c = it - pr * n;
-                double sacc = 0;
-                for (int t = 0; t < n; t++) sacc += Je[pr * n + t] * Sig[t * n + c];
-                Tm[it] = sacc;
+            CFP(6);
+            if (big) team_gemm<NT>(T, Tm, n, Je, n, false, Sig, n, false, re, n, n, 0, false, panel);       // Tm = J Sigma
+            else {
+                for (int it = tid; it < re * n; it += NT) {
+                    const int pr = it / n, c = it - pr * n;
+                    double sacc = 0;
+                    for (int t = 0; t < n; t++) sacc += Je[pr * n + t] * Sig[t * n + c];
+                    Tm[it] = sacc;
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            for (int it = tid; it < re * re; it += NT) {
-                const int pr = it / re, c = it - pr * re;
-                double sacc = 0;
-                for (int t = 0; t < n; t++) sacc += Tm[pr * n + t] * Je[c * n + t];
-                G[it] = sacc;
+            CFP(7);
+            if (big) team_gemm<NT>(T, G, re, Tm, n, false, Je, n, true, re, re, n, 0, false, panel);        // G = (J Sigma) J^T
+            else {
+                for (int it = tid; it < re * re; it += NT) {
+                    const int pr = it / re, c = it - pr * re;
+                    double sacc = 0;
+                    for (int t = 0; t < n; t++) sacc += Tm[pr * n + t] * Je[c * n + t];
+                    G[it] = sacc;
+                }
+                __syncthreads();
             }
-            __syncthreads();
+            CFP(8);
             for (int it = tid; it < re * re; it += NT) { const int pr = it / re, c = it - pr * re; C[it] = 0.5 * (G[pr * re + c] + G[c * re + pr]); }
             if (tid == 0) flag_s = 0;
             __syncthreads();
-            chol_lower<NT>(T, C, re, re);
+            chol_big(C, re, re, Wm, (long long)re * re);
             if (flag_s) { status = SPG_ST_CLOSED_FORM_NOT_PD; n_new = 0; finish(); return; }
-            tri_inverse_lower<NT>(T, C, Wm, re, re);        // W = C^-1 (lower): X = W^T W
-            gram_lower_inverse<NT>(T, Wm, X, re, re);
+            CFP(9);
+            spd_inverse_from_chol(C, Wm, X, re);            // W = C^-1 (lower): X = W^T W
+            CFP(10);
+            CFP(11);
             // A += J_e^T X J_e
-            for (int it = tid; it < re * n; it += NT) {
-                const int pr = it / n, c = it - pr * n;
-                double sacc = 0;
-                for (int t = 0; t < re; t++) sacc += X[pr * re + t] * Je[t * n + c];
-                Tm[it] = sacc;
+            if (big) {
+                team_gemm<NT>(T, Tm, n, X, re, false, Je, n, false, re, n, re, 0, false, panel);
+                team_gemm<NT>(T, Ai, n, Je, n, true, Tm, n, false, n, n, re, 1, false, panel);
+            } else {
+                for (int it = tid; it < re * n; it += NT) {
+                    const int pr = it / n, c = it - pr * n;
+                    double sacc = 0;
+                    for (int t = 0; t < re; t++) sacc += X[pr * re + t] * Je[t * n + c];
+                    Tm[it] = sacc;
+                }
+                __syncthreads();
+                for (int it = tid; it < n * n; it += NT) {
+                    const int i = it / n, j = it - i * n;
+                    double sacc = 0;
+                    for (int t = 0; t < re; t++) sacc += Je[t * n + i] * Tm[t * n + j];
+                    Ai[it] += sacc;
+                }
             }
-            __syncthreads();
-            for (int it = tid; it < n * n; it += NT) {
-                const int i = it / n, j = it - i * n;
-                double sacc = 0;
-                for (int t = 0; t < re; t++) sacc += Je[t * n + i] * Tm[t * n + j];
-                Ai[it] += sacc;
-            }
+            CFP(12);
             // the record
             double *rec = arena + bd.new_off + rel;
             const double *zb = ws + L.zbuf + (int64_t)i0 * PS;
@@ -883,6 +1155,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             }
             __syncthreads();
         }
+        CFP(13);
         bool okc = false;
         double fv;
         if (gauge_ok) {
@@ -898,7 +1171,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             }
             if (tid == 0) flag_s = 0;
             __syncthreads();
-            chol_lower<NT>(T, A1, n, n);
+            chol_big(A1, n, n, ws + L.V, (long long)n * n);
             okc = flag_s == 0;
             __syncthreads();
             if (tid == 0) flag_s = 0;
@@ -908,6 +1181,11 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             l = T.sum(l);
             fv = okc ? 0.5 * (tr - 2.0 * l + logdetC - r) : __builtin_inf();
         } else fv = value_from_A(okc);
+        CFP(14);
+#ifdef SPG_CF_PROF
+        if (tid == 0 && k >= 40) printf("cf prof k=%d m=%d n=%d gauge=%d (us): assemble %lld | Hmm chol+W %lld | schur %lld | pattern %lld | skeleton+gauge %lld | eig %lld | group: zero+Je %lld, J Sig %lld, G %lld, chol %lld, tri inv %lld, gram %lld, A+= %lld | record %lld | value %lld\n",
+                                        k, m, n, (int)gauge_ok, cfp[0] / 100, cfp[1] / 100, cfp[2] / 100, cfp[3] / 100, cfp[4] / 100, cfp[5] / 100, cfp[6] / 100, cfp[7] / 100, cfp[8] / 100, cfp[9] / 100, cfp[10] / 100, cfp[11] / 100, cfp[12] / 100, cfp[13] / 100, cfp[14] / 100);
+#endif
         tab_mode = true;
         n_new = ng;
         if (!okc || !isfinite(fv)) { status = SPG_ST_KLD_NOT_PD; kld = __builtin_nan(""); finish(); return; }
