@@ -200,6 +200,278 @@ __device__ __forceinline__ void rr_pair(int s, int pi, int n2, int &p, int &q) {
     if (p > q) { int t = p; p = q; q = t; }
 }
 
+// Symmetric eigendecomposition of a LARGE matrix in the L2 workspace (clusters of several hundred vertices, where the
+// Jacobi sweeps below take tens of seconds): Householder tridiagonalisation, Q formed explicitly, implicit-shift QL on
+// the tridiagonal matrix with the rotations applied to the columns of Q (the tred2 / tql2 pair, arranged for a workgroup).
+// A (n x n, full symmetric, destroyed: on exit its diagonal holds the eigenvalues, unordered), V receives the
+// eigenvectors in columns — the interface of jacobi_eigh. gl: 3 n doubles of global scratch (d, e, beta). lds: 6 n
+// doubles. Returns false (uniformly) if an eigenvalue does not converge in 60 iterations. n <= 8 * NT.
+// One workgroup streaming matrices out of L2 is bound by the memory round trips it waits for, so every pass keeps many
+// independent accesses in flight per lane:
+//   * column sums (A v = A^T v, v^T V): wavefront w takes the rows i = w (mod 4), a lane up to 16 columns 64 apart, two
+//     rows per step — 32 loads in flight, no reduction across lanes; the four partial vectors meet in LDS;
+//   * rank-1 / rank-2 updates: the same tiling, loads of a step issued before its stores;
+//   * QL: wavefront 0 runs the scalar recurrence of a sweep (d, e in LDS) and leaves the rotations in LDS; then every lane
+//     applies them to the rows of V it owns, eight rotations and all its rows per step (a rotation of columns i, i + 1
+//     treats the rows independently). The first form — rotations applied as they were produced, one load and one store
+//     per rotation — waited a full memory round trip per rotation: 0.9 s of 1.4 s at n = 792.
+template <int NT>
+__device__ bool tridiag_eigh(const Team<NT> T, double *A, double *V, int n, int ld, double *gl, double *lds) {
+    constexpr int NW = NT / 64, CMAX = 16;
+    const int tid = T.tid, lane = tid & 63, wv = tid >> 6;
+    double *dg = gl, *eg = gl + n, *bg = gl + 2 * n;
+    if (n == 1) { if (tid == 0) V[0] = 1.0; T.sync(); return true; }
+    double *vb = lds, *wb = lds + n, *part = lds + 2 * n;      // Householder vector, p / w / u, NW partial column sums
+#ifdef SPG_CF_PROF
+    long long tq0 = wall_clock64(), tq1, tq2, tq3;
+#endif
+    // out[j] = scale * sum_i M[i][j] vec[i] over the m x m block at M (leading dimension ld)
+    auto colsum = [&](const double *M, int m, const double *vec, double *out, double scale) {
+        for (int c0 = 0; c0 < m; c0 += 64 * CMAX) {
+            double acc[CMAX];
+#pragma unroll
+            for (int c = 0; c < CMAX; c++) acc[c] = 0.0;
+            for (int i = wv; i < m; i += 2 * NW) {
+                const int i2 = i + NW;
+                const double *r1 = M + (long long)i * ld + c0 + lane, *r2 = M + (long long)i2 * ld + c0 + lane;
+                const double v1 = vec[i], v2 = (i2 < m) ? vec[i2] : 0.0;
+                double x1[CMAX], x2[CMAX];
+#pragma unroll
+                for (int c = 0; c < CMAX; c++) {
+                    const bool in = c0 + lane + 64 * c < m;
+                    x1[c] = in ? r1[64 * c] : 0.0;
+                    x2[c] = (in && i2 < m) ? r2[64 * c] : 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < CMAX; c++) acc[c] += x1[c] * v1 + x2[c] * v2;
+            }
+#pragma unroll
+            for (int c = 0; c < CMAX; c++) { const int j = c0 + lane + 64 * c; if (j < m) part[wv * n + j] = acc[c]; }
+        }
+        T.sync();
+        for (int j = tid; j < m; j += NT) {
+            double sacc = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2++) sacc += part[w2 * n + j];
+            out[j] = scale * sacc;
+        }
+        T.sync();
+    };
+    // M[i][j] -= a[i] b[j] (+ b[i] a[j] when sym: products rounded separately, the update stays symmetric bit for bit)
+    auto rank_update = [&](double *M, int m, const double *av, const double *bv, bool sym) {
+        for (int c0 = 0; c0 < m; c0 += 64 * CMAX)
+            for (int i = wv; i < m; i += 2 * NW) {
+                const int i2 = i + NW;
+                double *r1 = M + (long long)i * ld + c0 + lane, *r2 = M + (long long)i2 * ld + c0 + lane;
+                const double a1 = av[i], b1 = bv[i], a2 = (i2 < m) ? av[i2] : 0.0, b2 = (i2 < m) ? bv[i2] : 0.0;
+                double x1[CMAX], x2[CMAX];
+#pragma unroll
+                for (int c = 0; c < CMAX; c++) {
+                    const bool in = c0 + lane + 64 * c < m;
+                    x1[c] = in ? r1[64 * c] : 0.0;
+                    x2[c] = (in && i2 < m) ? r2[64 * c] : 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < CMAX; c++) {
+                    const int j = c0 + lane + 64 * c;
+                    if (j < m) {
+                        const double aj = av[j], bj = bv[j];
+                        r1[64 * c] = x1[c] - (sym ? __dadd_rn(__dmul_rn(a1, bj), __dmul_rn(b1, aj)) : a1 * bj);
+                        if (i2 < m) r2[64 * c] = x2[c] - (sym ? __dadd_rn(__dmul_rn(a2, bj), __dmul_rn(b2, aj)) : a2 * bj);
+                    }
+                }
+            }
+        T.sync();
+    };
+    // ---------------------------------------------------------------- tridiagonalisation
+    for (int k = 0; k + 2 < n; k++) {
+        const int m = n - k - 1;
+        const double *x = A + (long long)k * ld + k + 1;      // row k right of the diagonal = column k below it
+        double sg = 0;
+        for (int j = 1 + tid; j < m; j += NT) sg += x[j] * x[j];
+        const double sigma = T.sum(sg), x0 = x[0];
+        double beta = 0.0, mu = x0, v0 = 1.0;
+        if (sigma > 0.0) {
+            mu = sqrt(x0 * x0 + sigma);
+            v0 = (x0 <= 0.0) ? x0 - mu : -sigma / (x0 + mu);
+            beta = 2.0 * v0 * v0 / (sigma + v0 * v0);
+        }
+        for (int j = tid; j < m; j += NT) vb[j] = (j == 0) ? 1.0 : x[j] / v0;
+        T.sync();
+        if (tid == 0) { dg[k] = A[(long long)k * ld + k]; eg[k] = (sigma > 0.0) ? mu : x0; bg[k] = beta; }
+        for (int j = 1 + tid; j < m; j += NT) A[(long long)k * ld + k + 1 + j] = vb[j];      // kept for Q
+        if (beta != 0.0) {
+            double *A22 = A + (long long)(k + 1) * ld + k + 1;
+            colsum(A22, m, vb, wb, beta);                      // p = beta A22 v
+            double pv = 0;
+            for (int j = tid; j < m; j += NT) pv += wb[j] * vb[j];
+            const double alpha = 0.5 * beta * T.sum(pv);
+            for (int j = tid; j < m; j += NT) wb[j] -= alpha * vb[j];
+            T.sync();
+            rank_update(A22, m, vb, wb, true);                 // A22 -= v w^T + w v^T
+        } else T.sync();
+    }
+    if (tid == 0) {
+        dg[n - 2] = A[(long long)(n - 2) * ld + n - 2];
+        dg[n - 1] = A[(long long)(n - 1) * ld + n - 1];
+        eg[n - 2] = A[(long long)(n - 2) * ld + n - 1];
+        eg[n - 1] = 0.0;
+    }
+#ifdef SPG_CF_PROF
+    T.sync(); tq1 = wall_clock64();
+#endif
+    // ---------------------------------------------------------------- V = Q = H_0 H_1 ... H_{n-3}
+    for (long long it = tid; it < (long long)n * n; it += NT) { const int i = (int)(it / n), j = (int)(it - (long long)i * n); V[(long long)i * ld + j] = (i == j) ? 1.0 : 0.0; }
+    T.sync();
+    for (int k = n - 3; k >= 0; k--) {
+        const int m = n - k - 1;
+        const double beta = bg[k];
+        if (beta == 0.0) continue;
+        for (int j = tid; j < m; j += NT) vb[j] = (j == 0) ? 1.0 : A[(long long)k * ld + k + 1 + j];
+        T.sync();
+        double *V22 = V + (long long)(k + 1) * ld + k + 1;
+        colsum(V22, m, vb, wb, beta);                          // u = beta v^T V22
+        rank_update(V22, m, vb, wb, false);                    // V22 -= v u^T
+    }
+#ifdef SPG_CF_PROF
+    T.sync(); tq2 = wall_clock64();
+#endif
+    // Q^T into A (the Householder vectors are spent): a rotation of two COLUMNS of V is then a rotation of two ROWS of
+    // A, which the lanes read and write side by side — with V itself a lane would own a row and every access of the
+    // wavefront would touch 64 cache lines (measured: 1 us per rotation, three quarters of the whole decomposition)
+    for (long long it = tid; it < (long long)n * n; it += NT) { const int rr = (int)(it / n), c = (int)(it - (long long)rr * n); A[(long long)c * ld + rr] = V[(long long)rr * ld + c]; }
+    T.sync();
+    // ---------------------------------------------------------------- implicit QL (tql2)
+    double *d = lds, *e = lds + n, *csb = lds + 2 * n, *snb = lds + 3 * n;
+    int *ctl = reinterpret_cast<int *>(lds + 4 * n);       // [0] m, [1] lowest rotation index applied, [2] state: 0 sweep, 1 eigenvalue done, 2 failed
+    for (int i = tid; i < n; i += NT) { d[i] = dg[i]; e[i] = eg[i]; }
+    T.sync();
+    constexpr int RC = 4, U8 = 8;                    // entries of a row of Q^T per lane and pass, rotations per step
+    const int nrows = (n - tid + NT - 1) / NT;       // entries tid, tid + NT, ...
+    bool ok = true;
+#ifdef SPG_CF_PROF
+    long long tA = 0, tB = 0, nsweep = 0, nrot = 0, tl = wall_clock64();
+#endif
+    for (int l = 0; l < n && ok; l++) {
+        int iter = 0;
+        for (;;) {
+            if (wv == 0) {
+                // the scalar recurrence of one sweep (every lane of the wavefront computes it; lane 0's stores count)
+                int m = l;
+                for (; m < n - 1; m++) {
+                    const double dd = fabs(d[m]) + fabs(d[m + 1]);
+                    if (fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
+                }
+                int state = 0, lo = l;
+                if (m == l) state = 1;
+                else if (iter == 60) state = 2;
+                else {
+                    double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                    double r = sqrt(g * g + 1.0);
+                    g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? r : -r));
+                    double sn = 1.0, cs = 1.0, pp = 0.0;
+                    bool underflow = false;
+                    int i = m - 1;
+                    // One wavefront alone: nothing hides the latency of a dependent operation, so the chain is kept short — the
+                    // next step's d, e are read a step ahead, 1 / r comes from the reciprocal square root (hardware seed + two Newton
+                    // steps; no division, no sqrt sequence), and all lanes store (same value, same address) instead of branching.
+                    double e_i = e[i], d_i = d[i], d_i1 = d[i + 1];
+                    for (; i >= l; i--) {
+                        const double e_n = (i > l) ? e[i - 1] : 0.0, d_n = (i > l) ? d[i - 1] : 0.0;
+                        const double f = sn * e_i, b = cs * e_i;
+                        const double h2 = f * f + g * g;
+                        if (h2 == 0.0) { e[i + 1] = 0.0; d[i + 1] = d_i1 - pp; e[m] = 0.0; underflow = true; break; }
+                        const double rinv = fast_rsqrt(h2);
+                        r = h2 * rinv;
+                        e[i + 1] = r;
+                        sn = f * rinv; cs = g * rinv;
+                        g = d_i1 - pp;
+                        r = (d_i - g) * sn + 2.0 * cs * b;
+                        pp = sn * r;
+                        d[i + 1] = g + pp;
+                        csb[i] = cs; snb[i] = sn;
+                        g = cs * r - b;
+                        // (d[i + 1] as the next step sees it is d[i] of this one, untouched so far in this sweep)
+                        d_i1 = d_i; d_i = d_n; e_i = e_n;
+                    }
+                    lo = i + 1;
+                    if (!underflow) { d[l] -= pp; e[l] = g; e[m] = 0.0; }
+                }
+                if (lane == 0) { ctl[0] = m; ctl[1] = lo; ctl[2] = state; }
+            }
+            T.sync();
+#ifdef SPG_CF_PROF
+            { long long t_ = wall_clock64(); tA += t_ - tl; tl = t_; }
+#endif
+            const int m = ctl[0], lo = ctl[1], state = ctl[2];
+            if (state == 1) { T.sync(); break; }
+            if (state == 2) { ok = false; T.sync(); break; }
+            iter++;
+            // rotations i = m - 1 .. lo on rows (i, i + 1) of Q^T, for the entries of this lane: four entries at a time, eight
+            // rotations per step, the next step's loads issued before this step's stores (memory operations complete in
+            // order: loads behind stores would wait for the stores too — two round trips per step instead of a hidden one)
+            if (m - 1 >= lo) {
+                for (int t0 = 0; t0 < nrows; t0 += RC) {
+                    double zc[RC];
+                    int col[RC];
+                    bool live[RC];
+#pragma unroll
+                    for (int t = 0; t < RC; t++) { live[t] = t0 + t < nrows; col[t] = tid + (t0 + t) * NT; zc[t] = live[t] ? A[(long long)m * ld + col[t]] : 0.0; }
+                    double ba[RC][U8], bb[RC][U8];
+                    auto load = [&](int i0, double (&buf)[RC][U8]) {
+#pragma unroll
+                        for (int t = 0; t < RC; t++)
+#pragma unroll
+                            for (int u = 0; u < U8; u++) buf[t][u] = (live[t] && i0 - u >= lo) ? A[(long long)(i0 - u) * ld + col[t]] : 0.0;
+                    };
+                    auto apply = [&](int i0, const double (&buf)[RC][U8]) {
+#pragma unroll
+                        for (int u = 0; u < U8; u++) {
+                            const int i = i0 - u;
+                            if (i >= lo) {
+                                const double cs = csb[i], sn = snb[i];
+#pragma unroll
+                                for (int t = 0; t < RC; t++)
+                                    if (live[t]) {
+                                        A[(long long)(i + 1) * ld + col[t]] = sn * buf[t][u] + cs * zc[t];
+                                        zc[t] = cs * buf[t][u] - sn * zc[t];
+                                    }
+                            }
+                        }
+                    };
+                    int i0 = m - 1;
+                    load(i0, ba);
+                    while (i0 >= lo) {
+                        if (i0 - U8 >= lo) load(i0 - U8, bb);
+                        apply(i0, ba);
+                        i0 -= U8;
+                        if (i0 < lo) break;
+                        if (i0 - U8 >= lo) load(i0 - U8, ba);
+                        apply(i0, bb);
+                        i0 -= U8;
+                    }
+#pragma unroll
+                    for (int t = 0; t < RC; t++) if (live[t]) A[(long long)lo * ld + col[t]] = zc[t];
+                }
+            }
+            T.sync();
+#ifdef SPG_CF_PROF
+            { long long t_ = wall_clock64(); tB += t_ - tl; tl = t_; nsweep++; nrot += m - lo; }
+#endif
+        }
+    }
+    T.sync();
+#ifdef SPG_CF_PROF
+    tq3 = wall_clock64();
+    if (tid == 0) printf("tridiag_eigh n=%d (us): tridiagonalise %lld, form Q %lld, QL %lld (recurrence %lld, rows %lld; %lld sweeps, %lld rotations)\n", n, (tq1 - tq0) / 100, (tq2 - tq1) / 100, (tq3 - tq2) / 100, tA / 100, tB / 100, nsweep, nrot);
+#endif
+    for (long long it = tid; it < (long long)n * n; it += NT) { const int rr = (int)(it / n), c = (int)(it - (long long)rr * n); V[(long long)rr * ld + c] = A[(long long)c * ld + rr]; }
+    T.sync();
+    for (int i = tid; i < n; i += NT) A[(long long)i * ld + i] = d[i];
+    T.sync();
+    return ok;
+}
+
 // Symmetric eigendecomposition by parallel-order two-sided Jacobi. A (n x n, full, destroyed: on
 // exit its diagonal holds the eigenvalues), V receives the eigenvectors in columns. cs: 2*(n/2+1)
 // doubles of scratch. Returns false (uniformly) if not converged in max_sweeps.

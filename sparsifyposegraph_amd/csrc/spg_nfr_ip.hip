@@ -217,6 +217,7 @@ __device__ __forceinline__ void chol_lower_reg(int tid, double *A, int n, int ld
 // cores work on the current one. lower_only skips the tiles strictly above the block diagonal (M = N products whose
 // upper part is mirrored or not needed). lds: 2 * 64 * 34 doubles. mode 0: C = AB, 1: C += AB, 2: C -= AB.
 constexpr int kGemmLds = 2 * 64 * 34;
+constexpr int kBlockedLds = kGemmLds + 2 * 64 * 65;      // the blocked routines below: staging area + two 64 x 64 blocks
 template <int NT_>
 __device__ void team_gemm(const Team<NT_> T, double *C, int ldc, const double *A, int lda, bool ta, const double *B, int ldb, bool tb,
                           int M, int N, int K, int mode, bool lower_only, double *lds) {
@@ -281,7 +282,7 @@ __device__ void team_gemm(const Team<NT_> T, double *C, int ldc, const double *A
 // Li = L^-1 (lower; strict upper zeroed) for a matrix of a cluster, in block columns of 64: the diagonal block is inverted by
 // one lane per column as tri_inverse_lower does, the block below it is  -Li[below, below] (L[below, jb] Li[jb, jb])  — two
 // products on the matrix cores, right to left so that the inverse of the trailing block is already in place. Li may not
-// alias L; tmp: (n - 64) x 64 doubles of workspace. (tri_inverse_lower: 39 ms at n = 600, three calls per cluster.)
+// alias L; tmp: (n - 64) x 64 doubles of workspace; lds: kBlockedLds doubles. (tri_inverse_lower: 39 ms at n = 600, three calls per cluster.)
 template <int NT_>
 __device__ void tri_inverse_lower_blocked(const Team<NT_> T, const double *L, int ldl, double *Li, int ldi, int n, double *tmp, double *lds) {
     const int tid = T.tid;
@@ -289,16 +290,13 @@ __device__ void tri_inverse_lower_blocked(const Team<NT_> T, const double *L, in
     const int nb = (n + 63) / 64;
     for (int jb = nb - 1; jb >= 0; jb--) {
         const int j0 = jb * 64, w = min(64, n - j0), below = n - j0 - w;
-        // diagonal block: one lane per column
-        if (tid < w) {
-            const int c = j0 + tid;
-            Li[(long long)c * ldi + c] = fast_rcp(L[(long long)c * ldl + c]);
-            for (int i = c + 1; i < j0 + w; i++) {
-                double sacc = 0;
-                for (int k2 = c; k2 < i; k2++) sacc += L[(long long)i * ldl + k2] * Li[(long long)k2 * ldi + c];
-                Li[(long long)i * ldi + c] = -sacc * fast_rcp(L[(long long)i * ldl + i]);
-            }
-        }
+        // diagonal block: staged into LDS, one lane per column there (out of L2 each of the 2 000 dependent steps of a lane
+        // is a memory round trip: 2 ms per block), written back
+        double *Lb = lds + kGemmLds, *Ib = Lb + 64 * 65;
+        for (int it = tid; it < w * w; it += NT_) { const int i = it / w, c = it - i * w; Lb[i * 65 + c] = (c <= i) ? L[(long long)(j0 + i) * ldl + j0 + c] : 0.0; }
+        T.sync();
+        tri_inverse_lower<NT_>(T, Lb, Ib, w, 65);
+        for (int it = tid; it < w * w; it += NT_) { const int i = it / w, c = it - i * w; if (c <= i) Li[(long long)(j0 + i) * ldi + j0 + c] = Ib[i * 65 + c]; }
         T.sync();
         if (below > 0) {
             // tmp = L[below, jb] * Li[jb, jb]   (below x w, K = w)
@@ -319,12 +317,13 @@ __device__ void tri_inverse_lower_blocked(const Team<NT_> T, const double *L, in
 // written) in block columns of 64 with the trailing update on the matrix cores: the diagonal block is factorised in LDS
 // (chol_lower, the LDS routine) and inverted there, the panel below it is its product with that inverse, the trailing
 // matrix takes P P^T through team_gemm (lower block triangle, K = 64). lds: 64 * 65 doubles (the same region team_gemm
-// stages through — the two never run together); tmp: (n + 64) * 65 doubles of workspace. Failure as chol_lower: *T.flag = 1.
+// stages through — the two never run together — and its inverse behind that area; kBlockedLds doubles in all); tmp: n * 64
+// doubles of workspace. Failure as chol_lower: *T.flag = 1.
 template <int NT_>
 __device__ void chol_lower_blocked(const Team<NT_> T, double *A, int n, int ld, double *tmp, double *lds) {
     static_assert(kGemmLds >= 64 * 65, "the diagonal block borrows the staging area of team_gemm");
     const int tid = T.tid;
-    double *Db = lds, *Dinv = tmp, *P = tmp + 64 * 65;
+    double *Db = lds, *Dinv = lds + kGemmLds, *P = tmp;
     for (int j0 = 0; j0 < n; j0 += 64) {
         const int w = min(64, n - j0), below = n - j0 - w;
         for (int it = tid; it < w * w; it += NT_) { const int i = it / w, c = it - i * w; Db[i * 65 + c] = (c <= i) ? A[(long long)(j0 + i) * ld + j0 + c] : 0.0; }
@@ -456,21 +455,32 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     Team<NT> T{tid, red, &flag_s};
     // Cholesky of a matrix of the closed-form path: out of L2 in panels once it is large (never while the interior point's
     // packed Hessian owns the dynamic LDS), the LDS-style routine otherwise
-    const bool big = n >= 96 && !hx_lds;
+    // a cluster: its matrices live in the L2 workspace and the whole dynamic LDS is free for the blocked routines
+    const bool big = n >= 96 && !hx_lds && hot == ws + L.cold_total && kBlockedLds <= a.lds_doubles;
     // Cholesky of a matrix of the closed-form path: blocked on the matrix cores once it is large (tmp: cap doubles of free
-    // workspace, (nn + 64) * 65 needed — else in LDS panels), the LDS routine for the small ones and whenever the interior
+    // workspace, nn * 64 needed — else in LDS panels), the LDS routine for the small ones and whenever the interior
     // point's packed Hessian owns the dynamic LDS
     auto chol_big = [&](double *A, int nn, int ld, double *tmp, long long cap) {
-        if (nn >= 96 && !hx_lds) {
-            if ((long long)(nn + 64) * 65 <= cap) chol_lower_blocked<NT>(T, A, nn, ld, tmp, panel);
+        if (nn >= 96 && big) {
+            if ((long long)nn * 64 <= cap) chol_lower_blocked<NT>(T, A, nn, ld, tmp, panel);
             else chol_lower_panel<NT>(T, A, nn, ld, panel);
         } else chol_lower<NT>(T, A, nn, ld);
+    };
+    // strict lower triangle copied over the strict upper one (products of symmetric results are formed on the lower block
+    // triangle only)
+    auto mirror_lower = [&](double *Mx, int nn) {
+        for (long long it = tid; it < (long long)nn * nn; it += NT) {
+            const int i = (int)(it / nn), j = (int)(it - (long long)i * nn);
+            if (j > i) Mx[it] = Mx[(long long)j * nn + i];
+        }
+        __syncthreads();
     };
     // (L L^T)^-1 into Out (full symmetric) with L^-1 left in Linv_; Out doubles as scratch of the blocked inverse
     auto spd_inverse_from_chol = [&](const double *Lc, double *Linv_, double *Out, int nn) {
         if (big && nn >= 96) {
             tri_inverse_lower_blocked<NT>(T, Lc, nn, Linv_, nn, nn, Out, panel);
-            team_gemm<NT>(T, Out, nn, Linv_, nn, true, Linv_, nn, false, nn, nn, nn, 0, false, panel);
+            team_gemm<NT>(T, Out, nn, Linv_, nn, true, Linv_, nn, false, nn, nn, nn, 0, true, panel);      // lower block triangle,
+            mirror_lower(Out, nn);                                                                           // then the other half
         } else {
             tri_inverse_lower<NT>(T, Lc, Linv_, nn, nn);
             gram_lower_inverse<NT>(T, Linv_, Out, nn, nn);
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     long long ipt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ipt_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
 #ifdef SPG_CF_PROF
-    long long cfp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, cfp_last = wall_clock64();
+    long long cfp[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, cfp_last = wall_clock64();
 #endif
     int status = SPG_OK, info = 0, n_new = 0;
     double kld = __builtin_nan(""), min_gap = __builtin_inf();
@@ -557,6 +567,44 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                     for (int x = 0; x < D; x++) for (int y = 0; y < D; y++) { Jm[(i * D + x) * dq + la * D + y] += Ja[x * D + y]; Jm[(i * D + x) * dq + lb * D + y] += Jbb[x * D + y]; }
                 }
                 __syncthreads();
+                if (rr >= 64 && big) {
+                    // a correlated edge of a cluster (a 180-measurement edge of parking.g2o: two products of 1.4 G FMAs, seconds
+                    // in scalar loops): both on the matrix cores, the second into scratch behind Am and scattered from there
+                    double *Pm = Am + (int64_t)rr * dq;
+                    // Am = W J: a column of J belongs to one pose of the edge and is non-zero in the rows of the measurements at
+                    // that pose only (lists in LDS; the Newton solve's vector is idle here)
+                    int *incp = reinterpret_cast<int *>(colbuf), *inc = incp + 264, *icnt = inc + 528;
+                    for (int v = tid; v <= q; v += NT) { incp[v] = 0; icnt[v] = 0; }
+                    __syncthreads();
+                    if (tid == 0) {
+                        for (int i = 0; i < nmi; i++) { incp[(int)rec[1 + 2 * i] + 1]++; incp[(int)rec[2 + 2 * i] + 1]++; }
+                        for (int v = 0; v < q; v++) incp[v + 1] += incp[v];
+                        for (int i = 0; i < nmi; i++)
+                            for (int side = 0; side < 2; side++) { const int v = (int)rec[1 + 2 * i + side]; inc[incp[v] + icnt[v]++] = i; }
+                    }
+                    __syncthreads();
+                    for (int it = tid; it < rr * dq; it += NT) {
+                        const int p = it / dq, c = it - p * dq, v = c / D;
+                        double sacc = 0;
+                        for (int e2 = incp[v]; e2 < incp[v + 1]; e2++) {
+                            const int j = inc[e2];
+#pragma unroll
+                            for (int x = 0; x < D; x++) sacc += Wd[p * rr + j * D + x] * Jm[(j * D + x) * dq + c];
+                        }
+                        Am[it] = sacc;
+                    }
+                    __syncthreads();
+                    team_gemm<NT>(T, Pm, dq, Am, dq, true, Am, dq, false, dq, dq, rr, 0, true, panel);      // (W J)^T (W J), lower block triangle
+                    for (long long it = tid; it < (long long)dq * dq; it += NT) { const int i = (int)(it / dq), j = (int)(it - (long long)i * dq); if (j > i) Pm[it] = Pm[(long long)j * dq + i]; }
+                    __syncthreads();
+                    for (int it = tid; it < dq * dq; it += NT) {
+                        const int r1 = it / dq, c1 = it - r1 * dq;
+                        const int gi = a.ev[er.vbegin + r1 / D] * D + r1 % D, gj = a.ev[er.vbegin + c1 / D] * D + c1 % D;
+                        H[gi * N + gj] += Pm[it];
+                    }
+                    __syncthreads();
+                    continue;
+                }
                 for (int it = tid; it < rr * dq; it += NT) {
                     const int p = it / dq, c = it - p * dq;
                     double sacc = 0;
@@ -674,6 +722,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         chol_big(A1, n, n, Vv, (long long)n * n);
         if (flag_s) { status = SPG_ST_TIKHONOV_NOT_PD; finish(); return; }
         spd_inverse_from_chol(A1, Vv, Sg, n);
+        CFP(15);
         const int P2 = k * (k - 1) / 2;
         double *w = ws + L.w;               // w[p], then (after P2) scratch
         int *pij = reinterpret_cast<int *>(ws + L.w + P2);    // 2 P2 ints
@@ -698,27 +747,85 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             if (!isfinite(w[p])) flag_s = 1;
         }
         __syncthreads();
+        CFP(16);
         if (flag_s) { status = SPG_ST_TIKHONOV_NOT_PD; finish(); return; }
         // pop order: weight descending, ties by (i, j) ascending = index ascending (rank by counting, all lanes: a
         // serial sort of the k (k - 1) / 2 weights of a 100-vertex cluster would take seconds)
-        sort_ascending<NT>(T, w, 1, P2, pij + 2 * P2);
-        __syncthreads();
-        if (tid == 0) {
-            int *order = pij + 2 * P2;     // P2 ints (inside the 4 P2 + 8 doubles reserved at L.w)
-            int *comp = reinterpret_cast<int *>(ws + L.ibuf);
-            for (int v = 0; v < k; v++) comp[v] = v;
-            int nacc = 0, nrej = 0, last = 0;
-            int *rej = order + P2;         // rejected pair indices, in pop order (P2 more ints)
-            for (int s = 0; s < P2; s++) {
-                const int p = order[s], i = pij[2 * p], j = pij[2 * p + 1];
-                if (comp[i] != comp[j]) {
-                    pairs[2 * nacc] = i; pairs[2 * nacc + 1] = j;
-                    nacc++;
-                    const int ci = comp[i], cj = comp[j];
-                    for (int v = 0; v < k; v++) if (comp[v] == cj) comp[v] = ci;
-                    last = s;
-                } else rej[nrej++] = p;
+        if (big && P2 > 2048) {
+            // the same ranks with the keys passing through LDS in chunks (every lane reads every key: out of L2 the 300 M
+            // comparisons of a 190-vertex cluster took tens of milliseconds)
+            int *perm_o = pij + 2 * P2;
+            for (int base = 0; base < P2; base += NT) {
+                const int i = base + tid;
+                const double ki = (i < P2) ? w[i] : 0.0;
+                int rk = 0;
+                for (int c0 = 0; c0 < P2; c0 += kPanelDoubles) {
+                    const int cnt = min(kPanelDoubles, P2 - c0);
+                    __syncthreads();
+                    for (int t = tid; t < cnt; t += NT) panel[t] = w[c0 + t];
+                    __syncthreads();
+                    if (i < P2) {
+                        // branch-free, eight keys per step (the short-circuit form compiled to a divergent branch per key)
+                        int j = 0;
+                        for (; j + 8 <= cnt; j += 8) {
+                            double kj[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) kj[u] = panel[j + u];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) rk += (int)(kj[u] < ki) | ((int)(kj[u] == ki) & (int)(c0 + j + u < i));
+                        }
+                        for (; j < cnt; j++) { const double kj = panel[j]; rk += (int)(kj < ki) | ((int)(kj == ki) & (int)(c0 + j < i)); }
+                    }
+                }
+                if (i < P2) perm_o[rk] = i;
             }
+        } else sort_ascending<NT>(T, w, 1, P2, pij + 2 * P2);
+        __syncthreads();
+        CFP(17);
+        // Kruskal over the pairs in pop order. The union-find labels live in LDS and the pairs reach the one lane that walks
+        // them in batches staged by all lanes (a lane alone reading order -> pair -> labels out of L2 spends three memory
+        // round trips per pair: 50 ms for the 17 000 pairs of a 190-vertex cluster); the scan stops when the tree is
+        // complete — every later pair is a rejected one, in pop order.
+        int *order = pij + 2 * P2;     // P2 ints (inside the 4 P2 + 8 doubles reserved at L.w)
+        int *rej = order + P2;         // rejected pair indices, in pop order (P2 more ints)
+        {
+            int *kcomp = reinterpret_cast<int *>(colbuf);     // (the Newton solve's vector is idle here) k <= 256 labels
+            int *kb = kcomp + 256;                            // a batch: (pair index, i, j) per lane
+            for (int v = tid; v < k; v += NT) kcomp[v] = v;
+            if (tid == 0) { si[4] = 0; si[5] = 0; si[6] = 0; }
+            __syncthreads();
+            int s0 = 0;
+            while (s0 < P2) {
+                if (s0 + tid < P2) { const int pp = order[s0 + tid]; kb[3 * tid] = pp; kb[3 * tid + 1] = pij[2 * pp]; kb[3 * tid + 2] = pij[2 * pp + 1]; }
+                __syncthreads();
+                if (tid == 0) {
+                    int nacc = si[4], nrej = si[5], last = si[6];
+                    const int cnt = min(NT, P2 - s0);
+                    for (int t = 0; t < cnt; t++) {
+                        const int pp = kb[3 * t], i = kb[3 * t + 1], j = kb[3 * t + 2];
+                        if (kcomp[i] != kcomp[j]) {
+                            pairs[2 * nacc] = i; pairs[2 * nacc + 1] = j;
+                            nacc++;
+                            const int ci = kcomp[i], cj = kcomp[j];
+                            for (int v = 0; v < k; v++) if (kcomp[v] == cj) kcomp[v] = ci;
+                            last = s0 + t;
+                        } else rej[nrej++] = pp;
+                    }
+                    si[4] = nacc; si[5] = nrej; si[6] = last;
+                }
+                __syncthreads();
+                s0 += NT;
+                if (si[4] == k - 1) break;
+            }
+            // the rest of the bin: rejected pairs in pop order (only the first E - (k - 1) of the bin are ever read)
+            const int nrej0 = si[5];
+            for (int s2 = s0 + tid; s2 < P2 && nrej0 + (s2 - s0) < E; s2 += NT) rej[nrej0 + (s2 - s0)] = order[s2];
+            __syncthreads();
+            if (tid == 0) si[5] = nrej0 + max(0, P2 - s0);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const int nacc = si[4], nrej = si[5];
             for (int t = 0; nacc + t < E && t < nrej; t++) { pairs[2 * (nacc + t)] = pij[2 * rej[t]]; pairs[2 * (nacc + t) + 1] = pij[2 * rej[t] + 1]; }
             if (cliquey) {
                 // groups of tree measurements = correlated edges (src/pseudo_chow_liu.cpp:62-85, fillCliques :198-251);
@@ -774,14 +881,20 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                 if (nout == k - 1) for (int i = 0; i < 2 * nout; i++) pairs[i] = tmp[i];
                 }
             }
-            const int upto = min(last + 1, P2 - 1);
+        }
+        __syncthreads();
+        {
+            // smallest relative gap between consecutive weights up to the last accepted pair
+            const int upto = min(si[6] + 1, P2 - 1);
             double g = __builtin_inf();
-            for (int s = 0; s < upto; s++) {
-                const double x = -w[order[s]], y = -w[order[s + 1]];
+            for (int s2 = tid; s2 < upto; s2 += NT) {
+                const double x = -w[order[s2]], y = -w[order[s2 + 1]];
                 const double den = fmax(fmax(fabs(x), fabs(y)), 1e-300);
                 g = fmin(g, (x - y) / den);
             }
-            sc[0] = g;
+            red[tid] = g;
+            __syncthreads();
+            if (tid == 0) { for (int t = 1; t < NT; t++) g = fmin(g, red[t]); sc[0] = g; }
         }
         __syncthreads();
         min_gap = sc[0];
@@ -922,7 +1035,14 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     if (!gauge_ok) {
     for (int it = tid; it < n * n; it += NT) A1[it] = Lam[it];
     __syncthreads();
-    if (!jacobi_eigh<NT>(T, A1, Vv, n, n, hot + L.T1)) { status = SPG_ST_EIG_FAIL; finish(); return; }
+    {
+        // spectrum of a cluster's target (n of several hundred: Jacobi sweeps out of L2 take tens of seconds) by
+        // tridiagonalisation + implicit QL; needs 8 n doubles of LDS, which the launch has free when the hot buffers do not
+        // fit there anyway. Small targets keep the Jacobi route the LDS kernels and the oracle share.
+        const bool eig_big = big && n >= 128 && hot == ws + L.cold_total && 8LL * n <= (long long)a.lds_doubles && (long long)n * r >= 3LL * n && n <= 8 * NT;
+        const bool eig_ok = eig_big ? tridiag_eigh<NT>(T, A1, Vv, n, n, hot + L.T1, lds_pool) : jacobi_eigh<NT>(T, A1, Vv, n, n, hot + L.T1);
+        if (!eig_ok) { status = SPG_ST_EIG_FAIL; finish(); return; }
+    }
     {
         int *perm = reinterpret_cast<int *>(hot + L.T1);     // n ints
         sort_ascending<NT>(T, A1, n + 1, n, perm);
@@ -990,6 +1110,12 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     // LogdetFunction::value (src/logdet_function.cpp:119-133) of the product information held in Ai (full symmetric):
     // M = U^T A U, 1/2 (tr(M S) - log det M - log det S - r); leaves chol(M) in Mc
     auto value_from_A = [&](bool &ok) -> double {
+        if (big && closed) {       // (the interior point keeps its own, order-sensitive evaluation)
+            team_gemm<NT>(T, T1, r, Ai, n, false, U, r, false, n, r, n, 0, false, panel);         // T1 = A U
+            team_gemm<NT>(T, M, r, U, r, true, T1, r, false, r, r, n, 0, true, panel);            // M = U^T (A U), lower block triangle
+            for (long long it = tid; it < (long long)r * r; it += NT) { const int i = (int)(it / r), j = (int)(it - (long long)i * r); if (j > i) M[it] = M[(long long)j * r + i]; }
+            __syncthreads();
+        } else {
         for (int it = tid; it < n * r; it += NT) {
             const int i = it / r, c = it - i * r;
             double sacc = 0;
@@ -1008,6 +1134,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             }
         }
         __syncthreads();
+        }
         IPT(8);
         double tr = 0;
         for (int i = tid; i < r; i += NT) tr += M[i * r + i] * Sv[i];
@@ -1017,6 +1144,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         __syncthreads();
         IPT(10);
         if (r <= 32) chol_lower_reg<32>(tid, Mc, r, r, &flag_s);
+        else if (big && closed) chol_big(Mc, r, r, T1, (long long)n * r);
         else chol_lower<NT>(T, Mc, r, r);
         ok = flag_s == 0;
         __syncthreads();
@@ -1036,6 +1164,8 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         if (!gauge_ok) {
             for (int it = tid; it < n * r; it += NT) { const int c = it % r; T1[it] = U[it] * Sv[c]; }
             __syncthreads();
+            if (big) team_gemm<NT>(T, Sig, n, T1, r, false, U, r, true, n, n, r, 0, false, panel);      // Sigma = (U S) U^T
+            else
             for (int it = tid; it < n * n; it += NT) {
                 const int i = it / n, j = it - i * n;
                 if (j <= i) { double sacc = 0; for (int t = 0; t < r; t++) sacc += T1[i * r + t] * U[j * r + t]; Sig[i * n + j] = sacc; Sig[j * n + i] = sacc; }
@@ -1065,8 +1195,30 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             }
             __syncthreads();
             CFP(6);
-            if (big) team_gemm<NT>(T, Tm, n, Je, n, false, Sig, n, false, re, n, n, 0, false, panel);       // Tm = J Sigma
-            else {
+            // A row of J_e has two d x d blocks (the measurement's two poses): the four products with J_e below walk those
+            // blocks instead of the whole row — 12 terms instead of n per entry (dense on the matrix cores they were 110 ms of a
+            // 190-vertex cluster). inc: the measurements at each kept vertex (LDS; the Newton solve's vector is idle here).
+            int *incp = reinterpret_cast<int *>(colbuf), *inc = incp + 264, *icnt = inc + 528;
+            if (big) {
+                for (int v = tid; v <= k; v += NT) { incp[v] = 0; icnt[v] = 0; }
+                __syncthreads();
+                if (tid == 0) {
+                    for (int i = 0; i < nmg; i++) { incp[pairs[2 * (i0 + i)] + 1]++; incp[pairs[2 * (i0 + i) + 1] + 1]++; }
+                    for (int v = 0; v < k; v++) incp[v + 1] += incp[v];
+                    for (int i = 0; i < nmg; i++)
+                        for (int side = 0; side < 2; side++) { const int v = pairs[2 * (i0 + i) + side]; inc[incp[v] + icnt[v]++] = i; }
+                }
+                __syncthreads();
+                for (int it = tid; it < re * n; it += NT) {           // Tm = J Sigma
+                    const int pr = it / n, c = it - pr * n, i = pr / D;
+                    const int oa = pairs[2 * (i0 + i)] * D, ob = pairs[2 * (i0 + i) + 1] * D;
+                    double sacc = 0;
+#pragma unroll
+                    for (int y = 0; y < D; y++) sacc += Je[pr * n + oa + y] * Sig[(oa + y) * n + c] + Je[pr * n + ob + y] * Sig[(ob + y) * n + c];
+                    Tm[it] = sacc;
+                }
+                __syncthreads();
+            } else {
                 for (int it = tid; it < re * n; it += NT) {
                     const int pr = it / n, c = it - pr * n;
                     double sacc = 0;
@@ -1076,8 +1228,17 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                 __syncthreads();
             }
             CFP(7);
-            if (big) team_gemm<NT>(T, G, re, Tm, n, false, Je, n, true, re, re, n, 0, false, panel);        // G = (J Sigma) J^T
-            else {
+            if (big) {
+                for (int it = tid; it < re * re; it += NT) {          // G = (J Sigma) J^T
+                    const int pr = it / re, c = it - pr * re, j = c / D;
+                    const int oa = pairs[2 * (i0 + j)] * D, ob = pairs[2 * (i0 + j) + 1] * D;
+                    double sacc = 0;
+#pragma unroll
+                    for (int y = 0; y < D; y++) sacc += Tm[pr * n + oa + y] * Je[c * n + oa + y] + Tm[pr * n + ob + y] * Je[c * n + ob + y];
+                    G[it] = sacc;
+                }
+                __syncthreads();
+            } else {
                 for (int it = tid; it < re * re; it += NT) {
                     const int pr = it / re, c = it - pr * re;
                     double sacc = 0;
@@ -1098,8 +1259,27 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             CFP(11);
             // A += J_e^T X J_e
             if (big) {
-                team_gemm<NT>(T, Tm, n, X, re, false, Je, n, false, re, n, re, 0, false, panel);
-                team_gemm<NT>(T, Ai, n, Je, n, true, Tm, n, false, n, n, re, 1, false, panel);
+                for (int it = tid; it < re * n; it += NT) {           // Tm = X J
+                    const int pr = it / n, c = it - pr * n, v = c / D;
+                    double sacc = 0;
+                    for (int e2 = incp[v]; e2 < incp[v + 1]; e2++) {
+                        const int j = inc[e2];
+#pragma unroll
+                        for (int x = 0; x < D; x++) sacc += X[pr * re + j * D + x] * Je[(j * D + x) * n + c];
+                    }
+                    Tm[it] = sacc;
+                }
+                __syncthreads();
+                for (int it = tid; it < n * n; it += NT) {            // A += J^T (X J)
+                    const int r1 = it / n, c = it - r1 * n, v = r1 / D;
+                    double sacc = 0;
+                    for (int e2 = incp[v]; e2 < incp[v + 1]; e2++) {
+                        const int j = inc[e2];
+#pragma unroll
+                        for (int x = 0; x < D; x++) sacc += Je[(j * D + x) * n + r1] * Tm[(j * D + x) * n + c];
+                    }
+                    Ai[it] += sacc;
+                }
             } else {
                 for (int it = tid; it < re * n; it += NT) {
                     const int pr = it / n, c = it - pr * n;
@@ -1183,8 +1363,8 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         } else fv = value_from_A(okc);
         CFP(14);
 #ifdef SPG_CF_PROF
-        if (tid == 0 && k >= 40) printf("cf prof k=%d m=%d n=%d gauge=%d (us): assemble %lld | Hmm chol+W %lld | schur %lld | pattern %lld | skeleton+gauge %lld | eig %lld | group: zero+Je %lld, J Sig %lld, G %lld, chol %lld, tri inv %lld, gram %lld, A+= %lld | record %lld | value %lld\n",
-                                        k, m, n, (int)gauge_ok, cfp[0] / 100, cfp[1] / 100, cfp[2] / 100, cfp[3] / 100, cfp[4] / 100, cfp[5] / 100, cfp[6] / 100, cfp[7] / 100, cfp[8] / 100, cfp[9] / 100, cfp[10] / 100, cfp[11] / 100, cfp[12] / 100, cfp[13] / 100, cfp[14] / 100);
+        if (tid == 0 && k >= 40) printf("cf prof k=%d m=%d n=%d gauge=%d (us): assemble %lld | Hmm chol+W %lld | schur %lld | pattern: inverse %lld weights %lld sort %lld rest %lld | skeleton+gauge %lld | eig %lld | group: zero+Je %lld, J Sig %lld, G %lld, chol %lld, tri inv %lld, gram %lld, A+= %lld | record %lld | value %lld\n",
+                                        k, m, n, (int)gauge_ok, cfp[0] / 100, cfp[1] / 100, cfp[2] / 100, cfp[15] / 100, cfp[16] / 100, cfp[17] / 100, cfp[3] / 100, cfp[4] / 100, cfp[5] / 100, cfp[6] / 100, cfp[7] / 100, cfp[8] / 100, cfp[9] / 100, cfp[10] / 100, cfp[11] / 100, cfp[12] / 100, cfp[13] / 100, cfp[14] / 100);
 #endif
         tab_mode = true;
         n_new = ng;
