@@ -1056,12 +1056,14 @@ __device__ inline int big_shortcut_status(const int *flags, const double *stats,
 }
 // The truncating eigen route of glc_chol (src/topology_provider_glc.cpp:59-71) for a large blanket whose target fails the
 // shortcut's guard (rank-deficient beyond the gauge, or lambda_min < 1e-8): eigen-decomposition of the whole n x n
-// M = sym(Mt) by one workgroup (parallel-order Jacobi on matrices in HBM — the rare path: seconds at n ~ 600), rows
-// sqrt(lambda) v^T for lambda >= 1e-8 in ascending order, as the LDS kernels emit them. A, V: n x n scratch with leading
-// dimension lda; cs: n + 2 doubles, perm: n ints. flags[4] = 1 done / 2 no convergence, flags[5] = rows kept.
-__global__ __launch_bounds__(1024) void big_glc_eig_kernel(int *flags, const double *stats, const double *partial, int np, const double *Mt, int ldm, int n,
+// M = sym(Mt) by one workgroup (tridiagonalisation + implicit QL on matrices in HBM, spg_dev_la.hpp — the rare path: 0.3 s
+// at n ~ 600; parallel-order Jacobi below 128 variables, where SPG_FORCE_BIG sends test blankets), rows sqrt(lambda) v^T for
+// lambda >= 1e-8 in ascending order, as the LDS kernels emit them. A, V: n x n scratch with leading dimension lda;
+// cs: 3 n + 2 doubles, perm: n ints; dynamic LDS: 6 n doubles. flags[4] = 1 done / 2 no convergence, flags[5] = rows kept.
+__global__ __launch_bounds__(256) void big_glc_eig_kernel(int *flags, const double *stats, const double *partial, int np, const double *Mt, int ldm, int n,
                                                            int rmax, double *A, double *V, int lda, double *cs, int *perm, const double *meas, double *rec) {
-    constexpr int NT = 1024;
+    constexpr int NT = 256;
+    extern __shared__ double eig_lds[];
     __shared__ double red[NT / 64];
     __shared__ int flag_s;
     const int tid = threadIdx.x;
@@ -1075,7 +1077,8 @@ __global__ __launch_bounds__(1024) void big_glc_eig_kernel(int *flags, const dou
         A[(long long)i * lda + j] = 0.5 * (Mt[(long long)i * ldm + j] + Mt[(long long)j * ldm + i]);
     }
     T.sync();
-    if (!jacobi_eigh<NT>(T, A, V, n, lda, cs)) { if (tid == 0) flags[4] = 2; return; }
+    const bool eok = (n >= 128 && 6 * n * 8 <= 140 * 1024) ? tridiag_eigh<NT>(T, A, V, n, lda, cs, eig_lds) : jacobi_eigh<NT>(T, A, V, n, lda, cs);
+    if (!eok) { if (tid == 0) flags[4] = 2; return; }
     double *ev = cs;
     for (int i = tid; i < n; i += NT) ev[i] = A[(long long)i * lda + i];
     T.sync();
@@ -1428,9 +1431,12 @@ static int big_glc_dense_impl(hipStream_t s, const spg::DenseGraphIn &in, int m,
             // the eigen route, taken inside the kernel only when the shortcut's guard failed: A in Y (free since the left
             // multiplication), V and the small scratch in H (free since the Schur complement was read)
             double *Vs = H, *cs = Vs + (size_t)Ng * Ng;
-            int *perm = reinterpret_cast<int *>(cs + n + 2);
-            static_assert(TB >= 16, "the scratch behind V assumes N^2 - Ng^2 >= 2 n + 2");
-            hipLaunchKernelGGL(big_glc_eig_kernel, dim3(1), dim3(1024), 0, s, flags, (const double *)stats, (const double *)partial, np,
+            int *perm = reinterpret_cast<int *>(cs + 3 * n + 2);
+            static_assert(TB >= 16, "the scratch behind V assumes N^2 - Ng^2 >= 4 n + 2");
+            size_t eig_lds = n >= 128 ? (size_t)6 * n * 8 : 0;
+            if (eig_lds > 140 * 1024) eig_lds = 0;      // (beyond 2 986 variables: the Jacobi sweeps, which need no LDS)
+            if (eig_lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(big_glc_eig_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds));
+            hipLaunchKernelGGL(big_glc_eig_kernel, dim3(1), dim3(256), eig_lds, s, flags, (const double *)stats, (const double *)partial, np,
                                (const double *)Mt, Ng, n, n - D, Y, Vs, Ng, cs, perm, (const double *)meas, arena + new_off);
         }
         hipLaunchKernelGGL(big_out_record_kernel, dim3(1), dim3(256), 0, s, orec, (const int *)flags, (const double *)stats, (const double *)partial, np,

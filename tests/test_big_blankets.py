@@ -134,6 +134,37 @@ for e in range(len(he["kind"])):
 assert rows and all(r == nn - 3 - 1 for nn, r in rows), rows      # one direction beyond the gauge is cut at 1e-8
 worst = util.compare_edge_sets(3, oe, he)
 print(f"deficient ok: {len(rows)} GLC edges with (n, rows) = {rows}, worst rel err {worst:.2e}")
+# the same with a blanket of 135 variables, where the eigen route is the tridiagonal QL solver instead of Jacobi sweeps: a hub
+# with 45 neighbours, three of them measured in translation only, a chain among the others
+k = 45
+n = k + 1
+poses = np.zeros((n, 3))
+for i in range(1, n):
+    a = 2 * np.pi * i / k
+    poses[i] = [8 * np.cos(a), 8 * np.sin(a), a + rng.normal(scale=0.3)]
+ij, data = [], []
+weak = {7, 21, 40}
+for i in range(1, n):
+    ij.append((0, i)); data.append(np.concatenate([rel(0, i), trans if i in weak else full]))
+for i in range(1, n - 1):
+    if i in weak or i + 1 in weak: continue
+    ij.append((i, i + 1)); data.append(np.concatenate([rel(i, i + 1), full]))
+g = {"pose_dim": 3, "ids": np.arange(n, dtype=np.int32), "poses": poses, "edge_ij": np.array(ij, np.int32), "edge_data": np.array(data)}
+which = np.array([0], np.int32)
+og = oracle_lib.OracleGraph.from_dict(g)
+assert og.marginalize(which, opts) == 0
+assert (og.blankets()["status"] == 0).all(), og.blankets()
+hg = GraphWrapperHIP.from_dict(g, ctx=ctx, useGLC=True)
+st = hg.marginalizeNoOptimize(which, opts)
+assert st["n_bad_status"] == 0, st
+he, oe = hg.edges(), og.edges()
+glc = [e for e in range(len(he["kind"])) if he["kind"][e] == abi.EDGE_GLC]
+assert len(glc) == 1
+nn = 3 * (he["vert_off"][glc[0] + 1] - he["vert_off"][glc[0]])
+r2 = (he["data_off"][glc[0] + 1] - he["data_off"][glc[0]] - nn) // nn
+assert nn == 135 and r2 == nn - 3 - 3, (nn, r2)
+worst = util.compare_edge_sets(3, oe, he)
+print(f"deficient 135 ok: rows {r2} of {nn}, worst rel err {worst:.2e}")
 """
 
 
@@ -142,12 +173,13 @@ def test_dense_pipeline_truncating_eigen_route(tmp_path):
     """A blanket whose target is rank-deficient beyond the gauge (a pendant pose measured in translation only) fails the
     Cholesky shortcut's guard of the dense HBM pipeline; the truncating eigen route of glc_chol
     (src/topology_provider_glc.cpp:59-71) then cuts the spectrum at 1e-8 as the oracle does: same edges, n - d - 1 rows,
-    W^T W to 1e-9 (SPG_FORCE_BIG=1 in its own process, so that 9-variable blankets take that pipeline)."""
+    W^T W to 1e-9 (SPG_FORCE_BIG=1 in its own process, so that 9-variable blankets take that pipeline). Then a 135-variable
+    blanket with three such poses: the same through the tridiagonal QL solver the eigen route uses from 128 variables on."""
     script = tmp_path / "deficient.py"
     script.write_text(DEFICIENT)
     out = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    assert "deficient ok" in out.stdout
+    assert "deficient ok" in out.stdout and "deficient 135 ok" in out.stdout
     print(out.stdout)
 
 

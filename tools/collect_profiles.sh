@@ -25,4 +25,6 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 # GLC Tree on the bench graph and BASELINE config 4 (parking.g2o, NFR Tree): kernel stats behind the figures quoted in DESIGN.md
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_glc -o run -- python3 tools/glc_check.py > $OUT/prof_glc.log 2>&1 || true
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_parking -o run -- python3 bench.py --config parking --steps 5 --warmup 1 --no-cpu-baseline > $OUT/prof_parking.log 2>&1 || true
+# clusters of the generic NFR kernel: sphere.g2o and parking.g2o under CliqueyDense at full size
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cluster -o run -- python3 tools/cluster_bench.py sphere parking > $OUT/prof_cluster.log 2>&1 || true
 find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -name '*.csv' | head -20

@@ -102,7 +102,8 @@ for k, v in kernels.items():
 
 
 # block-sparse path at the headline size and the interior-point kernel (tools/sparse_bench.py, tools/ip_bench.py)
-for d, name in (("prof_sparse", "sparse_100k"), ("prof_ip", "interior_point"), ("prof_big", "big_blanket"), ("prof_glc", "glc_tree"), ("prof_parking", "parking")):
+for d, name in (("prof_sparse", "sparse_100k"), ("prof_ip", "interior_point"), ("prof_big", "big_blanket"), ("prof_glc", "glc_tree"), ("prof_parking", "parking"),
+                ("prof_cluster", "cluster")):
     try:
         shutil.copy(one(f"{d}/**/*kernel_stats.csv"), os.path.join(prof, f"{tag}_{name}_kernel_stats.csv"))
         lines = [l for l in open(os.path.join(out, f"{d}.log")) if l.startswith("{")]
