@@ -101,6 +101,7 @@ struct IpArgs {
     int64_t mail_base;
     int topology, lin_point, tag;
     int lds_doubles;          // dynamic LDS of the launch: a blanket whose hot buffers fit keeps them there
+    int eig_jacobi;           // diagnostic (SPG_EIG_JACOBI=1): Jacobi sweeps for the spectrum of large targets too
     int ip_untiled;           // diagnostic (SPG_IP_UNTILED=1): the column-at-a-time LDS factorisation instead of the register-tiled one
     double chord_ratio;
 };

@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         // spectrum of a cluster's target (n of several hundred: Jacobi sweeps out of L2 take tens of seconds) by
         // tridiagonalisation + implicit QL; needs 8 n doubles of LDS, which the launch has free when the hot buffers do not
         // fit there anyway. Small targets keep the Jacobi route the LDS kernels and the oracle share.
-        const bool eig_big = big && n >= 128 && hot == ws + L.cold_total && 8LL * n <= (long long)a.lds_doubles && (long long)n * r >= 3LL * n && n <= 8 * NT;
+        const bool eig_big = !a.eig_jacobi && big && n >= 128 && hot == ws + L.cold_total && 8LL * n <= (long long)a.lds_doubles && (long long)n * r >= 3LL * n && n <= 8 * NT;
         const bool eig_ok = eig_big ? tridiag_eigh<NT>(T, A1, Vv, n, n, hot + L.T1, lds_pool) : jacobi_eigh<NT>(T, A1, Vv, n, n, hot + L.T1);
         if (!eig_ok) { status = SPG_ST_EIG_FAIL; finish(); return; }
     }
@@ -2207,6 +2207,8 @@ int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int64_t hot_max)
     if (no_packed) a.lds_doubles = 9000;
     static const bool untiled = [] { const char *e = getenv("SPG_IP_UNTILED"); return e && e[0] == '1'; }();           // diagnostic: the column-at-a-time LDS factorisation
     a.ip_untiled = untiled ? 1 : 0;
+    static const bool eig_jacobi = [] { const char *e = getenv("SPG_EIG_JACOBI"); return e && e[0] == '1'; }();        // diagnostic: Jacobi sweeps at every size
+    a.eig_jacobi = eig_jacobi ? 1 : 0;
     const void *fn = D == 6 ? reinterpret_cast<const void *>(nfr_ip_kernel<6>) : reinterpret_cast<const void *>(nfr_ip_kernel<3>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
