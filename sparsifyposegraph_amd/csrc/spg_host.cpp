@@ -3001,6 +3001,11 @@ extern "C" int spg_graph_marginalize_ranks(spg_graph *g, const int32_t *which, i
 
 // tools/host_sim.cpp (declared in csrc/spg_internal.h, not part of the public ABI): the streaming driver of a context
 // with an injected backend talks to this port — host memory, with a thread of the tool playing the persistent worker.
+extern "C" int spg_debug_la(int op, int M, int N, int K, int flags, int mode, double *A, int ra, int lda, double *B, int rb, int ldb, double *C, int rc, int ldc, int *ok) {
+    if (!A || !B || !C || !ok || M <= 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return SPG_EINVAL;
+    return spg::hip_la_test(op, M, N, K, flags, mode, A, ra, lda, B, rb, ldb, C, rc, ldc, ok);
+}
+
 extern "C" int spg_debug_set_stream_port(spg_ctx *c, void *port) {
     if (!c || c->is_hip) return SPG_EINVAL;
     c->sim_port = (spg::StreamPort *)port;

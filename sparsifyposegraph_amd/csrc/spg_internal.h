@@ -73,6 +73,8 @@ int hip_dense_kld(void *stream, const DenseGraphIn &base, const DenseGraphIn &ot
 // One GLC Dense blanket too large for the LDS kernel, dense in HBM on the fp64 matrix cores (spg_dense.hip)
 int hip_big_glc_dense(void *stream, const DenseGraphIn &local_graph, int m, int k, int Nm, int64_t new_off, double *orec, int n_new_max, int tag,
                       double *seconds, double *flops, char *err, size_t errlen);
+// test harness of the generic kernel's workgroup linear algebra (csrc/spg_nfr_ip.hip: la_test_kernel), see spg_debug_la
+int hip_la_test(int op, int M, int N, int K, int flags, int mode, double *A, int ra, int lda, double *B, int rb, int ldb, double *C, int rc, int ldc, int *ok);
 // frees the scratch the large-blanket pipeline keeps between calls (device block + pinned staging); called when a backend goes
 void hip_big_release_scratch();
 int hip_dense_optimize(void *stream, const DenseGraphIn &in, int n, int iterations, double *stats, double *seconds,
@@ -119,3 +121,5 @@ void rccl_comm_destroy(void *handle);
 
 // tools/host_sim.cpp only (host-side timing of the streaming driver against a simulated device); not in include/spg.h
 extern "C" int spg_debug_set_stream_port(spg_ctx *ctx, void *stream_port);
+// (tests) one of the device linear-algebra routines of the generic NFR kernel on host arrays; device 0 must be usable
+extern "C" int spg_debug_la(int op, int M, int N, int K, int flags, int mode, double *A, int ra, int lda, double *B, int rb, int ldb, double *C, int rc, int ldc, int *ok);

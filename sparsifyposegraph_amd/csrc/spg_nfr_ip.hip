@@ -2183,6 +2183,29 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     finish();
 }
 
+
+// Test harness of the workgroup routines above (tests/test_device_la.py through spg_debug_la): one workgroup, matrices in
+// device memory, the launch's dynamic LDS as the kernel itself has it. op 0: C = / += / -= op(A) op(B) (flags: 1 ta, 2 tb,
+// 4 lower_only; mode); 1: A <- chol(A) blocked; 2: A <- chol(A) in LDS panels; 3: B <- A^-1 for lower triangular A;
+// 4: eigen-decomposition of A (eigenvalues on its diagonal, vectors in B). ok[0] = 0 on failure.
+__global__ __launch_bounds__(NT) void la_test_kernel(int op, int M, int N, int K, int flags, int mode, double *A, int lda, double *B, int ldb,
+                                                      double *Cm, int ldc, double *tmp, int *ok) {
+    extern __shared__ double lds_pool[];
+    __shared__ double red[NT];
+    __shared__ int flag_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) flag_s = 0;
+    __syncthreads();
+    Team<NT> T{tid, red, &flag_s};
+    bool good = true;
+    if (op == 0) team_gemm<NT>(T, Cm, ldc, A, lda, (flags & 1) != 0, B, ldb, (flags & 2) != 0, M, N, K, mode, (flags & 4) != 0, lds_pool);
+    else if (op == 1) chol_lower_blocked<NT>(T, A, M, lda, tmp, lds_pool);
+    else if (op == 2) chol_lower_panel<NT>(T, A, M, lda, lds_pool);
+    else if (op == 3) tri_inverse_lower_blocked<NT>(T, A, lda, B, ldb, M, tmp, lds_pool);
+    else if (op == 4) good = tridiag_eigh<NT>(T, A, B, M, lda, tmp, lds_pool);
+    __syncthreads();
+    if (tid == 0) ok[0] = (good && flag_s == 0) ? 1 : 0;
+}
 }  // namespace
 
 namespace spg {
@@ -2217,6 +2240,34 @@ int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int64_t hot_max)
     if (D == 6) hipLaunchKernelGGL((nfr_ip_kernel<6>), dim3(count), dim3(NT), lds, s, a);
     else hipLaunchKernelGGL((nfr_ip_kernel<3>), dim3(count), dim3(NT), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : SPG_EHIP;
+}
+
+
+// host side of la_test_kernel: A (ra x lda), B (rb x ldb), C (rc x ldc) row-major host arrays, copied to the device, the kernel
+// run on the default stream of device 0, copied back. Returns 0, or SPG_EHIP / SPG_ENOMEM; *ok as the kernel left it.
+int hip_la_test(int op, int M, int N, int K, int flags, int mode, double *A, int ra, int lda, double *B, int rb, int ldb, double *Cm, int rc, int ldc, int *ok) {
+    double *dA = nullptr, *dB = nullptr, *dC = nullptr, *dT = nullptr;
+    int *dok = nullptr;
+    const size_t sa = (size_t)std::max(ra, 1) * lda * 8, sb = (size_t)std::max(rb, 1) * ldb * 8, sc2 = (size_t)std::max(rc, 1) * ldc * 8;
+    const size_t st = ((size_t)std::max(M, 64) + 64) * 65 * 8 + (size_t)3 * std::max(M, 1) * 8;
+    int rcode = 0;
+    const size_t lds = 140 * 1024;
+    if (hipMalloc(&dA, sa) != hipSuccess || hipMalloc(&dB, sb) != hipSuccess || hipMalloc(&dC, sc2) != hipSuccess || hipMalloc(&dT, st) != hipSuccess ||
+        hipMalloc(&dok, sizeof(int)) != hipSuccess) { rcode = SPG_ENOMEM; goto out; }
+    if (hipMemcpy(dA, A, sa, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dB, B, sb, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dC, Cm, sc2, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dT, 0, st) != hipSuccess) { rcode = SPG_EHIP; goto out; }
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(la_test_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { rcode = SPG_EHIP; goto out; }
+    hipLaunchKernelGGL(la_test_kernel, dim3(1), dim3(NT), lds, 0, op, M, N, K, flags, mode, dA, lda, dB, ldb, dC, ldc, dT, dok);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rcode = SPG_EHIP; goto out; }
+    if (hipMemcpy(A, dA, sa, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(B, dB, sb, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(Cm, dC, sc2, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(ok, dok, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rcode = SPG_EHIP;
+out:
+    if (dA) (void)hipFree(dA);
+    if (dB) (void)hipFree(dB);
+    if (dC) (void)hipFree(dC);
+    if (dT) (void)hipFree(dT);
+    if (dok) (void)hipFree(dok);
+    return rcode;
 }
 
 }  // namespace spg

@@ -14,6 +14,7 @@ void hip_backend_profile_read_big(spg_backend *, double *, double *, long long *
 int hip_backend_end_of_call(spg_backend *) { return 0; }
 int hip_stream_open(spg_backend *, int, int, int, StreamPort *) { return 1; }
 void hip_stream_close(spg_backend *, const StreamPort *, double, long long) {}
+int hip_la_test(int, int, int, int, int, int, double *, int, int, double *, int, int, double *, int, int, int *) { return SPG_ENODEV; }
 int hip_big_glc_dense(void *, const DenseGraphIn &, int, int, int, int64_t, double *, int, int, double *, double *, char *, size_t) { return SPG_ENODEV; }
 int hip_dense_information(void *, const DenseGraphIn &, int, double *, char *, size_t) { return SPG_ENODEV; }
 int hip_dense_covariance(void *, const DenseGraphIn &, int, double *, char *, size_t) { return SPG_ENODEV; }
