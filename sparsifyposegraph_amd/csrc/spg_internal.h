@@ -107,9 +107,10 @@ struct IpArgs {
     int ip_untiled;           // diagnostic (SPG_IP_UNTILED=1): the column-at-a-time LDS factorisation instead of the register-tiled one
     double chord_ratio;
 };
+constexpr int kIpMaxVars = 5200;     // Newton systems of the interior point: d^2 E up to this (k = 17 SE3 / 34 SE2 poses under Dense)
 int nfr_ip_pattern_size(int topology, double chord_ratio, int k);   // new edges of a blanket with k kept vertices (-1: correlated patterns)
 int64_t nfr_ip_workspace(int D, int k, int m, int E, int closed, int64_t *hot);  // doubles of workspace one such blanket needs (*hot: its LDS-eligible part)
-int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int64_t hot_max);
+int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int n_closed, int64_t hot_max);   // n_closed of the blankets have a closed-form pattern
 
 // RCCL binding (spg_rccl.cpp): librccl.so.1 is bound with dlopen when the first multi-rank context is created
 int rccl_get_unique_id(void *id_out, char *err, size_t errlen);

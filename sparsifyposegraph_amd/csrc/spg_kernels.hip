@@ -2047,6 +2047,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
     // NFR blankets whose pattern (Dense / Subgraph with more than k-1 edges) has no closed form: interior point, its own
     // kernel (spg_nfr_ip.hip), one workgroup per blanket after the launches below
     std::vector<int32_t> ip_list;
+    int ip_closed = 0;
     int64_t ip_stride = 0, ip_hot = 0;
     if (o.algorithm == SPG_ALG_NFR) {
         const bool cliquey = o.topology == SPG_TOPO_CLIQUEY_SUBGRAPH || o.topology == SPG_TOPO_CLIQUEY_DENSE;
@@ -2074,11 +2075,14 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
                 if (ip || (cliquey && k >= 3) || (has_multi && k >= 2) || local_cluster || too_big) {
                     const int msub = (int)((1 + o.chord_ratio) * (k - 1));
                     const bool masks = o.topology == SPG_TOPO_CLIQUEY_SUBGRAPH && msub < k * (k - 1) / 2;   // fillCliques on 64-bit vertex masks
-                    if ((ip && (int64_t)D * D * E > 2048) || (masks && k > 64) || k > 256) {
-                        snprintf(err, sizeof hb->err, "interior-point / correlated NFR: a blanket with k=%d kept vertices and %d new measurements is beyond the generic kernel (Hessian limit 2048^2; k <= 64 for CliqueySubgraph, 256 otherwise)", k, E);
+                    // (interior point: Newton systems up to 2 048 variables in LDS-resident forms, up to spg::kIpMaxVars through the
+                    //  blocked factorisation — one workgroup, 0.1 s per Newton step at 2 400 variables, 1 s at 4 900)
+                    if ((ip && (int64_t)D * D * E > spg::kIpMaxVars) || (masks && k > 64) || k > 256) {
+                        snprintf(err, sizeof hb->err, "interior-point / correlated NFR: a blanket with k=%d kept vertices and %d new measurements is beyond the generic kernel (Newton systems up to %d variables; k <= 64 for CliqueySubgraph, 256 otherwise)", k, E, spg::kIpMaxVars);
                         return SPG_ECAPACITY;
                     }
                     ip_list.push_back(b);
+                    if (!ip) ip_closed++;        // (closed form: every correlated pattern, trees with correlated input edges)
                     int64_t hot = 0;
                     ip_stride = std::max(ip_stride, spg::nfr_ip_workspace(D, k, m, E, ip ? 0 : 1, &hot));
                     ip_hot = std::max(ip_hot, hot);
@@ -2335,7 +2339,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
             ia.vpo = (const int64_t *)d_vpo2;
             ia.lin_point = SPG_LIN_GLOBAL;   // the scratch poses ARE the local linearisation point: taken as they are
         }
-        if (int rc2 = spg::hip_nfr_ip_launch((void *)S.stream, D, ia, (int)ip_list.size(), ip_hot)) { snprintf(err, sizeof hb->err, "launch of the interior-point kernel failed"); return rc2; }
+        if (int rc2 = spg::hip_nfr_ip_launch((void *)S.stream, D, ia, (int)ip_list.size(), ip_closed, ip_hot)) { snprintf(err, sizeof hb->err, "launch of the interior-point kernel failed"); return rc2; }
         // (this kernel comes AFTER the event a bin launch left in wait_ev: waiting for the slot must mean the whole stream.
         //  Until round 3 wait_slot returned when the bin kernel was done — with a cluster of 150 vertices still running in
         //  this one, the commit read whatever the mailbox held at its record's place: silently wrong graphs on parking.g2o

@@ -45,6 +45,7 @@ constexpr int RIF = 4;    // rows in flight per wavefront in the trailing update
 #else
 #define CFP(k) do { } while (0)
 #endif
+constexpr int kIpLdsVector = 2048;     // Newton systems up to this size can keep their running vector in static LDS (paths A, A', B, B')
 constexpr int kPanelDoubles = 8192;   // 64 KB: 16 columns of a panel up to 480 rows tall, fewer columns for taller ones
 
 struct IpLayout {   // offsets (doubles) of one blanket's buffers: a cold part in the global workspace, a hot part (everything the
@@ -61,7 +62,7 @@ __host__ __device__ inline IpLayout ip_layout(int D, int k, int m, int E, bool c
     int64_t o = 0;
     auto take = [&](int64_t len) { int64_t at = o; o += (len + 7) & ~(int64_t)7; return at; };
     const int64_t n = L.n, N = L.N, r = L.r > 0 ? L.r : 1, q = L.q, nx = L.nx, P2 = (int64_t)k * (k - 1) / 2;
-    L.H = take(N * N); L.Lam = take(n * n); L.A1 = take(n * n); L.V = take(n * n); L.Hx = take(closed ? 8 : (nx + 8) * (nx + 8));   // rows of nx + 8 doubles, nx + 8 of them: whole 8 x 8 tiles everywhere (no Newton iterations when the pattern has a closed form)
+    L.H = take(N * N); L.Lam = take(n * n); L.A1 = take(n * n); L.V = take(n * n); L.Hx = take(closed ? 8 : (nx + 8) * (nx + 8) + 64 * (nx + 8));   // rows of nx + 8 doubles, nx + 8 of them: whole 8 x 8 tiles everywhere (no Newton iterations when the pattern has a closed form)
     L.pose = take(12 * (int64_t)(k + m)); L.w = take(4 * P2 + 8);
     L.Sc = take(3 * N * N + 5 * n * n);            // correlated input edges (J, W J), closed form of correlated new edges (J_e, G, C, W, X)
     L.zbuf = take(7 * (int64_t)(E + 1)); L.grp = take(2 * (int64_t)k + 8); L.otab = take(8 * (int64_t)k + 8);
@@ -412,7 +413,12 @@ __device__ void chol_lower_panel(const Team<NT_> T, double *A, int n, int ld, do
     T.sync();
 }
 
-template <int D>
+// Two instantiations per pose dimension: CLOSED takes the blankets whose pattern has a closed form (every correlated pattern,
+// trees with correlated input edges — the cluster path with its matrix-core routines), the other one the interior point.
+// Each leaves the other's blankets alone, and the compiler drops the other's code: with both in one kernel the register
+// allocation of the interior point's two-tiles-per-thread factorisation degraded by half (sphere.g2o under Subgraph:
+// 3.3 -> 4.4 s) once the cluster routines had grown.
+template <int D, bool CLOSED>
 __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     constexpr int DD = D * D, PS = (D == 6) ? 7 : 3, PSZ = (D == 6) ? 12 : 3, REC = PS + D * (D + 1) / 2;
     extern __shared__ double lds_pool[];
@@ -420,7 +426,8 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     __shared__ int flag_s;
     __shared__ double sc[8];      // scalars broadcast by thread 0
     __shared__ int si[8];
-    __shared__ double colbuf[2048];   // running vector of the Newton solve (d^2 E <= 2048)
+    __shared__ double colbuf_s[2048];   // running vector of the Newton solve (d^2 E <= 2048)
+    double *const colbuf = colbuf_s;
     const int tid = threadIdx.x;
     const int b = a.list[blockIdx.x];
     const spg_blanket_desc bd = a.blk[b];
@@ -429,7 +436,8 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     const bool cliquey = a.topology == SPG_TOPO_CLIQUEY_SUBGRAPH || a.topology == SPG_TOPO_CLIQUEY_DENSE;
     // closed form (src/logdet_function.cpp:83-86): as many measurement rows as the target has rank — every correlated
     // pattern, and the uncorrelated ones that are trees (they come here when the blanket holds correlated input edges)
-    const bool closed = cliquey || E <= k - 1;
+    if ((cliquey || E <= k - 1) != CLOSED) return;        // the other instantiation's blanket
+    constexpr bool closed = CLOSED;
     const IpLayout L = ip_layout(D, k, m, E > 0 ? E : 1, closed);
     const int n = L.n, nm = L.nm, N = L.N, r = L.r, q = L.q, nx = L.nx;
     double *ws = a.ws + (int64_t)blockIdx.x * a.ws_stride;
@@ -444,6 +452,9 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     const bool hx_tiled = hx_lds && nx + 1 <= 176 && !a.ip_untiled;     // (A') below: the Hessian goes straight into register tiles
     const bool hx_tiled2 = !closed && !hx_tiled && nx + 1 > 176 && nx + 1 <= 248 && !a.ip_untiled;     // two tiles per thread, factor in the L2 workspace
     const bool hx_streamed = !closed && !hx_lds && !hx_tiled2 && ((nx + 8) >> 3) * 73 <= kPanelDoubles && !a.ip_untiled;   // (B') below: up to 895 variables
+    // (C): blocked Cholesky through team_gemm, running vector in dynamic LDS — everything beyond the streamed sizes (the
+    // column-panel form (B) it replaces needed 84 s for a 1 980-variable blanket that (C) does in 9; SPG_IP_UNTILED=1 keeps (B))
+    const bool hx_big = !closed && !hx_lds && !hx_tiled2 && !hx_streamed && (!a.ip_untiled || nx > kIpLdsVector);
     double *panel = lds_pool;
     const long long packed_pad = (packed_len + 1) & ~1LL;
     double *hot = hx_lds ? ((packed_pad + L.hot_total <= (int64_t)a.lds_doubles) ? lds_pool + packed_pad : ws + L.cold_total)
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     // Cholesky of a matrix of the closed-form path: out of L2 in panels once it is large (never while the interior point's
     // packed Hessian owns the dynamic LDS), the LDS-style routine otherwise
     // a cluster: its matrices live in the L2 workspace and the whole dynamic LDS is free for the blocked routines
-    const bool big = n >= 96 && !hx_lds && hot == ws + L.cold_total && kBlockedLds <= a.lds_doubles;
+    const bool big = CLOSED && n >= 96 && !hx_lds && hot == ws + L.cold_total && kBlockedLds <= a.lds_doubles;
     // Cholesky of a matrix of the closed-form path: blocked on the matrix cores once it is large (tmp: cap doubles of free
     // workspace, nn * 64 needed — else in LDS panels), the LDS routine for the small ones and whenever the interior
     // point's packed Hessian owns the dynamic LDS
@@ -1110,12 +1121,6 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     // LogdetFunction::value (src/logdet_function.cpp:119-133) of the product information held in Ai (full symmetric):
     // M = U^T A U, 1/2 (tr(M S) - log det M - log det S - r); leaves chol(M) in Mc
     auto value_from_A = [&](bool &ok) -> double {
-        if (big && closed) {       // (the interior point keeps its own, order-sensitive evaluation)
-            team_gemm<NT>(T, T1, r, Ai, n, false, U, r, false, n, r, n, 0, false, panel);         // T1 = A U
-            team_gemm<NT>(T, M, r, U, r, true, T1, r, false, r, r, n, 0, true, panel);            // M = U^T (A U), lower block triangle
-            for (long long it = tid; it < (long long)r * r; it += NT) { const int i = (int)(it / r), j = (int)(it - (long long)i * r); if (j > i) M[it] = M[(long long)j * r + i]; }
-            __syncthreads();
-        } else {
         for (int it = tid; it < n * r; it += NT) {
             const int i = it / r, c = it - i * r;
             double sacc = 0;
@@ -1134,7 +1139,6 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             }
         }
         __syncthreads();
-        }
         IPT(8);
         double tr = 0;
         for (int i = tid; i < r; i += NT) tr += M[i * r + i] * Sv[i];
@@ -1144,11 +1148,33 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
         __syncthreads();
         IPT(10);
         if (r <= 32) chol_lower_reg<32>(tid, Mc, r, r, &flag_s);
-        else if (big && closed) chol_big(Mc, r, r, T1, (long long)n * r);
         else chol_lower<NT>(T, Mc, r, r);
         ok = flag_s == 0;
         __syncthreads();
         IPT(9);
+        if (!ok) { if (tid == 0) flag_s = 0; __syncthreads(); return __builtin_inf(); }
+        double l = 0;
+        for (int i = tid; i < r; i += NT) l += log(Mc[i * r + i]);
+        l = T.sum(l);
+        return 0.5 * (tr - 2.0 * l - logdetS - r);
+    };
+    // the same value for a cluster on the eigen route, products and factorisation on the matrix cores. A function of its own:
+    // value_from_A sits inside every line-search step of the interior point, and the extra branches cost that loop 30 %
+    // (register allocation of the whole kernel) when they lived there.
+    auto value_from_A_cluster = [&](bool &ok) -> double {
+        team_gemm<NT>(T, T1, r, Ai, n, false, U, r, false, n, r, n, 0, false, panel);         // T1 = A U
+        team_gemm<NT>(T, M, r, U, r, true, T1, r, false, r, r, n, 0, true, panel);            // M = U^T (A U), lower block triangle
+        for (long long it = tid; it < (long long)r * r; it += NT) { const int i = (int)(it / r), j = (int)(it - (long long)i * r); if (j > i) M[it] = M[(long long)j * r + i]; }
+        __syncthreads();
+        double tr = 0;
+        for (int i = tid; i < r; i += NT) tr += M[i * r + i] * Sv[i];
+        tr = T.sum(tr);
+        for (int it = tid; it < r * r; it += NT) Mc[it] = M[it];
+        if (tid == 0) flag_s = 0;
+        __syncthreads();
+        chol_big(Mc, r, r, T1, (long long)n * r);
+        ok = flag_s == 0;
+        __syncthreads();
         if (!ok) { if (tid == 0) flag_s = 0; __syncthreads(); return __builtin_inf(); }
         double l = 0;
         for (int i = tid; i < r; i += NT) l += log(Mc[i * r + i]);
@@ -1360,7 +1386,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
             for (int i = tid; i < n; i += NT) l += log(A1[i * n + i]);
             l = T.sum(l);
             fv = okc ? 0.5 * (tr - 2.0 * l + logdetC - r) : __builtin_inf();
-        } else fv = value_from_A(okc);
+        } else fv = big ? value_from_A_cluster(okc) : value_from_A(okc);
         CFP(14);
 #ifdef SPG_CF_PROF
         if (tid == 0 && k >= 40) printf("cf prof k=%d m=%d n=%d gauge=%d (us): assemble %lld | Hmm chol+W %lld | schur %lld | pattern: inverse %lld weights %lld sort %lld rest %lld | skeleton+gauge %lld | eig %lld | group: zero+Je %lld, J Sig %lld, G %lld, chol %lld, tri inv %lld, gram %lld, A+= %lld | record %lld | value %lld\n",
@@ -1948,7 +1974,11 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     // out = L^-T y with y = row nn of the factorised matrix (= L^-1 rhs, see chol_rows), by ONE wavefront without
     // barriers: the running vector lives in LDS, a row of L is one coalesced read (the next row is fetched while the
     // current one is applied), right-looking: x_i = y_i / L_ii, then y_t -= L[i][t] x_i over the row.
-    auto solve_rows = [&](const double *Lc, int nn, double *out) {
+    // (the running vector: the static LDS array, or — path (C), more than 2 048 variables possible — the dynamic LDS; chosen at
+    //  compile time so that the accesses stay LDS instructions: through a pointer argument they became flat ones and the
+    //  streamed sizes that use this substitution lost 30 %)
+    auto solve_rows = [&](const double *Lc, int nn, double *out, auto big_c) {
+        double *const colbuf = decltype(big_c)::value ? lds_pool : colbuf_s;
         for (int it = tid; it < nn; it += NT) colbuf[it] = Lc[(long long)nn * ldh + it];
         __syncthreads();
         if (tid < 64) {
@@ -2106,6 +2136,23 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                                              : chol_solve_packed(nx, xn, dv);      // d = -(L L^T)^-1 g
                 IPT(2);
                 if (!hok) { hessian_failed = true; return; }
+            } else if (hx_big) {
+                // (C) Newton systems beyond the LDS vector (k = 12 SE3 poses under Dense: 2 376 variables): the blocked
+                // factorisation of the cluster path on the matrix cores. The right-hand side rides along as row nx as in (B) —
+                // with a pivot of its own that cannot fail, so that the factor of the bordered matrix carries L^-1 rhs in that
+                // row — and the substitution's running vector lives in the dynamic LDS the factorisation has left.
+                for (int it = tid; it < nx; it += NT) Hx[(long long)nx * ldh + it] = -g[it];
+                if (tid == 0) { Hx[(long long)nx * ldh + nx] = 1e300; flag_s = 0; }
+                __syncthreads();
+                chol_lower_blocked<NT>(T, Hx, nx + 1, ldh, Hx + (long long)(nx + 8) * ldh, lds_pool);
+                const bool hok = flag_s == 0;
+                __syncthreads();
+                if (tid == 0) flag_s = 0;
+                __syncthreads();
+                IPT(2);
+                if (!hok) { hessian_failed = true; return; }
+                solve_rows(Hx, nx, dv, std::true_type{});
+                IPT(3);
             } else {
                 for (int it = tid; it < nx; it += NT) Hx[(long long)nx * ldh + it] = -g[it];     // the right-hand side rides along as row nx
                 __syncthreads();
@@ -2113,7 +2160,7 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
                 IPT(2);
                 if (!hok) { hessian_failed = true; return; }
                 if (hx_streamed && nx <= 511) solve_reg(std::integral_constant<int, 8>{}, std::false_type{}, nx, dv);
-                else solve_rows(Hx, nx, dv);     // d = -(L L^T)^-1 g
+                else solve_rows(Hx, nx, dv, std::false_type{});     // d = -(L L^T)^-1 g
                 IPT(3);
             }
             double gd = 0, da = 0;
@@ -2218,7 +2265,7 @@ int64_t nfr_ip_workspace(int D, int k, int m, int E, int closed, int64_t *hot) {
     return L.total;
 }
 
-int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int64_t hot_max) {
+int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int n_closed, int64_t hot_max) {
     if (count <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     // dynamic LDS next to the 18 KB of static LDS: as much as the device gives one workgroup (packed Hessians up to
@@ -2232,14 +2279,21 @@ int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int64_t hot_max)
     a.ip_untiled = untiled ? 1 : 0;
     static const bool eig_jacobi = [] { const char *e = getenv("SPG_EIG_JACOBI"); return e && e[0] == '1'; }();        // diagnostic: Jacobi sweeps at every size
     a.eig_jacobi = eig_jacobi ? 1 : 0;
-    const void *fn = D == 6 ? reinterpret_cast<const void *>(nfr_ip_kernel<6>) : reinterpret_cast<const void *>(nfr_ip_kernel<3>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        (void)hipGetLastError();
-        return SPG_EHIP;
+    // n_closed of the count blankets have a closed form: each kind has its kernel (both walk the whole list and skip the
+    // other's blankets: the workspace slices stay indexed by the position in the list)
+    for (int closed = 0; closed < 2; closed++) {
+        if ((closed ? n_closed : count - n_closed) <= 0) continue;
+        const void *fn = D == 6 ? (closed ? reinterpret_cast<const void *>(nfr_ip_kernel<6, true>) : reinterpret_cast<const void *>(nfr_ip_kernel<6, false>))
+                                : (closed ? reinterpret_cast<const void *>(nfr_ip_kernel<3, true>) : reinterpret_cast<const void *>(nfr_ip_kernel<3, false>));
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return SPG_EHIP;
+        }
+        if (D == 6) { if (closed) hipLaunchKernelGGL((nfr_ip_kernel<6, true>), dim3(count), dim3(NT), lds, s, a); else hipLaunchKernelGGL((nfr_ip_kernel<6, false>), dim3(count), dim3(NT), lds, s, a); }
+        else { if (closed) hipLaunchKernelGGL((nfr_ip_kernel<3, true>), dim3(count), dim3(NT), lds, s, a); else hipLaunchKernelGGL((nfr_ip_kernel<3, false>), dim3(count), dim3(NT), lds, s, a); }
+        if (hipGetLastError() != hipSuccess) return SPG_EHIP;
     }
-    if (D == 6) hipLaunchKernelGGL((nfr_ip_kernel<6>), dim3(count), dim3(NT), lds, s, a);
-    else hipLaunchKernelGGL((nfr_ip_kernel<3>), dim3(count), dim3(NT), lds, s, a);
-    return hipGetLastError() == hipSuccess ? 0 : SPG_EHIP;
+    return 0;
 }
 
 

@@ -280,3 +280,43 @@ def test_factorisation_paths_are_bit_identical(tmp_path):
     assert int((a["info"] >> 8).sum()) > 50000
     for k in a.files:
         assert a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), k
+
+
+def _hub_blanket_against(ref_edges, ref_b, k, hip_ctx):
+    from sparsifyposegraph_amd.graph import GraphWrapperHIP
+    from tests.test_big_blankets import _star_graph
+    g = _star_graph(k, seed=5)
+    hg = GraphWrapperHIP.from_dict(g, ctx=hip_ctx)
+    st = hg.marginalizeNoOptimize(np.array([0], np.int32), abi.make_options(6, abi.ALG_NFR, abi.TOPO_DENSE))
+    hb = hg.blankets()
+    assert st["n_bad_status"] == 0 and np.array_equal(hb["status"], ref_b["status"])
+    worst = util.compare_edge_sets(6, ref_edges, hg.edges())            # 1e-9
+    kerr = float(np.abs(hb["kld"] - ref_b["kld"]).max())
+    print(f"hub with {k} neighbours under Dense: {36 * k * (k - 1) // 2} variables, Newton steps {hb['info'] >> 8} (oracle {ref_b['info'] >> 8}), "
+          f"KLD {hb['kld'][0]:.9g}, worst edge rel err {worst:.2e}, KLD abs err {kerr:.1e}")
+    assert np.array_equal(hb["info"], ref_b["info"])                    # Newton-step count and flags
+    assert kerr <= 1e-9
+    return hg
+
+
+@pytest.mark.gpu
+def test_device_interior_point_blocked_factorisation_matches_oracle(hip_ctx):
+    """Path (C) of the interior point — Newton systems beyond the streamed sizes, factorised in 64-wide block columns on the
+    matrix cores — against the oracle run here: the hub of an SE3 hub graph with 8 neighbours under Dense, 28 new edges =
+    1 008 variables (the oracle needs ~15 s for it). Informations and KLD to 1e-9, the Newton-step count equal."""
+    from tests.test_big_blankets import _star_graph
+    og = oracle_lib.OracleGraph.from_dict(_star_graph(8, seed=5))
+    assert og.marginalize(np.array([0], np.int32), abi.make_options(6, abi.ALG_NFR, abi.TOPO_DENSE)) == 0
+    _hub_blanket_against(og.edges(), og.blankets(), 8, hip_ctx)
+
+
+@pytest.mark.gpu
+def test_device_interior_point_beyond_2048_variables(hip_ctx):
+    """The size round 2 refused with SPG_ECAPACITY (parking.g2o under Dense fails there at k = 12): 12 SE3 neighbours, 66 new
+    edges = 2 376 variables, a 2 376^2 Newton system per step. Against the committed oracle result (the oracle needs three
+    minutes for this blanket: tests/golden/make_dense_ip_golden.py): 79 Newton steps on both sides, informations and KLD 1e-9."""
+    import os
+    z = np.load(os.path.join(util.GOLDEN_DIR, "digest_hub_dense_ip.npz"))
+    ref_e = {k2: z[k2] for k2 in ("kind", "vert_off", "vert_ids", "data_off", "data")}
+    ref_b = {"status": z["status"], "kld": z["kld"], "info": z["info"]}
+    _hub_blanket_against(ref_e, ref_b, 12, hip_ctx)
