@@ -107,7 +107,8 @@ struct IpArgs {
     int ip_untiled;           // diagnostic (SPG_IP_UNTILED=1): the column-at-a-time LDS factorisation instead of the register-tiled one
     double chord_ratio;
 };
-constexpr int kIpMaxVars = 5200;     // Newton systems of the interior point: d^2 E up to this (k = 17 SE3 / 34 SE2 poses under Dense)
+constexpr int kIpMaxVars = 8400;     // Newton systems of the interior point: d^2 E up to this (k = 22 SE3 / 43 SE2 poses under Dense: what
+                                     // parking.g2o's largest blanket asks for); one workgroup factorises them: minutes per blanket at the top
 int nfr_ip_pattern_size(int topology, double chord_ratio, int k);   // new edges of a blanket with k kept vertices (-1: correlated patterns)
 int64_t nfr_ip_workspace(int D, int k, int m, int E, int closed, int64_t *hot);  // doubles of workspace one such blanket needs (*hot: its LDS-eligible part)
 int hip_nfr_ip_launch(void *stream, int D, IpArgs a, int count, int n_closed, int64_t hot_max);   // n_closed of the blankets have a closed-form pattern

@@ -2076,7 +2076,7 @@ static int hip_run_round(void *user, void *arena, const spg_round_desc *rd) {
                     const int msub = (int)((1 + o.chord_ratio) * (k - 1));
                     const bool masks = o.topology == SPG_TOPO_CLIQUEY_SUBGRAPH && msub < k * (k - 1) / 2;   // fillCliques on 64-bit vertex masks
                     // (interior point: Newton systems up to 2 048 variables in LDS-resident forms, up to spg::kIpMaxVars through the
-                    //  blocked factorisation — one workgroup, 0.1 s per Newton step at 2 400 variables, 1 s at 4 900)
+                    //  blocked factorisation — one workgroup, 0.1 s per Newton step at 2 400 variables, 1 s at 4 900, 5 s at 8 300)
                     if ((ip && (int64_t)D * D * E > spg::kIpMaxVars) || (masks && k > 64) || k > 256) {
                         snprintf(err, sizeof hb->err, "interior-point / correlated NFR: a blanket with k=%d kept vertices and %d new measurements is beyond the generic kernel (Newton systems up to %d variables; k <= 64 for CliqueySubgraph, 256 otherwise)", k, E, spg::kIpMaxVars);
                         return SPG_ECAPACITY;
