@@ -1059,7 +1059,7 @@ __device__ inline int big_shortcut_status(const int *flags, const double *stats,
 // M = sym(Mt) by one workgroup (tridiagonalisation + implicit QL on matrices in HBM, spg_dev_la.hpp — the rare path: 0.3 s
 // at n ~ 600; parallel-order Jacobi below 128 variables, where SPG_FORCE_BIG sends test blankets), rows sqrt(lambda) v^T for
 // lambda >= 1e-8 in ascending order, as the LDS kernels emit them. A, V: n x n scratch with leading dimension lda;
-// cs: 3 n + 2 doubles, perm: n ints; dynamic LDS: 6 n doubles. flags[4] = 1 done / 2 no convergence, flags[5] = rows kept.
+// cs: 3 n + 2 doubles, perm: n ints; dynamic LDS: 6 n + 8 doubles. flags[4] = 1 done / 2 no convergence, flags[5] = rows kept.
 __global__ __launch_bounds__(256) void big_glc_eig_kernel(int *flags, const double *stats, const double *partial, int np, const double *Mt, int ldm, int n,
                                                            int rmax, double *A, double *V, int lda, double *cs, int *perm, const double *meas, double *rec) {
     constexpr int NT = 256;
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(256) void big_glc_eig_kernel(int *flags, const doub
         A[(long long)i * lda + j] = 0.5 * (Mt[(long long)i * ldm + j] + Mt[(long long)j * ldm + i]);
     }
     T.sync();
-    const bool eok = (n >= 128 && 6 * n * 8 <= 140 * 1024) ? tridiag_eigh<NT>(T, A, V, n, lda, cs, eig_lds) : jacobi_eigh<NT>(T, A, V, n, lda, cs);
+    const bool eok = (n >= 128 && (6 * n + 8) * 8 <= 140 * 1024) ? tridiag_eigh<NT>(T, A, V, n, lda, cs, eig_lds) : jacobi_eigh<NT>(T, A, V, n, lda, cs);
     if (!eok) { if (tid == 0) flags[4] = 2; return; }
     double *ev = cs;
     for (int i = tid; i < n; i += NT) ev[i] = A[(long long)i * lda + i];
@@ -1433,7 +1433,7 @@ static int big_glc_dense_impl(hipStream_t s, const spg::DenseGraphIn &in, int m,
             double *Vs = H, *cs = Vs + (size_t)Ng * Ng;
             int *perm = reinterpret_cast<int *>(cs + 3 * n + 2);
             static_assert(TB >= 16, "the scratch behind V assumes N^2 - Ng^2 >= 4 n + 2");
-            size_t eig_lds = n >= 128 ? (size_t)6 * n * 8 : 0;
+            size_t eig_lds = n >= 128 ? ((size_t)6 * n + 8) * 8 : 0;
             if (eig_lds > 140 * 1024) eig_lds = 0;      // (beyond 2 986 variables: the Jacobi sweeps, which need no LDS)
             if (eig_lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(big_glc_eig_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds));
             hipLaunchKernelGGL(big_glc_eig_kernel, dim3(1), dim3(256), eig_lds, s, flags, (const double *)stats, (const double *)partial, np,

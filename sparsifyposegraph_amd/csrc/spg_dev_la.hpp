@@ -204,17 +204,18 @@ __device__ __forceinline__ void rr_pair(int s, int pi, int n2, int &p, int &q) {
 // Jacobi sweeps below take tens of seconds): Householder tridiagonalisation, Q formed explicitly, implicit-shift QL on
 // the tridiagonal matrix with the rotations applied to the columns of Q (the tred2 / tql2 pair, arranged for a workgroup).
 // A (n x n, full symmetric, destroyed: on exit its diagonal holds the eigenvalues, unordered), V receives the
-// eigenvectors in columns — the interface of jacobi_eigh. gl: 3 n doubles of global scratch (d, e, beta). lds: 6 n
+// eigenvectors in columns — the interface of jacobi_eigh. gl: 3 n doubles of global scratch (d, e, beta). lds: 6 n + 8
 // doubles. Returns false (uniformly) if an eigenvalue does not converge in 60 iterations. n <= 8 * NT.
 // One workgroup streaming matrices out of L2 is bound by the memory round trips it waits for, so every pass keeps many
 // independent accesses in flight per lane:
 //   * column sums (A v = A^T v, v^T V): wavefront w takes the rows i = w (mod 4), a lane up to 16 columns 64 apart, two
 //     rows per step — 32 loads in flight, no reduction across lanes; the four partial vectors meet in LDS;
 //   * rank-1 / rank-2 updates: the same tiling, loads of a step issued before its stores;
-//   * QL: wavefront 0 runs the scalar recurrence of a sweep (d, e in LDS) and leaves the rotations in LDS; then every lane
-//     applies them to the rows of V it owns, eight rotations and all its rows per step (a rotation of columns i, i + 1
-//     treats the rows independently). The first form — rotations applied as they were produced, one load and one store
-//     per rotation — waited a full memory round trip per rotation: 0.9 s of 1.4 s at n = 792.
+//   * QL: wavefront 0 runs the scalar recurrence of a sweep (d, e in LDS) and leaves the rotations in LDS; the other
+//     wavefronts apply the previous sweep's rotations to Q^T meanwhile — rows side by side, eight rotations and four entries
+//     per lane per step (a rotation of columns i, i + 1 of Q treats the rows independently). The first form — rotations
+//     applied to Q as they were produced, one load and one store per rotation, a lane per row — waited a full memory round
+//     trip per rotation and touched 64 cache lines per access: 0.9 s of 1.4 s at n = 792.
 template <int NT>
 __device__ bool tridiag_eigh(const Team<NT> T, double *A, double *V, int n, int ld, double *gl, double *lds) {
     constexpr int NW = NT / 64, CMAX = 16;
@@ -341,129 +342,138 @@ __device__ bool tridiag_eigh(const Team<NT> T, double *A, double *V, int n, int 
     // wavefront would touch 64 cache lines (measured: 1 us per rotation, three quarters of the whole decomposition)
     for (long long it = tid; it < (long long)n * n; it += NT) { const int rr = (int)(it / n), c = (int)(it - (long long)rr * n); A[(long long)c * ld + rr] = V[(long long)rr * ld + c]; }
     T.sync();
-    // ---------------------------------------------------------------- implicit QL (tql2)
-    double *d = lds, *e = lds + n, *csb = lds + 2 * n, *snb = lds + 3 * n;
-    int *ctl = reinterpret_cast<int *>(lds + 4 * n);       // [0] m, [1] lowest rotation index applied, [2] state: 0 sweep, 1 eigenvalue done, 2 failed
+    // ---------------------------------------------------------------- implicit QL (tql2), two stages in a pipeline
+    // Stage A (wavefront 0): the scalar recurrence of the next sweep — d, e and the sweep's rotations in LDS. Stage B (the other
+    // wavefronts): the previous sweep's rotations applied to Q^T. A sweep's rotations depend on d, e only, never on Q, so the two
+    // overlap; the rotation buffers alternate. (One after the other they took 198 + 145 ms at n = 792.)
+    double *d = lds, *e = lds + n;
+    double *csb2[2] = {lds + 2 * n, lds + 4 * n}, *snb2[2] = {lds + 3 * n, lds + 5 * n};
+    int *ctl = reinterpret_cast<int *>(lds + 6 * n);       // per buffer: [0] m, [1] lowest rotation index, [2] state: 0 sweep, 1 all done, 2 failed
     for (int i = tid; i < n; i += NT) { d[i] = dg[i]; e[i] = eg[i]; }
     T.sync();
     constexpr int RC = 4, U8 = 8;                    // entries of a row of Q^T per lane and pass, rotations per step
-    const int nrows = (n - tid + NT - 1) / NT;       // entries tid, tid + NT, ...
+    constexpr int NTB = NT - 64;                     // lanes of stage B
+    const int tb = tid - 64;                         // stage B's lane index
+    const int nrows = tb >= 0 ? (n - tb + NTB - 1) / NTB : 0;     // entries tb, tb + NTB, ...
     bool ok = true;
 #ifdef SPG_CF_PROF
-    long long tA = 0, tB = 0, nsweep = 0, nrot = 0, tl = wall_clock64();
+    long long nsweep = 0, nrot = 0;
 #endif
-    for (int l = 0; l < n && ok; l++) {
-        int iter = 0;
-        for (;;) {
-            if (wv == 0) {
-                // the scalar recurrence of one sweep (every lane of the wavefront computes it; lane 0's stores count)
-                int m = l;
+    int l = 0, iter = 0, cur = 0;     // (stage A's state, kept by every lane of wavefront 0)
+    bool pending = false;             // a sweep in buffer cur ^ 1 waits for stage B
+    int pm = 0, plo = 0;
+    for (;;) {
+        if (wv == 0) {
+            // ---- stage A: advance to the next sweep (or to the end) and leave it in buffer `cur`
+            int state = 1, m = 0, lo = 0;
+            double *csb = csb2[cur], *snb = snb2[cur];
+            while (l < n) {
+                m = l;
                 for (; m < n - 1; m++) {
                     const double dd = fabs(d[m]) + fabs(d[m + 1]);
                     if (fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
                 }
-                int state = 0, lo = l;
-                if (m == l) state = 1;
-                else if (iter == 60) state = 2;
-                else {
-                    double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-                    double r = sqrt(g * g + 1.0);
-                    g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? r : -r));
-                    double sn = 1.0, cs = 1.0, pp = 0.0;
-                    bool underflow = false;
-                    int i = m - 1;
-                    // One wavefront alone: nothing hides the latency of a dependent operation, so the chain is kept short — the
-                    // next step's d, e are read a step ahead, 1 / r comes from the reciprocal square root (hardware seed + two Newton
-                    // steps; no division, no sqrt sequence), and all lanes store (same value, same address) instead of branching.
-                    double e_i = e[i], d_i = d[i], d_i1 = d[i + 1];
-                    for (; i >= l; i--) {
-                        const double e_n = (i > l) ? e[i - 1] : 0.0, d_n = (i > l) ? d[i - 1] : 0.0;
-                        const double f = sn * e_i, b = cs * e_i;
-                        const double h2 = f * f + g * g;
-                        if (h2 == 0.0) { e[i + 1] = 0.0; d[i + 1] = d_i1 - pp; e[m] = 0.0; underflow = true; break; }
-                        const double rinv = fast_rsqrt(h2);
-                        r = h2 * rinv;
-                        e[i + 1] = r;
-                        sn = f * rinv; cs = g * rinv;
-                        g = d_i1 - pp;
-                        r = (d_i - g) * sn + 2.0 * cs * b;
-                        pp = sn * r;
-                        d[i + 1] = g + pp;
-                        csb[i] = cs; snb[i] = sn;
-                        g = cs * r - b;
-                        // (d[i + 1] as the next step sees it is d[i] of this one, untouched so far in this sweep)
-                        d_i1 = d_i; d_i = d_n; e_i = e_n;
-                    }
-                    lo = i + 1;
-                    if (!underflow) { d[l] -= pp; e[l] = g; e[m] = 0.0; }
+                if (m == l) { l++; iter = 0; continue; }           // eigenvalue l has converged
+                if (iter++ == 60) { state = 2; break; }
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = sqrt(g * g + 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? r : -r));
+                double sn = 1.0, cs = 1.0, pp = 0.0;
+                bool underflow = false;
+                int i = m - 1;
+                // One wavefront alone: nothing hides the latency of a dependent operation, so the chain is kept short — the
+                // next step's d, e are read a step ahead, 1 / r comes from the reciprocal square root (hardware seed + two Newton
+                // steps; no division, no sqrt sequence), and all lanes store (same value, same address) instead of branching.
+                double e_i = e[i], d_i = d[i], d_i1 = d[i + 1];
+                for (; i >= l; i--) {
+                    const double e_n = (i > l) ? e[i - 1] : 0.0, d_n = (i > l) ? d[i - 1] : 0.0;
+                    const double f = sn * e_i, b = cs * e_i;
+                    const double h2 = f * f + g * g;
+                    if (h2 == 0.0) { e[i + 1] = 0.0; d[i + 1] = d_i1 - pp; e[m] = 0.0; underflow = true; break; }
+                    const double rinv = fast_rsqrt(h2);
+                    r = h2 * rinv;
+                    e[i + 1] = r;
+                    sn = f * rinv; cs = g * rinv;
+                    g = d_i1 - pp;
+                    r = (d_i - g) * sn + 2.0 * cs * b;
+                    pp = sn * r;
+                    d[i + 1] = g + pp;
+                    csb[i] = cs; snb[i] = sn;
+                    g = cs * r - b;
+                    // (d[i + 1] as the next step sees it is d[i] of this one, untouched so far in this sweep)
+                    d_i1 = d_i; d_i = d_n; e_i = e_n;
                 }
-                if (lane == 0) { ctl[0] = m; ctl[1] = lo; ctl[2] = state; }
+                lo = i + 1;
+                if (!underflow) { d[l] -= pp; e[l] = g; e[m] = 0.0; }
+                state = 0;
+                break;
             }
-            T.sync();
-#ifdef SPG_CF_PROF
-            { long long t_ = wall_clock64(); tA += t_ - tl; tl = t_; }
-#endif
-            const int m = ctl[0], lo = ctl[1], state = ctl[2];
-            if (state == 1) { T.sync(); break; }
-            if (state == 2) { ok = false; T.sync(); break; }
-            iter++;
-            // rotations i = m - 1 .. lo on rows (i, i + 1) of Q^T, for the entries of this lane: four entries at a time, eight
-            // rotations per step, the next step's loads issued before this step's stores (memory operations complete in
-            // order: loads behind stores would wait for the stores too — two round trips per step instead of a hidden one)
-            if (m - 1 >= lo) {
-                for (int t0 = 0; t0 < nrows; t0 += RC) {
-                    double zc[RC];
-                    int col[RC];
-                    bool live[RC];
+            if (lane == 0) { ctl[4 * cur] = m; ctl[4 * cur + 1] = lo; ctl[4 * cur + 2] = state; }
+        } else if (pending && pm - 1 >= plo) {
+            // ---- stage B: rotations i = m - 1 .. lo of the previous sweep on rows (i, i + 1) of Q^T, for the entries of this
+            // lane: four entries at a time, eight rotations per step, the next step's loads issued before this step's stores
+            // (memory operations complete in order: loads behind stores would wait for the stores too)
+            const int m = pm, lo = plo;
+            const double *csb = csb2[cur ^ 1], *snb = snb2[cur ^ 1];
+            for (int t0 = 0; t0 < nrows; t0 += RC) {
+                double zc[RC];
+                int col[RC];
+                bool live[RC];
 #pragma unroll
-                    for (int t = 0; t < RC; t++) { live[t] = t0 + t < nrows; col[t] = tid + (t0 + t) * NT; zc[t] = live[t] ? A[(long long)m * ld + col[t]] : 0.0; }
-                    double ba[RC][U8], bb[RC][U8];
-                    auto load = [&](int i0, double (&buf)[RC][U8]) {
+                for (int t = 0; t < RC; t++) { live[t] = t0 + t < nrows; col[t] = tb + (t0 + t) * NTB; zc[t] = live[t] ? A[(long long)m * ld + col[t]] : 0.0; }
+                double ba[RC][U8], bb[RC][U8];
+                auto load = [&](int i0, double (&buf)[RC][U8]) {
 #pragma unroll
-                        for (int t = 0; t < RC; t++)
+                    for (int t = 0; t < RC; t++)
 #pragma unroll
-                            for (int u = 0; u < U8; u++) buf[t][u] = (live[t] && i0 - u >= lo) ? A[(long long)(i0 - u) * ld + col[t]] : 0.0;
-                    };
-                    auto apply = [&](int i0, const double (&buf)[RC][U8]) {
+                        for (int u = 0; u < U8; u++) buf[t][u] = (live[t] && i0 - u >= lo) ? A[(long long)(i0 - u) * ld + col[t]] : 0.0;
+                };
+                auto apply = [&](int i0, const double (&buf)[RC][U8]) {
 #pragma unroll
-                        for (int u = 0; u < U8; u++) {
-                            const int i = i0 - u;
-                            if (i >= lo) {
-                                const double cs = csb[i], sn = snb[i];
+                    for (int u = 0; u < U8; u++) {
+                        const int i = i0 - u;
+                        if (i >= lo) {
+                            const double cs = csb[i], sn = snb[i];
 #pragma unroll
-                                for (int t = 0; t < RC; t++)
-                                    if (live[t]) {
-                                        A[(long long)(i + 1) * ld + col[t]] = sn * buf[t][u] + cs * zc[t];
-                                        zc[t] = cs * buf[t][u] - sn * zc[t];
-                                    }
-                            }
+                            for (int t = 0; t < RC; t++)
+                                if (live[t]) {
+                                    A[(long long)(i + 1) * ld + col[t]] = sn * buf[t][u] + cs * zc[t];
+                                    zc[t] = cs * buf[t][u] - sn * zc[t];
+                                }
                         }
-                    };
-                    int i0 = m - 1;
-                    load(i0, ba);
-                    while (i0 >= lo) {
-                        if (i0 - U8 >= lo) load(i0 - U8, bb);
-                        apply(i0, ba);
-                        i0 -= U8;
-                        if (i0 < lo) break;
-                        if (i0 - U8 >= lo) load(i0 - U8, ba);
-                        apply(i0, bb);
-                        i0 -= U8;
                     }
-#pragma unroll
-                    for (int t = 0; t < RC; t++) if (live[t]) A[(long long)lo * ld + col[t]] = zc[t];
+                };
+                int i0 = m - 1;
+                load(i0, ba);
+                while (i0 >= lo) {
+                    if (i0 - U8 >= lo) load(i0 - U8, bb);
+                    apply(i0, ba);
+                    i0 -= U8;
+                    if (i0 < lo) break;
+                    if (i0 - U8 >= lo) load(i0 - U8, ba);
+                    apply(i0, bb);
+                    i0 -= U8;
                 }
+#pragma unroll
+                for (int t = 0; t < RC; t++) if (live[t]) A[(long long)lo * ld + col[t]] = zc[t];
             }
-            T.sync();
-#ifdef SPG_CF_PROF
-            { long long t_ = wall_clock64(); tB += t_ - tl; tl = t_; nsweep++; nrot += m - lo; }
-#endif
         }
+        T.sync();
+        // the sweep stage A has just produced becomes stage B's next job; the one stage B has just applied is done
+        const int state = ctl[4 * cur + 2];
+        pending = state == 0;
+        pm = ctl[4 * cur]; plo = ctl[4 * cur + 1];
+#ifdef SPG_CF_PROF
+        if (pending) { nsweep++; nrot += pm - plo; }
+#endif
+        if (state == 2) ok = false;
+        if (state != 0) break;              // (nothing pending any more: the last sweep was applied in this very round)
+        cur ^= 1;                           // (stage A writes the other buffer and the other ctl slot next: no second barrier needed)
     }
     T.sync();
 #ifdef SPG_CF_PROF
     tq3 = wall_clock64();
-    if (tid == 0) printf("tridiag_eigh n=%d (us): tridiagonalise %lld, form Q %lld, QL %lld (recurrence %lld, rows %lld; %lld sweeps, %lld rotations)\n", n, (tq1 - tq0) / 100, (tq2 - tq1) / 100, (tq3 - tq2) / 100, tA / 100, tB / 100, nsweep, nrot);
+    if (tid == 0) printf("tridiag_eigh n=%d (us): tridiagonalise %lld, form Q %lld, QL %lld (%lld sweeps, %lld rotations)\n", n, (tq1 - tq0) / 100, (tq2 - tq1) / 100, (tq3 - tq2) / 100, nsweep, nrot);
 #endif
     for (long long it = tid; it < (long long)n * n; it += NT) { const int rr = (int)(it / n), c = (int)(it - (long long)rr * n); V[(long long)rr * ld + c] = A[(long long)c * ld + rr]; }
     T.sync();
