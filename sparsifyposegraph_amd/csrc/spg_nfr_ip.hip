@@ -712,6 +712,11 @@ __global__ __launch_bounds__(NT) void nfr_ip_kernel(spg::IpArgs a) {
     __syncthreads();
     for (int it = tid; it < n * n; it += NT) { const int i = it / n, j = it - i * n; if (j < i) Lam[it] = Lam[j * n + i]; }
     __syncthreads();
+    // the blanket's target information for the batch interface (spg_batch_result::target_info), as the blanket kernel leaves it
+    if (bd.tinfo_off >= 0) {
+        double *dst = arena + bd.tinfo_off;
+        for (int it = tid; it < n * n; it += NT) dst[it] = Lam[it];
+    }
     {
         double bad = 0;
         for (int it = tid; it < n * n; it += NT) if (!isfinite(Lam[it])) bad = 1;

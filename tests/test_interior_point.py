@@ -155,6 +155,10 @@ def test_device_interior_point_matches_oracle(case, topo, chord, hip_ctx, oracle
     print(f"{case} topo={topo}: {ip.sum()} interior-point blankets, worst information rel err {worst:.1e}, worst KLD abs err {kerr:.1e}, "
           f"Newton steps oracle {steps_r.mean():.1f} device {steps_g.mean():.1f}")
     assert worst <= 1e-9 and kerr <= 1e-9      # (the north star's bar; measured ~5e-12)
+    # the target information of the batch interface comes from the generic kernel too
+    for b in np.nonzero(ip)[0]:
+        lo, hi = ref["target_info_off"][b], ref["target_info_off"][b + 1]
+        assert util.rel_err(ref["target_info"][lo:hi], got["target_info"][lo:hi]) <= 1e-9
     assert np.array_equal(steps_r, steps_g)    # where a tolerance-terminated Newton run stops is part of the result
     assert np.array_equal(ref["info"][ip] & abi.INFO_IP_HESSIAN_NOT_PD, got["info"][ip] & abi.INFO_IP_HESSIAN_NOT_PD)   # a given-up barrier step is reported alike
     fin = ~ip & np.isfinite(ref["kld"])
