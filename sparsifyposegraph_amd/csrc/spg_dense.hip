@@ -1240,19 +1240,22 @@ void launch_tiles(const TileOp &op, hipStream_t s) {
 constexpr int OUTER = 8;   // 64-tiles per outer block
 // stop_tiles >= 0: factorise the first stop_tiles block columns only — the trailing block then holds the Schur complement
 // of the leading one (lower triangle), which is how a blanket's target information is formed (big blankets below).
-void potrf_lower(double *M, int N, double *linv /*64*64*/, int *bad, hipStream_t s, int stop_tiles = -1) {
+// linv_keep != nullptr: the inverses of the diagonal blocks are kept, block j at linv_keep + j * 64 * 64 (a triangular solve with
+// the factor then needs no pass of its own over the diagonal)
+void potrf_lower(double *M, int N, double *linv /*64*64*/, int *bad, hipStream_t s, int stop_tiles = -1, double *linv_keep = nullptr) {
     const int nt = N / TB;
     const int lim = stop_tiles < 0 ? nt : std::min(stop_tiles, nt);
     const long long ld = N;
     for (int J0 = 0; J0 < lim; J0 += OUTER) {
         const int J1 = std::min(lim, J0 + OUTER);
         for (int j = J0; j < J1; j++) {
-            hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(64), 0, s, M + (long long)j * TB * (ld + 1), N, linv, bad, 1);
+            double *lj = linv_keep ? linv_keep + (long long)j * TB * TB : linv;
+            hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(64), 0, s, M + (long long)j * TB * (ld + 1), N, lj, bad, 1);
             const int rem = nt - j - 1;
             if (rem == 0) break;
             double *panel = M + ((long long)(j + 1) * TB * ld + (long long)j * TB);
             // panel <- panel * L_jj^-T
-            TileOp trsm{panel, panel, linv, TB * ld, 0, TB * ld, 0, N, N, TB, rem, 1, 0, 0, 2};
+            TileOp trsm{panel, panel, lj, TB * ld, 0, TB * ld, 0, N, N, TB, rem, 1, 0, 0, 2};
             launch_tiles(trsm, s);
             // remaining columns of the outer block: M[j+1.., j+1..J1) -= panel * panel[0..J1-j-1]^T
             // (the few tiles above the diagonal that this rectangle covers are never read)
@@ -1277,9 +1280,10 @@ void potrf_lower(double *M, int N, double *linv /*64*64*/, int *bad, hipStream_t
 // Same two levels as the factorisation: inside an outer block of OUTER column tiles the columns are
 // scaled (product with L_cc^-T) and the later columns of the block updated with K = 64; the columns to
 // the right of the block take ONE update with K = 64 * OUTER.
-void rsolve_lower_transposed(double *Y, int ldy, const double *Ls, int ld, int Ng, double *linv_all, int *bad, hipStream_t s) {
+// have_linv: linv_all already holds the inverses of the diagonal blocks of Ls (potrf_lower with linv_keep)
+void rsolve_lower_transposed(double *Y, int ldy, const double *Ls, int ld, int Ng, double *linv_all, int *bad, hipStream_t s, bool have_linv = false) {
     const int nt = Ng / TB;
-    hipLaunchKernelGGL(diag_potrf_kernel, dim3(nt), dim3(64), 0, s, const_cast<double *>(Ls), ld, linv_all, bad, 0);
+    if (!have_linv) hipLaunchKernelGGL(diag_potrf_kernel, dim3(nt), dim3(64), 0, s, const_cast<double *>(Ls), ld, linv_all, bad, 0);
     for (int C0 = 0; C0 < nt; C0 += OUTER) {
         const int C1 = std::min(nt, C0 + OUTER);
         for (int c = C0; c < C1; c++) {
@@ -1422,8 +1426,8 @@ static int big_glc_dense_impl(hipStream_t s, const spg::DenseGraphIn &in, int m,
         if (Nr > n - D) hipLaunchKernelGGL(pad_identity_kernel, dim3((Nr - (n - D) + 255) / 256), dim3(256), 0, s, Mrel, Nr, n - D, Nr);
         hipLaunchKernelGGL(pad_identity_kernel, dim3((Nr + 255) / 256), dim3(256), 0, s, Yi, Nr, 0, Nr);
         // lambda_min(M_rel) > 1e-8 is proven by trace(M_rel^-1) = ||L^-T||_F^2 < 1e8
-        potrf_lower(Mrel, Nr, linv, flags + 2, s);
-        rsolve_lower_transposed(Yi, Nr, Mrel, Nr, Nr, linv_all, flags + 3, s);
+        potrf_lower(Mrel, Nr, linv, flags + 2, s, -1, linv_all);
+        rsolve_lower_transposed(Yi, Nr, Mrel, Nr, Nr, linv_all, flags + 3, s, true);
         hipLaunchKernelGGL(sumsq_kernel, dim3(np), dim3(256), 0, s, (const double *)Yi, Nr, n - D, partial);
         const long long rec_len = (long long)n + (long long)(n - D) * n;
         hipLaunchKernelGGL((big_write_record_kernel<D>), dim3(512), dim3(256), 0, s, (const double *)Mrel, Nr, n, (const double *)meas, arena + new_off);
