@@ -70,6 +70,10 @@ struct TileOp {
     int tri;       // 1: blockIdx.x enumerates the 128-tile pairs q <= p of a triangle
     int subtract;  // 1: C -= A B^T; 0: C = A B^T (C may alias A: A is consumed before C is written)
     int kchunks;   // K = 32 * kchunks (2 for a 64-wide panel; 16 for the 512-wide outer block)
+    // latency form only: the workgroup of tile (0, 0) goes on to factorise that tile (the next panel's diagonal block) and
+    // to write its inverse here — the factorisation chain loses one launch per panel
+    double *diag_linv;
+    int *diag_bad;
 };
 
 constexpr int KC = 32, LDK = 34;
@@ -166,73 +170,6 @@ __global__ __launch_bounds__(256, 2) void tile_abt_kernel(TileOp op) {
     int p = blockIdx.x, q = blockIdx.y;
     if (op.tri) tile_of(op, blockIdx.x, p, q);
     tile_abt_body(op, p, q, As, Bs);
-}
-
-// The same step for the steps of a factorisation chain, which have a handful of tiles and are waited for: what counts
-// is the time to the LAST tile, not the throughput. One workgroup per 64 x 64 tile (four times as many workgroups), its
-// four wavefronts split K: each reads its quarter of the two operands straight from memory in the fragment layout (no
-// LDS staging, no barrier in the loop — all loads of a wavefront are in flight together), the partial sums meet in LDS
-// and wavefront w finishes rows 16 w .. 16 w + 15 of the tile. (128 x 128 x 512 on one CU is 27 us of matrix-core time
-// alone; a 64 x 64 tile with K split four ways holds each wavefront for a sixteenth of that.)
-__global__ __launch_bounds__(256) void tile_abt_small_kernel(TileOp op) {
-    __shared__ double part[4][3][16][64];       // [owner block row x][source slot][4 block columns x 4 registers][lane]
-    int p = blockIdx.x, q = blockIdx.y;
-    if (op.tri) {
-        const int t = blockIdx.x;   // t = p(p+1)/2 + q over 64-tiles
-        p = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-        while ((p + 1) * (p + 2) / 2 <= t) p++;
-        while (p * (p + 1) / 2 > t) p--;
-        q = t - p * (p + 1) / 2;
-    }
-    const double *A = op.A + p * op.a_p;
-    const double *B = op.B + q * op.b_q;
-    double *C = op.C + p * op.c_p + q * op.c_q;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
-    const int kw = 8 * op.kchunks, kbeg = w * kw;      // K = 32 * kchunks, a quarter per wavefront
-    d4 acc[4][4];
-#pragma unroll
-    for (int x = 0; x < 4; x++)
-#pragma unroll
-        for (int y = 0; y < 4; y++) acc[x][y] = d4{0, 0, 0, 0};
-    const double *ga = A + (long long)li * op.lda + kbeg + lk, *gb = B + (long long)li * op.ldb + kbeg + lk;
-#pragma unroll 2
-    for (int k0 = 0; k0 < kw; k0 += 4) {
-        double a[4], b[4];
-#pragma unroll
-        for (int x = 0; x < 4; x++) {
-            a[x] = ga[(long long)(16 * x) * op.lda + k0];
-            b[x] = gb[(long long)(16 * x) * op.ldb + k0];
-        }
-#pragma unroll
-        for (int x = 0; x < 4; x++)
-#pragma unroll
-            for (int y = 0; y < 4; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
-    }
-    // block row x of the tile belongs to wavefront x: the other three park their partial sums for it
-#pragma unroll
-    for (int x = 0; x < 4; x++) {
-        if (x == w) continue;
-        const int slot = (w - x - 1) & 3;       // 0..2
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) part[x][slot][4 * y + r][lane] = acc[x][y][r];
-    }
-    __syncthreads();
-    // (the operands were read before the barrier: C may alias A as in the 128-tile kernel)
-#pragma unroll
-    for (int x = 0; x < 4; x++) {
-        if (x != w) continue;
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const double v = acc[x][y][r] + part[x][0][4 * y + r][lane] + part[x][1][4 * y + r][lane] + part[x][2][4 * y + r][lane];
-                const int row = 16 * x + lk + 4 * r, col = 16 * y + li;      // C/D layout of the f64 MFMA
-                double *dst = C + (long long)row * op.ldc + col;
-                *dst = op.subtract ? (*dst - v) : v;
-            }
-    }
 }
 
 // Factor the 64x64 diagonal block at Ajj (lower Cholesky, in place, strict upper zeroed) and write
@@ -367,6 +304,79 @@ __device__ __forceinline__ void diag_potrf_body(double *Ls /* LDS, 64 * 65 */, d
 __global__ __launch_bounds__(64) void diag_potrf_kernel(double *Ajj, int ld, double *Linv, int *bad, int factor) {
     __shared__ double Ls[TB * 65], Li[TB * 65];
     diag_potrf_body(Ls, Li, Ajj + (long long)blockIdx.x * TB * ((long long)ld + 1), ld, Linv + (long long)blockIdx.x * TB * TB, bad, factor);
+}
+
+// The same step for the steps of a factorisation chain, which have a handful of tiles and are waited for: what counts
+// is the time to the LAST tile, not the throughput. One workgroup per 64 x 64 tile (four times as many workgroups), its
+// four wavefronts split K: each reads its quarter of the two operands straight from memory in the fragment layout (no
+// LDS staging, no barrier in the loop — all loads of a wavefront are in flight together), the partial sums meet in LDS
+// and wavefront w finishes rows 16 w .. 16 w + 15 of the tile. (128 x 128 x 512 on one CU is 27 us of matrix-core time
+// alone; a 64 x 64 tile with K split four ways holds each wavefront for a sixteenth of that.)
+__global__ __launch_bounds__(256) void tile_abt_small_kernel(TileOp op) {
+    __shared__ double part[4][3][16][64];       // [owner block row x][source slot][4 block columns x 4 registers][lane]
+    int p = blockIdx.x, q = blockIdx.y;
+    if (op.tri) {
+        const int t = blockIdx.x;   // t = p(p+1)/2 + q over 64-tiles
+        p = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((p + 1) * (p + 2) / 2 <= t) p++;
+        while (p * (p + 1) / 2 > t) p--;
+        q = t - p * (p + 1) / 2;
+    }
+    const double *A = op.A + p * op.a_p;
+    const double *B = op.B + q * op.b_q;
+    double *C = op.C + p * op.c_p + q * op.c_q;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int kw = 8 * op.kchunks, kbeg = w * kw;      // K = 32 * kchunks, a quarter per wavefront
+    d4 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+        for (int y = 0; y < 4; y++) acc[x][y] = d4{0, 0, 0, 0};
+    const double *ga = A + (long long)li * op.lda + kbeg + lk, *gb = B + (long long)li * op.ldb + kbeg + lk;
+#pragma unroll 2
+    for (int k0 = 0; k0 < kw; k0 += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            a[x] = ga[(long long)(16 * x) * op.lda + k0];
+            b[x] = gb[(long long)(16 * x) * op.ldb + k0];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+#pragma unroll
+            for (int y = 0; y < 4; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+    }
+    // block row x of the tile belongs to wavefront x: the other three park their partial sums for it
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        if (x == w) continue;
+        const int slot = (w - x - 1) & 3;       // 0..2
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[x][slot][4 * y + r][lane] = acc[x][y][r];
+    }
+    __syncthreads();
+    // (the operands were read before the barrier: C may alias A as in the 128-tile kernel)
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        if (x != w) continue;
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double v = acc[x][y][r] + part[x][0][4 * y + r][lane] + part[x][1][4 * y + r][lane] + part[x][2][4 * y + r][lane];
+                const int row = 16 * x + lk + 4 * r, col = 16 * y + li;      // C/D layout of the f64 MFMA
+                double *dst = C + (long long)row * op.ldc + col;
+                *dst = op.subtract ? (*dst - v) : v;
+            }
+    }
+    if (op.diag_linv && p == 0 && q == 0) {
+        // the next panel's diagonal block is this tile: factorise it here (the partial-sum area is free by now)
+        __syncthreads();
+        double *Ls = &part[0][0][0][0];
+        if (w == 0) diag_potrf_body(Ls, Ls + TB * 65, C, op.ldc, op.diag_linv, op.diag_bad, 1);
+    }
 }
 
 // pad rows [n, N) of an N x N matrix get a unit diagonal
@@ -1219,17 +1229,19 @@ void launch_assemble(const GraphBufs &gb, double *M, int ld, hipStream_t s, doub
 
 constexpr int kSmallTileSteps = 128;   // steps of at most this many 128-tiles take tile_abt_small_kernel
 
-void launch_tiles(const TileOp &op, hipStream_t s) {
-    if (op.P64 <= 0 || op.Q64 <= 0) return;
+// returns true when the step also factorised its tile (0, 0) (op.diag_linv set and the latency form taken)
+bool launch_tiles(const TileOp &op, hipStream_t s) {
+    if (op.P64 <= 0 || op.Q64 <= 0) return false;
     const int gp = (op.P64 + 1) / 2, gq = (op.Q64 + 1) / 2;
     const int big_tiles = op.tri ? gp * (gp + 1) / 2 : gp * gq;
     if (big_tiles <= kSmallTileSteps) {      // a step that cannot fill the chip: latency form
         if (op.tri) hipLaunchKernelGGL(tile_abt_small_kernel, dim3(op.P64 * (op.P64 + 1) / 2), dim3(256), 0, s, op);
         else hipLaunchKernelGGL(tile_abt_small_kernel, dim3(op.P64, op.Q64), dim3(256), 0, s, op);
-        return;
+        return op.diag_linv != nullptr;
     }
     if (op.tri) hipLaunchKernelGGL(tile_abt_kernel, dim3(gp * (gp + 1) / 2), dim3(256), 0, s, op);
     else hipLaunchKernelGGL(tile_abt_kernel, dim3(gp, gq), dim3(256), 0, s, op);
+    return false;
 }
 
 // Blocked right-looking lower Cholesky of the N x N matrix M (N a multiple of 64), in place.
@@ -1246,11 +1258,14 @@ void potrf_lower(double *M, int N, double *linv /*64*64*/, int *bad, hipStream_t
     const int nt = N / TB;
     const int lim = stop_tiles < 0 ? nt : std::min(stop_tiles, nt);
     const long long ld = N;
+    auto linv_of = [&](int j) { return linv_keep ? linv_keep + (long long)j * TB * TB : linv; };
+    bool diag_done = false;      // the step that last updated the coming diagonal block has factorised it as well
     for (int J0 = 0; J0 < lim; J0 += OUTER) {
         const int J1 = std::min(lim, J0 + OUTER);
         for (int j = J0; j < J1; j++) {
-            double *lj = linv_keep ? linv_keep + (long long)j * TB * TB : linv;
-            hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(64), 0, s, M + (long long)j * TB * (ld + 1), N, lj, bad, 1);
+            double *lj = linv_of(j);
+            if (!diag_done) hipLaunchKernelGGL(diag_potrf_kernel, dim3(1), dim3(64), 0, s, M + (long long)j * TB * (ld + 1), N, lj, bad, 1);
+            diag_done = false;
             const int rem = nt - j - 1;
             if (rem == 0) break;
             double *panel = M + ((long long)(j + 1) * TB * ld + (long long)j * TB);
@@ -1258,21 +1273,25 @@ void potrf_lower(double *M, int N, double *linv /*64*64*/, int *bad, hipStream_t
             TileOp trsm{panel, panel, lj, TB * ld, 0, TB * ld, 0, N, N, TB, rem, 1, 0, 0, 2};
             launch_tiles(trsm, s);
             // remaining columns of the outer block: M[j+1.., j+1..J1) -= panel * panel[0..J1-j-1]^T
-            // (the few tiles above the diagonal that this rectangle covers are never read)
+            // (the few tiles above the diagonal that this rectangle covers are never read); its tile (0, 0) is the next
+            // panel's diagonal block
             const int inner = J1 - j - 1;
             if (inner > 0) {
                 double *sub = M + (long long)(j + 1) * TB * (ld + 1);
                 TileOp upd{sub, panel, panel, TB * ld, TB, TB * ld, TB * ld, N, N, N, rem, inner, 0, 1, 2};
-                launch_tiles(upd, s);
+                upd.diag_linv = linv_of(j + 1); upd.diag_bad = bad;
+                diag_done = launch_tiles(upd, s);
             }
         }
         const int rem = nt - J1;
         if (rem <= 0) break;
-        // trailing(lower) -= P * P^T with P = M[J1.., J0*64 .. J1*64)
+        // trailing(lower) -= P * P^T with P = M[J1.., J0*64 .. J1*64); its tile (0, 0) opens the next outer block — unless the
+        // factorisation stops here and that block is the Schur complement the caller wants
         double *P = M + ((long long)J1 * TB * ld + (long long)J0 * TB);
         double *trail = M + (long long)J1 * TB * (ld + 1);
         TileOp syrk{trail, P, P, TB * ld, TB, TB * ld, TB * ld, N, N, N, rem, rem, 1, 1, 2 * (J1 - J0)};
-        launch_tiles(syrk, s);
+        if (J1 < lim) { syrk.diag_linv = linv_of(J1); syrk.diag_bad = bad; }
+        diag_done = launch_tiles(syrk, s);
     }
 }
 
