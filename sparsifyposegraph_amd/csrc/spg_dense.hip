@@ -21,6 +21,7 @@
 #include <cstring>
 #include <limits>
 #include <cmath>
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -1560,8 +1561,13 @@ int hip_big_glc_dense(void *stream, const DenseGraphIn &in, int m, int k, int Nm
     const double n = (double)in.D * k, nm = (double)in.D * m, nr = n - in.D;
     // the n^3-class work on the matrix cores: H_mm Cholesky + panel solves + Schur update, M_rel Cholesky, L^-T
     if (flops) *flops = nm * nm * nm / 3.0 + nm * nm * n + nm * n * n + nr * nr * nr / 3.0 + nr * nr * nr / 3.0;
-    return in.D == 6 ? big_glc_dense_impl<6>((hipStream_t)stream, in, m, k, Nm, new_off, orec, n_new_max, tag, seconds, err, errlen)
-                     : big_glc_dense_impl<3>((hipStream_t)stream, in, m, k, Nm, new_off, orec, n_new_max, tag, seconds, err, errlen);
+    static const bool trace = [] { const char *e = getenv("SPG_BIG_TRACE"); return e && e[0] == '1'; }();      // diagnostic: host time of a call next to its device time
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = in.D == 6 ? big_glc_dense_impl<6>((hipStream_t)stream, in, m, k, Nm, new_off, orec, n_new_max, tag, seconds, err, errlen)
+                             : big_glc_dense_impl<3>((hipStream_t)stream, in, m, k, Nm, new_off, orec, n_new_max, tag, seconds, err, errlen);
+    if (trace) fprintf(stderr, "big blanket n=%d nm=%d: call %.3f ms, device %.3f ms\n", (int)n, (int)nm,
+                       1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), seconds ? 1e3 * *seconds : 0.0);
+    return rc;
 }
 
 // Global KLD. base.pos orders the baseline's variables [marginalised | pad | kept | pad] with the
